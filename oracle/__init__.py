@@ -1,0 +1,24 @@
+"""CPU oracle for the Camera + ResNet-101 hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported by the product
+package (``privacy-preserving-vision_amd/``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker.
+
+The oracle is a restatement (torch-CPU / numpy ops, identical arithmetic and
+dtype promotions) of the reference's learned-optics camera and ResNet-101
+encoder; every function cites the reference file:line it follows.
+
+Parity pin status
+-----------------
+* IC ``OpticsZernike`` / FD ``Camera`` / RAFT ``CorrBlock``: PINNED against
+  golden vectors generated in the build container by importing the reference's
+  own Python (``tests/golden/make_golden.py``; fixtures ``tests/golden/*.npz``).
+* Third-party arithmetic absent from /root/reference: ``poppy`` 1.0.3
+  ``zernike_basis`` and ``cv2.circle`` -- *parity unpinned* (no reference
+  fixture stores a basis or a mask); the golden generator feeds the reference
+  the oracle's own basis / Euclidean disk (``oracle/zernike.py``), and the
+  reference itself treats the basis as a cached ``.npy`` input.
+* ``Encoder`` (torchvision ResNet-101): torchvision is absent, *parity
+  unpinned* against torchvision; oracle = ``torch.nn`` restatement on CPU fp32.
+"""

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by importing the REFERENCE's own Python.
+
+Run in the build container only (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py all
+
+The reference needs three third-party modules that are not installed here and are not
+part of /root/reference: ``torchvision`` (only
+``transforms.Resize(interpolation=0)`` on tensors == legacy nearest), ``cv2`` (only
+``circle`` filled) and ``poppy`` (only ``zernike.zernike_basis``).  Minimal stand-ins
+for exactly those calls are registered in ``sys.modules`` below; the basis and the disk
+come from ``oracle/zernike.py`` (parity unpinned vs poppy / OpenCV, see oracle/__init__.py).
+Everything else that executes is the reference's code, unmodified, on torch CPU.
+"""
+import math
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def install_standins():
+    from oracle import zernike as oz
+
+    np.math = math                                    # numpy>=2 dropped np.math (IC Utils.py:213)
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.models = types.ModuleType("torchvision.models")
+    tv.utils = types.ModuleType("torchvision.utils")
+
+    class Resize:
+        def __init__(self, size, interpolation=0):
+            assert interpolation == 0
+            self.size = list(size)
+
+        def __call__(self, x):
+            return F.interpolate(x, size=self.size, mode="nearest")
+
+    tv.transforms.Resize = Resize
+    cv2 = types.ModuleType("cv2")
+    cv2.FILLED = -1
+
+    def circle(img, center, radius, color, thickness=-1, lineType=-1):
+        d = oz.filled_disk(img.shape[0], center, radius)
+        img[d] = color
+        return img
+
+    cv2.circle = circle
+    poppy = types.ModuleType("poppy")
+    poppy.zernike = types.ModuleType("poppy.zernike")
+    poppy.zernike.zernike_basis = lambda nterms, npix, outside=0.0: oz.zernike_basis(nterms, npix, outside)
+    for name, mod in [("torchvision", tv), ("torchvision.transforms", tv.transforms),
+                      ("torchvision.models", tv.models), ("torchvision.utils", tv.utils),
+                      ("cv2", cv2), ("poppy", poppy), ("poppy.zernike", poppy.zernike)]:
+        sys.modules[name] = mod
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), (t * t).sum().item(), t.max().item(), t.min().item()])
+
+
+# --------------------------------------------------------------------------- IC
+def gen_ic():
+    install_standins()
+    sys.path.insert(0, os.path.join(REF, "Image_Caption"))
+    os.makedirs("/tmp/ppv_golden_scratch", exist_ok=True)
+    os.chdir("/tmp/ppv_golden_scratch")               # the reference caches the basis as .npy in cwd
+    from Camera.Lens import OpticsZernike
+    from Camera import Utils as RU
+    cpu = torch.device("cpu")
+
+    def run(cam, img, prueba, seed_noise, w):
+        for p in (cam.zernike_coeffs_train, cam.zernike_coeffs_no_train2):
+            p.requires_grad_(True)
+            p.grad = None
+        torch.manual_seed(seed_noise)
+        sensor, psf, coeffs, loss = cam(img, None, prueba)
+        l_sensor = (sensor * w).sum()
+        g_sensor = torch.autograd.grad(l_sensor, [cam.zernike_coeffs_train, cam.zernike_coeffs_no_train2],
+                                       retain_graph=True)
+        g_sensor = torch.cat([g_sensor[0].reshape(1), g_sensor[1].reshape(-1)])
+        g_loss = None
+        if loss is not None:
+            g = torch.autograd.grad(loss, [cam.zernike_coeffs_train, cam.zernike_coeffs_no_train2])
+            g_loss = torch.cat([g[0].reshape(1), g[1].reshape(-1)])
+        return sensor, psf, coeffs, loss, g_sensor, g_loss
+
+    # ---- G1: tiny, every stage -------------------------------------------------
+    cam = OpticsZernike(input_shape=[None, 32, 32, 3], device=cpu, zernike_terms=15, patch_size=32,
+                        height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[112, 112],
+                        sample_interval=3e-06, upsample=False)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        cam.zernike_coeffs_train.fill_(-0.6)
+        cam.zernike_coeffs_no_train2.copy_((torch.rand(11, 1, 1, generator=g) - 0.5) * 0.4)
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    w = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    sensor, psf, coeffs, loss, g_sensor, _ = run(cam, img, None, 1, w)
+    torch.manual_seed(1)
+    noise = torch.rand([1, 112, 112, 1])
+    # stage-level outputs from the reference's own functions
+    psfs = psf.detach().permute(1, 2, 0, 3)
+    raw = RU.img_psf_conv(img, psfs)
+    otf = RU.psf2otf(psfs, output_size=[64, 64])
+    delta_psf = torch.zeros(32, 32, 1, 3)
+    delta_psf[16, 16] = 1.0
+    raw_delta = RU.img_psf_conv(img, delta_psf)
+    np.savez_compressed(os.path.join(HERE, "ic_tiny.npz"),
+                        img=img.numpy(), w=w.numpy(), noise_u01=noise.numpy(),
+                        coeffs=coeffs.detach().numpy(), volume=cam.zernike_volume.numpy(),
+                        sensor=sensor.detach().numpy(), psf=psf.detach().numpy(),
+                        raw=raw.numpy(), otf=otf.numpy(), raw_delta=raw_delta.numpy(),
+                        grad_sensor_w=g_sensor.numpy())
+    print("ic_tiny: sensor", stats(sensor), "psf sum", psf.sum().item())
+
+    # ---- G2: real size (train.py:64-66), coefficients of Camera/Model.pth ----------
+    cam = OpticsZernike(input_shape=[None, 256, 256, 3], device=cpu, zernike_terms=350, patch_size=256,
+                        height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[896, 896],
+                        sample_interval=3e-06, upsample=False)
+    ck = torch.load(os.path.join(REF, "Image_Caption/Camera/Model.pth"), map_location=cpu, weights_only=False)["model"]
+    tr = ck["optics.zernike_coeffs_train"]
+    img = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    w = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    out = {}
+    for tag in ("init", "modelpth"):
+        with torch.no_grad():
+            if tag == "modelpth":
+                cam.zernike_coeffs_no_train.copy_(ck["optics.zernike_coeffs_no_train"])
+                cam.zernike_coeffs_train.copy_(tr[0].reshape(1, 1))
+                cam.zernike_coeffs_no_train2.copy_(tr[1:])
+        sensor, psf, coeffs, loss, g_sensor, g_loss = run(cam, img, "3", 1, w)
+        out.update({
+            f"{tag}_coeffs": coeffs.detach().numpy().reshape(-1),
+            f"{tag}_psf": psf.detach().numpy(),                      # [1,256,256,3] f64, disk-masked
+            f"{tag}_loss": np.array(loss.item()),
+            f"{tag}_sensor_sub": sensor.detach()[:, :, ::8, ::8].numpy(),
+            f"{tag}_sensor_edge": sensor.detach()[:, :, :3, :].numpy(),
+            f"{tag}_sensor_stats": stats(sensor),
+            f"{tag}_grad_sensor_w": g_sensor.numpy(),
+            f"{tag}_grad_loss": g_loss.numpy(),
+        })
+        print("ic_real", tag, "loss", loss.item(), "sensor", stats(sensor))
+    out["noise_seed"] = np.array(1)
+    torch.manual_seed(1)
+    out["noise_stats"] = stats(torch.rand([1, 896, 896, 1]))
+    out["volume_sub"] = cam.zernike_volume[:, ::16, ::16].numpy()
+    out["volume_stats"] = stats(cam.zernike_volume)
+    np.savez_compressed(os.path.join(HERE, "ic_real.npz"), **out)
+
+
+# --------------------------------------------------------------------------- FD
+def gen_fd():
+    install_standins()
+    sys.path.insert(0, os.path.join(REF, "Face-DeId"))
+    from Camera.Optics import Camera
+    out = {}
+    for n, terms in ((64, 21), (256, 300), (512, 300)):
+        torch.manual_seed(3)
+        cam = Camera(device="cpu", N=n, zernike_terms=terms)
+        img = torch.rand(2, 3, n, n, generator=torch.Generator().manual_seed(0)) * 2 - 1
+        w = torch.rand(2, 3, n, n, generator=torch.Generator().manual_seed(5))
+        sensor = cam(img)
+        l = (sensor * w).sum() + 1e3 * cam.loss_rad + 1e6 * cam.centering_loss
+        grad, = torch.autograd.grad(l, [cam.Zer_train])
+        t = f"n{n}"
+        out[f"{t}_zer_train"] = cam.Zer_train.detach().numpy()
+        out[f"{t}_psfs"] = cam.psfs.detach().numpy()
+        out[f"{t}_loss_rad"] = np.array(cam.loss_rad.item())
+        out[f"{t}_centering_loss"] = np.array(cam.centering_loss.item())
+        out[f"{t}_sensor_sub"] = sensor.detach()[:, :, ::max(1, n // 32), ::max(1, n // 32)].numpy()
+        out[f"{t}_sensor_stats"] = stats(sensor)
+        out[f"{t}_grad"] = grad.numpy().reshape(-1)
+        if n == 64:
+            out[f"{t}_sensor"] = sensor.detach().numpy()
+            out[f"{t}_volume"] = cam.zernike_volume.numpy()
+        print("fd", n, "loss_rad", cam.loss_rad.item(), "cl", cam.centering_loss.item(), "sensor", stats(sensor),
+              "psf ch sums", cam.psfs.sum((0, 2, 3)).tolist())
+    np.savez_compressed(os.path.join(HERE, "fd.npz"), **out)
+
+
+# --------------------------------------------------------------------------- RAFT CorrBlock
+def gen_corr():
+    sys.path.insert(0, os.path.join(REF, "Face-DeId"))
+    from RAFT.core.corr import CorrBlock
+    g = torch.Generator().manual_seed(0)
+    f1 = torch.randn(1, 16, 16, 16, generator=g)
+    f2 = torch.randn(1, 16, 16, 16, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
+    coords = torch.stack([xs, ys], 0).float()[None] + 2.0 * torch.randn(1, 2, 16, 16, generator=g)
+    blk = CorrBlock(f1, f2, num_levels=4, radius=4)
+    out = blk(coords)
+    np.savez_compressed(os.path.join(HERE, "corr.npz"), f1=f1.numpy(), f2=f2.numpy(), coords=coords.numpy(),
+                        out=out.numpy(), pyr0=blk.corr_pyramid[0].numpy(), pyr3=blk.corr_pyramid[3].numpy())
+    print("corr", out.shape, stats(out))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "all":
+        for w in ("ic", "fd", "corr"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
+    else:
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr}[what]()

@@ -1,0 +1,70 @@
+"""ctypes binding of libppv_hip.so (include/ppv_hip.h).  The product path has NO fallback:
+if the shared object is missing or a symbol is absent, importing a kernel wrapper raises."""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libppv_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
+
+_c = ctypes
+_P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
+PROTOTYPES = {
+    "ppv_abi_version": (_I, []),
+    "ppv_init": (_I, []),
+    "ppv_fftconv_workspace_bytes": (_Z, [_I, _I, _I]),
+    "ppv_otf_elems": (_Z, [_I, _I]),
+    "ppv_otf_build": (_I, [_P, _I, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
+    "ppv_fftconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_fftconv_partials_per_image": (_I, [_I, _I, _I]),
+    "ppv_group_max": (_I, [_P, _P, _I, _I, _P]),
+    "ppv_div_by_group": (_I, [_P, _P, _L, _I, _P]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/ppv_hip.h."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppv_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"libppv_hip: {what} failed with status {status}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libppv_hip kernels need device tensors (no CPU path in the product)")

@@ -1,0 +1,49 @@
+// Immutable per-device constant tables for libppv_hip.so.
+#include "ppv_common.h"
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace {
+std::mutex g_mu;
+std::map<std::pair<int, int>, void*> g_tw32, g_tw64;
+
+template <typename T2, typename T>
+const void* get_table(std::map<std::pair<int, int>, void*>& cache, int N) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = cache.find({dev, N});
+    if (it != cache.end()) return it->second;
+    std::vector<T2> h(N);
+    for (int t = 0; t < N; ++t) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)t / (long double)N;
+        h[t].x = (T)cosl(a);
+        h[t].y = (T)sinl(a);
+    }
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(T2) * N) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(T2) * N, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    cache[{dev, N}] = d;
+    return d;
+}
+}  // namespace
+
+extern "C" {
+
+const void* ppv_twiddles_f32(int N) { return get_table<float2, float>(g_tw32, N); }
+const void* ppv_twiddles_f64(int N) { return get_table<double2, double>(g_tw64, N); }
+
+// Create every table the library can need on the current device (blocking). Returns 0 / <0.
+int ppv_init(void) {
+    const int n32[] = {256, 512};
+    for (int n : n32)
+        if (!ppv_twiddles_f32(n)) return PPV_ERR_INIT;
+    return PPV_OK;
+}
+
+int ppv_abi_version(void) { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,552 @@
+// Batched 2-D FFT image (x) PSF convolution for the learned-optics camera, gfx950.
+//
+// Replaces reference Image_Caption/Camera/Utils.py:251-297 (img_psf_conv + psf2otf:127-158)
+// and Face-DeId/Camera/Utils.py:7-12 (conv2D) with a three-kernel real-FFT pipeline:
+//
+//   rows_r2c   [planes][H][W] f32  -> S1 [planes][H][N/2] c64   (two rows per complex FFT;
+//                                       bin 0 packs (DC.re, Nyquist.re))
+//   cols_mul   S1 -> column FFT -> x OTF^T -> inverse column FFT -> S2 [planes][Hout][N/2]
+//              (16-column tile per workgroup, transposed through LDS, column kx==0 carries the
+//               two real DC/Nyquist columns packed as one complex column)
+//   rows_c2r   S2 -> two rows per inverse complex FFT -> real output, fused epilogue
+//              (IC: |.|, crop, nearest P-1 -> P index map, sign bits, partial max;
+//               FD: plain store, partial amax)
+//
+// The convolution geometry is "PSF centre at the origin": out(s,t) = sum psf[u,v] img[s+P/2-u, t+P/2-v],
+// which equals the reference's pad-129/127 + ifftshift + crop[pad+1:-pad] pipeline (the reference's
+// OTF centre at (1,1) and its crop offset cancel; proven by the delta-PSF golden in tests).
+// HBM traffic per plane (N=512, P=256): 0.25 + 0.5 + 0.5 + 0.5 + 0.5 + 0.25 MB = 2.5 MB.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft_wave.h"
+#include "ppv_common.h"
+
+namespace ppv {
+
+// ----------------------------------------------------------------------------- rows forward
+template <int R>
+__global__ __launch_bounds__(256) void rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out,
+                                                       const float2* __restrict__ twg, int planes, int H, int W,
+                                                       int ppw) {
+    constexpr int N = 64 * R, NH = N / 2;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < N; i += 256) s_tw[i] = twg[i];
+    __syncthreads();
+    const int ppp = (H + 1) >> 1;
+    const long total = (long)planes * ppp;
+    const long first = ((long)blockIdx.x * 4 + wave) * ppw;
+    for (int it = 0; it < ppw; ++it) {
+        const long pair = first + it;
+        if (pair >= total) break;
+        const int plane = (int)(pair / ppp), j = (int)(pair % ppp);
+        const int r0 = 2 * j;
+        const bool has_b = (r0 + 1) < H;
+        const float* pa = in + ((long)plane * H + r0) * W;
+        const float* pb = pa + W;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = lane + 64 * r;
+            const float a = (n < W) ? pa[n] : 0.f;
+            const float b = (has_b && n < W) ? pb[n] : 0.f;
+            u[r] = make_float2(a, b);
+        }
+        fft_wave<R>(u, s_scr[wave], s_tw, lane);
+        float2* oa = out + ((long)plane * H + r0) * NH;
+        float2* ob = oa + NH;
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const float2 z = u[q];
+            float2 m = shfl2(u[R - 1 - q], (64 - lane) & 63);
+            if (lane == 0) m = u[(R - q) % R];
+            float2 A = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+            float2 B = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
+            if (q == 0 && lane == 0) {
+                A = make_float2(z.x, u[R / 2].x);
+                B = make_float2(z.y, u[R / 2].y);
+            }
+            const int k = lane + 64 * q;
+            oa[k] = A;
+            if (has_b) ob[k] = B;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- column pass
+// otfT layout: [C][NH+1][N]  (kx-major, ky contiguous; entry kx == NH is the Nyquist column).
+template <int R>
+__global__ __launch_bounds__(512) void cols_mul_kernel(const float2* __restrict__ S1, float2* __restrict__ S2,
+                                                       const float2* __restrict__ otfT,
+                                                       const float2* __restrict__ twg, int C, int H_in, int row_off,
+                                                       int H_out, int conj_otf, float scale) {
+    constexpr int N = 64 * R, NH = N / 2, LD = 17;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[8][fft_scratch_elems<R>()];
+    __shared__ float2 s_tile[N * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int plane = blockIdx.y, tile = blockIdx.x, ch = plane % C;
+    for (int i = tid; i < N; i += 512) s_tw[i] = twg[i];
+    for (int idx = tid; idx < H_in * 8; idx += 512) {
+        const int row = idx >> 3, c4 = idx & 7;
+        const float4 v = *reinterpret_cast<const float4*>(&S1[((long)plane * H_in + row) * NH + tile * 16 + c4 * 2]);
+        s_tile[row * LD + c4 * 2] = make_float2(v.x, v.y);
+        s_tile[row * LD + c4 * 2 + 1] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = wave * 2 + cc;
+        const int kx = tile * 16 + c;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = lane + 64 * r;
+            u[r] = (row < H_in) ? s_tile[row * LD + c] : make_float2(0.f, 0.f);
+        }
+        fft_wave<R>(u, s_scr[wave], s_tw, lane);
+        const float2* o = otfT + ((long)ch * (NH + 1) + kx) * N;
+        if (kx == 0) {
+            const float2* on = otfT + ((long)ch * (NH + 1) + NH) * N;
+            float2 v[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const float2 z = u[q];
+                float2 m = shfl2(u[R - 1 - q], (64 - lane) & 63);
+                if (lane == 0) m = u[(R - q) % R];
+                const float2 A = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+                const float2 B = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
+                const int k = lane + 64 * q;
+                const float2 o0 = o[k], o1 = on[k];
+                const float2 pa = conj_otf ? cmul_conj(A, o0) : cmul(A, o0);
+                const float2 pb = conj_otf ? cmul_conj(B, o1) : cmul(B, o1);
+                v[q] = make_float2(pa.x - pb.y, pa.y + pb.x);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) u[q] = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const float2 w = o[lane + 64 * q];
+                u[q] = conj_otf ? cmul_conj(u[q], w) : cmul(u[q], w);
+            }
+        }
+        ifft_wave<R>(u, s_scr[wave], s_tw, lane);
+#pragma unroll
+        for (int q = 0; q < R; ++q) s_tile[(lane + 64 * q) * LD + c] = make_float2(u[q].x * scale, u[q].y * scale);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < H_out * 8; idx += 512) {
+        const int row = idx >> 3, c4 = idx & 7;
+        const float2 a = s_tile[(row_off + row) * LD + c4 * 2], b = s_tile[(row_off + row) * LD + c4 * 2 + 1];
+        *reinterpret_cast<float4*>(&S2[((long)plane * H_out + row) * NH + tile * 16 + c4 * 2]) =
+            make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// ----------------------------------------------------------------------------- rows inverse
+// MODE 0 (IC, Utils.py:289-295): out[plane][i][j] = |r(max(i-1,0), max(j-1,0))|, P = N/2 rows/cols,
+//         sign bits of r saved for the backward pass, per-workgroup max.
+// MODE 1 (FD / raw): out[plane][row][n] = r(row, n), n < N, per-workgroup max (signed).
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void rows_c2r_kernel(const float2* __restrict__ S2, float* __restrict__ out,
+                                                       unsigned long long* __restrict__ signs,
+                                                       float* __restrict__ partial_max,
+                                                       const float2* __restrict__ twg, int planes, int Hs, int ppw,
+                                                       float scale) {
+    constexpr int N = 64 * R, NH = N / 2;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
+    __shared__ float s_max[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < N; i += 256) s_tw[i] = twg[i];
+    __syncthreads();
+    const int ppp = (Hs + 1) >> 1;
+    const long total = (long)planes * ppp;
+    const long first = ((long)blockIdx.x * 4 + wave) * ppw;
+    float vmax = (MODE == 0) ? 0.f : -INFINITY;
+    for (int it = 0; it < ppw; ++it) {
+        const long pair = first + it;
+        if (pair >= total) break;
+        const int plane = (int)(pair / ppp), j = (int)(pair % ppp);
+        const int r0 = 2 * j, r1 = r0 + 1;
+        const bool has_b = r1 < Hs;
+        const float2* rowA = S2 + ((long)plane * Hs + r0) * NH;
+        const float2* rowB = rowA + NH;
+        const float2 zero = make_float2(0.f, 0.f);
+        float2 u[R];
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const int k = lane + 64 * q;
+            const float2 A = rowA[k], B = has_b ? rowB[k] : zero;
+            u[q] = make_float2(A.x - B.y, A.y + B.x);
+            if (q == 0 && lane == 0) u[q] = make_float2(A.x, B.x);
+        }
+#pragma unroll
+        for (int q = R / 2; q < R; ++q) {
+            const int kk = N - (lane + 64 * q);           // in [1, NH]
+            if (kk == NH) {                                // Nyquist: lane 0, q == R/2
+                const float2 A = rowA[0], B = has_b ? rowB[0] : zero;
+                u[q] = make_float2(A.y, B.y);
+            } else {
+                const float2 A = rowA[kk], B = has_b ? rowB[kk] : zero;
+                u[q] = make_float2(A.x + B.y, B.x - A.y);
+            }
+        }
+        ifft_wave<R>(u, s_scr[wave], s_tw, lane);
+        if (MODE == 0) {
+            constexpr int P = NH;
+            float* op = out + (long)plane * P * P;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int s = half ? r1 : r0;
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const int t = lane + 64 * q;
+                    const float r = (half ? u[q].y : u[q].x) * scale;
+                    const unsigned long long neg = __ballot(r < 0.f);
+                    if (s <= P - 2) {
+                        if (lane == 0) signs[((long)plane * P + s) * (R / 2) + q] = neg;
+                        const float v = fabsf(r);
+                        if (t <= P - 2) {
+                            vmax = fmaxf(vmax, v);
+                            float* orow = op + (long)(s + 1) * P;
+                            orow[t + 1] = v;
+                            if (t == 0) orow[0] = v;
+                            if (s == 0) {
+                                op[t + 1] = v;
+                                if (t == 0) op[0] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            float* op = out + ((long)plane * Hs + r0) * N;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int n = lane + 64 * q;
+                const float a = u[q].x * scale, b = u[q].y * scale;
+                op[n] = a;
+                vmax = fmaxf(vmax, a);
+                if (has_b) {
+                    op[N + n] = b;
+                    vmax = fmaxf(vmax, b);
+                }
+            }
+        }
+    }
+    if (partial_max) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) s_max[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) partial_max[blockIdx.x] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    }
+}
+
+// ----------------------------------------------------------------------------- OTF build
+// emb[ch][y][x] = psf(ch, (y+P/2) mod N, (x+P/2) mod N) if both < P else 0   (PSF centre -> origin).
+// psf element (ch,y,x) lives at psf[ch*sc + y*sy + x*sx] (f32 or f64: IC psf is NHWC f64 after the mask).
+template <typename T>
+__global__ void psf_embed_kernel(const T* __restrict__ psf, float* __restrict__ emb, int C, int P, int N, long sc,
+                                 long sy, long sx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * N * N) return;
+    const int x = (int)(i % N), y = (int)((i / N) % N), ch = (int)(i / ((long)N * N));
+    const int yy = (y + P / 2) % N, xx = (x + P / 2) % N;
+    emb[i] = (yy < P && xx < P) ? (float)psf[ch * sc + yy * sy + xx * sx] : 0.f;
+}
+
+// adjoint of psf_embed: grad_psf(ch,yy,xx) = gemb[ch][(yy - P/2) mod N][(xx - P/2) mod N]
+template <typename T>
+__global__ void psf_gather_kernel(const float* __restrict__ gemb, T* __restrict__ gpsf, int C, int P, int N, long sc,
+                                  long sy, long sx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * P * P) return;
+    const int xx = (int)(i % P), yy = (int)((i / P) % P), ch = (int)(i / ((long)P * P));
+    const int y = (yy - P / 2 + N) % N, x = (xx - P / 2 + N) % N;
+    gpsf[ch * sc + yy * sy + xx * sx] = (T)gemb[((long)ch * N + y) * N + x];
+}
+
+// one wave per (ch, kx) column of S1[ch][N][NH]: forward column FFT, written ky-contiguous.
+template <int R>
+__global__ __launch_bounds__(256) void cols_fwd_T_kernel(const float2* __restrict__ S1, float2* __restrict__ otfT,
+                                                         const float2* __restrict__ twg, int C) {
+    constexpr int N = 64 * R, NH = N / 2;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < N; i += 256) s_tw[i] = twg[i];
+    __syncthreads();
+    const int col = blockIdx.x * 4 + wave;
+    if (col >= C * NH) return;
+    const int ch = col / NH, kx = col % NH;
+    float2 u[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = S1[((long)ch * N + lane + 64 * r) * NH + kx];
+    fft_wave<R>(u, s_scr[wave], s_tw, lane);
+    float2* o = otfT + ((long)ch * (NH + 1) + kx) * N;
+    if (kx == 0) {
+        float2* on = otfT + ((long)ch * (NH + 1) + NH) * N;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const float2 z = u[q];
+            float2 m = shfl2(u[R - 1 - q], (64 - lane) & 63);
+            if (lane == 0) m = u[(R - q) % R];
+            o[lane + 64 * q] = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+            on[lane + 64 * q] = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q) o[lane + 64 * q] = u[q];
+    }
+}
+
+// ----------------------------------------------------------------------------- backward: d/d psf
+// For a batch chunk: acc[ch][kx][ky] += sum_b conj(FFTcol(X_b))[ky] * FFTcol(G_b)[ky]   (X = rows_r2c(img),
+// G = rows_r2c(grad)), written to part[chunk][C][NH+1][N].  One workgroup = (kx tile, ch, chunk).
+template <int R>
+__global__ __launch_bounds__(512) void cols_corr_acc_kernel(const float2* __restrict__ SX, const float2* __restrict__ SG,
+                                                            float2* __restrict__ part,
+                                                            const float2* __restrict__ twg, int B, int C, int HX,
+                                                            int HG, int bchunk) {
+    constexpr int N = 64 * R, NH = N / 2, LD = 17;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[8][fft_scratch_elems<R>()];
+    __shared__ float2 s_x[N / 2 * LD];      // IC path only: image and grad have P = N/2 rows
+    __shared__ float2 s_g[N / 2 * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x, ch = blockIdx.y, chunk = blockIdx.z;
+    for (int i = tid; i < N; i += 512) s_tw[i] = twg[i];
+    float2 acc[2][R], accn[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[0][q] = acc[1][q] = accn[q] = make_float2(0.f, 0.f);
+    const int b0 = chunk * bchunk, b1 = min(B, b0 + bchunk);
+    for (int b = b0; b < b1; ++b) {
+        const long plane = (long)b * C + ch;
+        __syncthreads();
+        for (int idx = tid; idx < HX * 8; idx += 512) {
+            const int row = idx >> 3, c4 = idx & 7;
+            const float4 v = *reinterpret_cast<const float4*>(&SX[(plane * HX + row) * NH + tile * 16 + c4 * 2]);
+            s_x[row * LD + c4 * 2] = make_float2(v.x, v.y);
+            s_x[row * LD + c4 * 2 + 1] = make_float2(v.z, v.w);
+        }
+        for (int idx = tid; idx < HG * 8; idx += 512) {
+            const int row = idx >> 3, c4 = idx & 7;
+            const float4 v = *reinterpret_cast<const float4*>(&SG[(plane * HG + row) * NH + tile * 16 + c4 * 2]);
+            s_g[row * LD + c4 * 2] = make_float2(v.x, v.y);
+            s_g[row * LD + c4 * 2 + 1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = wave * 2 + cc;
+            const int kx = tile * 16 + c;
+            float2 x[R], g[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = lane + 64 * r;
+                x[r] = (row < HX) ? s_x[row * LD + c] : make_float2(0.f, 0.f);
+                g[r] = (row < HG) ? s_g[row * LD + c] : make_float2(0.f, 0.f);
+            }
+            fft_wave<R>(x, s_scr[wave], s_tw, lane);
+            fft_wave<R>(g, s_scr[wave], s_tw, lane);
+            if (kx == 0) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    float2 mx = shfl2(x[R - 1 - q], (64 - lane) & 63), mg = shfl2(g[R - 1 - q], (64 - lane) & 63);
+                    if (lane == 0) { mx = x[(R - q) % R]; mg = g[(R - q) % R]; }
+                    const float2 xa = make_float2(0.5f * (x[q].x + mx.x), 0.5f * (x[q].y - mx.y));
+                    const float2 xb = make_float2(0.5f * (x[q].y + mx.y), -0.5f * (x[q].x - mx.x));
+                    const float2 ga = make_float2(0.5f * (g[q].x + mg.x), 0.5f * (g[q].y - mg.y));
+                    const float2 gb = make_float2(0.5f * (g[q].y + mg.y), -0.5f * (g[q].x - mg.x));
+                    acc[cc][q] = cadd(acc[cc][q], cmul_conj(ga, xa));
+                    accn[q] = cadd(accn[q], cmul_conj(gb, xb));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[cc][q] = cadd(acc[cc][q], cmul_conj(g[q], x[q]));
+            }
+        }
+    }
+    float2* pbase = part + ((long)chunk * C + ch) * (NH + 1) * N;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int kx = tile * 16 + wave * 2 + cc;
+#pragma unroll
+        for (int q = 0; q < R; ++q) pbase[(long)kx * N + lane + 64 * q] = acc[cc][q];
+        if (kx == 0) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) pbase[(long)NH * N + lane + 64 * q] = accn[q];
+        }
+    }
+}
+
+// one wave per (ch, kx): sum the chunk partials, inverse column FFT, store S2[ch][y][kx] (DC/Nyquist packed).
+template <int R>
+__global__ __launch_bounds__(256) void cols_inv_from_T_kernel(const float2* __restrict__ part, float2* __restrict__ S2,
+                                                              const float2* __restrict__ twg, int C, int nchunk,
+                                                              float scale) {
+    constexpr int N = 64 * R, NH = N / 2;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < N; i += 256) s_tw[i] = twg[i];
+    __syncthreads();
+    const int col = blockIdx.x * 4 + wave;
+    if (col >= C * NH) return;
+    const int ch = col / NH, kx = col % NH;
+    float2 u[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) u[q] = make_float2(0.f, 0.f);
+    for (int k = 0; k < nchunk; ++k) {
+        const float2* p = part + (((long)k * C + ch) * (NH + 1) + kx) * N;
+#pragma unroll
+        for (int q = 0; q < R; ++q) u[q] = cadd(u[q], p[lane + 64 * q]);
+        if (kx == 0) {
+            const float2* pn = part + (((long)k * C + ch) * (NH + 1) + NH) * N;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {          // pack P0 + i * Pnyq
+                const float2 w = pn[lane + 64 * q];
+                u[q] = make_float2(u[q].x - w.y, u[q].y + w.x);
+            }
+        }
+    }
+    ifft_wave<R>(u, s_scr[wave], s_tw, lane);
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        S2[((long)ch * N + lane + 64 * q) * NH + kx] = make_float2(u[q].x * scale, u[q].y * scale);
+}
+
+// ----------------------------------------------------------------------------- normalisation helpers
+__global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                        int per_group) {
+    __shared__ float s[4];
+    const float* p = partial + (long)blockIdx.x * per_group;
+    float v = -INFINITY;
+    for (int i = threadIdx.x; i < per_group; i += 256) v = fmaxf(v, p[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+}
+
+// x[g][i] /= m[g]   (true division as the reference: Lens.py:312, Optics.py:128)
+__global__ __launch_bounds__(256) void div_by_group_kernel(float* __restrict__ x, const float* __restrict__ m,
+                                                           long per_group4, int groups) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_group4 * groups) return;
+    const float d = m[i / per_group4];
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+    reinterpret_cast<float4*>(x)[i] = v;
+}
+
+}  // namespace ppv
+
+// =============================================================================== host launchers
+using namespace ppv;
+
+namespace {
+
+template <int R>
+int otf_build_t(const void* psf, int psf_is_f64, long sc, long sy, long sx, int C, int P, void* otfT, void* workspace,
+                hipStream_t stream) {
+    constexpr int N = 64 * R;
+    const float2* tw = (const float2*)ppv_twiddles_f32(N);
+    if (!tw) return PPV_ERR_INIT;
+    float* emb = (float*)workspace;
+    float2* S1 = (float2*)((char*)workspace + (size_t)C * N * N * sizeof(float));
+    const long tot = (long)C * N * N;
+    const unsigned ge = (unsigned)((tot + 255) / 256);
+    if (psf_is_f64)
+        psf_embed_kernel<double><<<ge, 256, 0, stream>>>((const double*)psf, emb, C, P, N, sc, sy, sx);
+    else
+        psf_embed_kernel<float><<<ge, 256, 0, stream>>>((const float*)psf, emb, C, P, N, sc, sy, sx);
+    const int ppw = 4;
+    const long pairs = (long)C * (N / 2);
+    rows_r2c_kernel<R><<<(unsigned)((pairs + 4 * ppw - 1) / (4 * ppw)), 256, 0, stream>>>(emb, S1, tw, C, N, N, ppw);
+    cols_fwd_T_kernel<R><<<(unsigned)((C * (N / 2) + 3) / 4), 256, 0, stream>>>(S1, (float2*)otfT, tw, C);
+    return ppv_last_error();
+}
+
+template <int R>
+int fftconv_fwd_t(const float* img, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
+                  int B, int C, int mode, int conj_otf, hipStream_t stream) {
+    constexpr int N = 64 * R;
+    const float2* tw = (const float2*)ppv_twiddles_f32(N);
+    if (!tw) return PPV_ERR_INIT;
+    const int H = (mode == 0) ? N / 2 : N;      // image rows == cols
+    const int planes = B * C;
+    float2* S1 = (float2*)workspace;
+    float2* S2 = S1 + (size_t)planes * H * (N / 2);
+    const int ppw = 4;
+    const long pairs = (long)planes * (H / 2);
+    const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
+    const float scale = 1.0f / ((float)N * (float)N);
+    rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(img, S1, tw, planes, H, H, ppw);
+    cols_mul_kernel<R><<<dim3(N / 32, planes), 512, 0, stream>>>(S1, S2, (const float2*)otfT, tw, C, H, 0, H, conj_otf,
+                                                                scale);
+    if (mode == 0)
+        rows_c2r_kernel<R, 0><<<g1, 256, 0, stream>>>(S2, out, (unsigned long long*)signs, partial_max, tw, planes, H,
+                                                      ppw, 1.f);
+    else
+        rows_c2r_kernel<R, 1><<<g1, 256, 0, stream>>>(S2, out, nullptr, partial_max, tw, planes, H, ppw, 1.f);
+    return ppv_last_error();
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+size_t ppv_fftconv_workspace_bytes(int B, int C, int N) {
+    // S1 + S2 for the batch (largest case: H = N rows) + OTF-build scratch
+    const size_t planes = (size_t)B * C;
+    const size_t s = planes * N * (N / 2) * sizeof(float2);
+    const size_t otf_scratch = (size_t)C * N * N * sizeof(float) + (size_t)C * N * (N / 2) * sizeof(float2);
+    return 2 * s + otf_scratch + 4096;
+}
+
+size_t ppv_otf_elems(int C, int N) { return (size_t)C * (N / 2 + 1) * N; }
+
+int ppv_otf_build(const void* psf, int psf_is_f64, long sc, long sy, long sx, int C, int P, int N, void* otfT,
+                  void* workspace, hipStream_t stream) {
+    if (!psf || !otfT || !workspace) return PPV_ERR_NULL;
+    if (P > N) return PPV_ERR_BAD_SIZE;
+    if (N == 512) return otf_build_t<8>(psf, psf_is_f64, sc, sy, sx, C, P, otfT, workspace, stream);
+    if (N == 256) return otf_build_t<4>(psf, psf_is_f64, sc, sy, sx, C, P, otfT, workspace, stream);
+    return PPV_ERR_BAD_SIZE;
+}
+
+int ppv_fftconv_fwd(const float* img, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
+                    int B, int C, int N, int mode, int conj_otf, hipStream_t stream) {
+    if (!img || !otfT || !out || !workspace) return PPV_ERR_NULL;
+    if (mode == 0 && !signs) return PPV_ERR_NULL;
+    if (N == 512) return fftconv_fwd_t<8>(img, otfT, out, signs, partial_max, workspace, B, C, mode, conj_otf, stream);
+    if (N == 256) return fftconv_fwd_t<4>(img, otfT, out, signs, partial_max, workspace, B, C, mode, conj_otf, stream);
+    return PPV_ERR_BAD_SIZE;
+}
+
+int ppv_fftconv_partials_per_image(int C, int N, int mode) {
+    const int H = (mode == 0) ? N / 2 : N;
+    return C * (H / 2) / 16;
+}
+
+int ppv_group_max(const float* partial, float* out, int groups, int per_group, hipStream_t stream) {
+    if (!partial || !out) return PPV_ERR_NULL;
+    group_max_kernel<<<groups, 256, 0, stream>>>(partial, out, per_group);
+    return ppv_last_error();
+}
+
+int ppv_div_by_group(float* x, const float* m, long per_group, int groups, hipStream_t stream) {
+    if (!x || !m) return PPV_ERR_NULL;
+    if (per_group % 4) return PPV_ERR_BAD_SIZE;
+    const long n4 = per_group / 4 * groups;
+    div_by_group_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>(x, m, per_group / 4, groups);
+    return ppv_last_error();
+}
+
+}  // extern "C"

@@ -24,6 +24,15 @@ PROTOTYPES = {
     "ppv_fftconv_partials_per_image": (_I, [_I, _I, _I]),
     "ppv_group_max": (_I, [_P, _P, _I, _I, _P]),
     "ppv_div_by_group": (_I, [_P, _P, _L, _I, _P]),
+    "ppv_fftconv_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
+    "ppv_sensor_dot_count": (_I, [_P, _P, _P, _L, _P]),
+    "ppv_fftconv_ic_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _P]),
+    "ppv_ic_psf_state_bytes": (_Z, [_I, _I, _I]),
+    "ppv_ic_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ppv_ic_psf_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
+    "ppv_zernike_max_order": (_I, []),
 }
 
 _lib = None

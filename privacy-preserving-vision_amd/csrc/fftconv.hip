@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512) void cols_mul_kernel(const float2* __restrict_
 // MODE 0 (IC, Utils.py:289-295): out[plane][i][j] = |r(max(i-1,0), max(j-1,0))|, P = N/2 rows/cols,
 //         sign bits of r saved for the backward pass, per-workgroup max.
 // MODE 1 (FD / raw): out[plane][row][n] = r(row, n), n < N, per-workgroup max (signed).
+// MODE 2 (IC adjoint): out[plane][row][n] = r(row, n), row, n < P = N/2.
 template <int R, int MODE>
 __global__ __launch_bounds__(256) void rows_c2r_kernel(const float2* __restrict__ S2, float* __restrict__ out,
                                                        unsigned long long* __restrict__ signs,
@@ -220,6 +221,15 @@ __global__ __launch_bounds__(256) void rows_c2r_kernel(const float2* __restrict_
                         }
                     }
                 }
+            }
+        } else if (MODE == 2) {
+            constexpr int P = NH;
+            float* op = out + ((long)plane * P + r0) * P;
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) {
+                const int n = lane + 64 * q;
+                op[n] = u[q].x * scale;
+                if (has_b) op[P + n] = u[q].y * scale;
             }
         } else {
             float* op = out + ((long)plane * Hs + r0) * N;
@@ -419,6 +429,54 @@ __global__ __launch_bounds__(256) void cols_inv_from_T_kernel(const float2* __re
         S2[((long)ch * N + lane + 64 * q) * NH + kx] = make_float2(u[q].x * scale, u[q].y * scale);
 }
 
+// ----------------------------------------------------------------------------- backward of Lens.py:312 + Utils.py:289-295
+// dotcnt[0] += sum g * sensor ; dotcnt[1] += #(sensor == 1)      (max() backward distributes evenly over ties)
+__global__ __launch_bounds__(256) void dot_count_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
+                                                        double* __restrict__ dotcnt, long n4) {
+    __shared__ double s_red[4][2];
+    double d = 0, c = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(g)[i], b = reinterpret_cast<const float4*>(sensor)[i];
+        d += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+        c += (b.x == 1.f) + (b.y == 1.f) + (b.z == 1.f) + (b.w == 1.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d += __shfl_xor(d, off, 64); c += __shfl_xor(c, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = d; s_red[threadIdx.x >> 6][1] = c; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        atomicAdd(&dotcnt[threadIdx.x], s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// gr[plane][s][t] = sign(r) * sum_{i in dup(s), j in dup(t)} (g[i][j] - [sensor[i][j]==1] dot/cnt) / M ; row/col P-1 = 0
+template <int R>
+__global__ __launch_bounds__(256) void ic_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
+                                                         const unsigned long long* __restrict__ signs,
+                                                         const float* __restrict__ maxv, const double* __restrict__ dotcnt,
+                                                         float* __restrict__ gr, long total) {
+    constexpr int P = 32 * R;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int t = (int)(idx % P), s = (int)((idx / P) % P);
+    const long plane = idx / ((long)P * P);
+    float out = 0.f;
+    if (s < P - 1 && t < P - 1) {
+        const float M = *maxv;
+        const float share = (float)(dotcnt[0] / dotcnt[1]);
+        const int i0 = (s == 0) ? 0 : s + 1, i1 = s + 1, j0 = (t == 0) ? 0 : t + 1, j1 = t + 1;
+        float acc = 0.f;
+        for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) {
+                const long o = (plane * P + i) * P + j;
+                const float gv = g[o] - ((sensor[o] == 1.f) ? share : 0.f);
+                acc += gv / M;
+            }
+        const unsigned long long bits = signs[(plane * P + s) * (R / 2) + (t >> 6)];
+        out = ((bits >> (t & 63)) & 1ull) ? -acc : acc;
+    }
+    gr[idx] = out;
+}
+
 // ----------------------------------------------------------------------------- normalisation helpers
 __global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                         int per_group) {
@@ -497,6 +555,54 @@ int fftconv_fwd_t(const float* img, const void* otfT, float* out, void* signs, f
     return ppv_last_error();
 }
 
+template <int R>
+int fftconv_bwd_t(const float* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
+                  const double* dotcnt, const void* otfT, void* g_psf, int is_f64, long sc, long sy, long sx,
+                  float* g_img, void* workspace, int B, int C, hipStream_t stream) {
+    constexpr int N = 64 * R, NH = N / 2, P = NH;
+    const float2* tw = (const float2*)ppv_twiddles_f32(N);
+    if (!tw) return PPV_ERR_INIT;
+    const int planes = B * C;
+    char* wp = (char*)workspace;
+    float* gr = (float*)wp;                 wp += (size_t)planes * P * P * sizeof(float);
+    float2* SX = (float2*)wp;               wp += (size_t)planes * P * NH * sizeof(float2);
+    float2* SG = (float2*)wp;               wp += (size_t)planes * P * NH * sizeof(float2);
+    const int nchunk = B < 16 ? B : 16;
+    const int bchunk = (B + nchunk - 1) / nchunk;
+    float2* part = (float2*)wp;             wp += (size_t)nchunk * C * (NH + 1) * N * sizeof(float2);
+    float2* S2 = (float2*)wp;               wp += (size_t)C * N * NH * sizeof(float2);
+    float* gemb = (float*)wp;
+    const long total = (long)planes * P * P;
+    ic_out_bwd_kernel<R><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(g_sensor, sensor, (const unsigned long long*)signs,
+                                                                             maxv, dotcnt, gr, total);
+    const int ppw = 4;
+    const long pairs = (long)planes * (P / 2);
+    const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
+    rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(gr, SG, tw, planes, P, P, ppw);
+    if (g_psf) {
+        rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(img, SX, tw, planes, P, P, ppw);
+        cols_corr_acc_kernel<R><<<dim3(N / 32, C, (B + bchunk - 1) / bchunk), 512, 0, stream>>>(SX, SG, part, tw, B, C, P, P,
+                                                                                           bchunk);
+        cols_inv_from_T_kernel<R><<<(unsigned)((C * NH + 3) / 4), 256, 0, stream>>>(part, S2, tw, C, (B + bchunk - 1) / bchunk,
+                                                                                  1.0f / ((float)N * (float)N));
+        const long cp = (long)C * (N / 2);
+        rows_c2r_kernel<R, 1><<<(unsigned)((cp + 4 * ppw - 1) / (4 * ppw)), 256, 0, stream>>>(S2, gemb, nullptr, nullptr, tw, C, N,
+                                                                                            ppw, 1.f);
+        const long tp = (long)C * P * P;
+        if (is_f64)
+            psf_gather_kernel<double><<<(unsigned)((tp + 255) / 256), 256, 0, stream>>>(gemb, (double*)g_psf, C, P, N, sc, sy, sx);
+        else
+            psf_gather_kernel<float><<<(unsigned)((tp + 255) / 256), 256, 0, stream>>>(gemb, (float*)g_psf, C, P, N, sc, sy, sx);
+    }
+    if (g_img) {   // adjoint convolution (Utils.py:285-286): SG x conj(OTF) -> plain P x P crop
+        float2* S2b = SX;   // SX is free again (or unused)
+        cols_mul_kernel<R><<<dim3(N / 32, planes), 512, 0, stream>>>(SG, S2b, (const float2*)otfT, tw, C, P, 0, P, 1,
+                                                                    1.0f / ((float)N * (float)N));
+        rows_c2r_kernel<R, 2><<<g1, 256, 0, stream>>>(S2b, g_img, nullptr, nullptr, tw, planes, P, ppw, 1.f);
+    }
+    return ppv_last_error();
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -547,6 +653,37 @@ int ppv_div_by_group(float* x, const float* m, long per_group, int groups, hipSt
     const long n4 = per_group / 4 * groups;
     div_by_group_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>(x, m, per_group / 4, groups);
     return ppv_last_error();
+}
+
+size_t ppv_fftconv_bwd_workspace_bytes(int B, int C, int N) {
+    const size_t planes = (size_t)B * C, P = N / 2, NH = N / 2;
+    const size_t nchunk = B < 16 ? B : 16;
+    return planes * P * P * sizeof(float) + 2 * planes * P * NH * sizeof(float2) +
+           nchunk * C * (NH + 1) * N * sizeof(float2) + (size_t)C * N * NH * sizeof(float2) +
+           (size_t)C * N * N * sizeof(float) + 4096;
+}
+
+// dotcnt[0] = sum g*sensor, dotcnt[1] = #(sensor == 1) over n elements (n % 4 == 0); dotcnt is zeroed first.
+int ppv_sensor_dot_count(const float* g, const float* sensor, double* dotcnt, long n, hipStream_t stream) {
+    if (!g || !sensor || !dotcnt) return PPV_ERR_NULL;
+    if (n % 4) return PPV_ERR_BAD_SIZE;
+    (void)hipMemsetAsync(dotcnt, 0, 16, stream);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    dot_count_kernel<<<(unsigned)blocks, 256, 0, stream>>>(g, sensor, dotcnt, n / 4);
+    return ppv_last_error();
+}
+
+// Backward of the IC sensor image (Lens.py:290,312 + Utils.py:251-297) given g_sensor = dL/d(sensor):
+//   g_psf (strided [C][P][P], f32/f64; may be null) and g_img ([B,C,P,P] f32; may be null).
+int ppv_fftconv_ic_bwd(const float* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
+                       const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64, long sc, long sy, long sx,
+                       float* g_img, void* workspace, int B, int C, int N, hipStream_t stream) {
+    if (!img || !g_sensor || !sensor || !signs || !maxv || !dotcnt || !workspace) return PPV_ERR_NULL;
+    if (g_img && !otfT) return PPV_ERR_NULL;
+    if (N == 512) return fftconv_bwd_t<8>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, g_img, workspace, B, C, stream);
+    if (N == 256) return fftconv_bwd_t<4>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, g_img, workspace, B, C, stream);
+    return PPV_ERR_BAD_SIZE;
 }
 
 }  // extern "C"

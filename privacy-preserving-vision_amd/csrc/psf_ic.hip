@@ -1,0 +1,569 @@
+// PSF generation of the Image_Caption learned-optics camera (batch independent, once per step), gfx950.
+//
+// Replaces reference Image_Caption/Camera/Lens.py:158-274 and the Utils.py functions it calls:
+//   zernike_contract   Lens.py:176            height map  sum_k c_k Z_k          (HBM-bound: reads the basis)
+//   ic_field           Utils.py:396-413,192-205,88-97 + Lens.py:210-213  noise, fp64 phase, aperture -> c128
+//   mixed-radix fp64 FFT (rows / cols x H / inverse rows)  Utils.py:328-378 Fresnel propagation
+//   intensity + area down-sample + normalise + mask/regulariser  Utils.py:208-248, Lens.py:239,269-274
+// and their adjoints for d/d(zernike coefficients).
+//
+// fp64 throughout the field chain: k*sqrt(x^2+y^2+d^2) ~ 7e6 rad cannot live in fp32.
+// Fields are planar per wavelength [L][RR][RR] double2.  The FFT length M = RR + 2*(RR/4)
+// (1344 = 2^6*3*7 for RR = 896) is kept (padding to 2048 would change the physics); radices 2,3,4,7.
+#include <hip/hip_runtime.h>
+#include "ppv_common.h"
+
+namespace ppv {
+
+constexpr int MAXM = 1344;
+constexpr int MAXST = 8;
+
+struct FftPlan {
+    int M;
+    int nst;
+    int radix[MAXST];
+};
+
+__device__ __forceinline__ double2 dmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 dadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 dsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 dmi(double2 a) { return make_double2(a.y, -a.x); }   // * (-i)
+
+__device__ __forceinline__ void dbfly(double2 (&u)[2]) {
+    const double2 a = u[0], b = u[1];
+    u[0] = dadd(a, b); u[1] = dsub(a, b);
+}
+__device__ __forceinline__ void dbfly(double2 (&u)[4]) {
+    const double2 s02 = dadd(u[0], u[2]), d02 = dsub(u[0], u[2]), s13 = dadd(u[1], u[3]), d13 = dmi(dsub(u[1], u[3]));
+    u[0] = dadd(s02, s13); u[2] = dsub(s02, s13); u[1] = dadd(d02, d13); u[3] = dsub(d02, d13);
+}
+__device__ __forceinline__ void dbfly(double2 (&u)[3]) {
+    const double h = 0.86602540378443864676;
+    const double2 t1 = dadd(u[1], u[2]);
+    const double2 t2 = make_double2(u[0].x - 0.5 * t1.x, u[0].y - 0.5 * t1.y);
+    const double2 d = dsub(u[1], u[2]);
+    const double2 t3 = make_double2(h * d.y, -h * d.x);       // -i h (u1 - u2)
+    u[0] = dadd(u[0], t1); u[1] = dadd(t2, t3); u[2] = dsub(t2, t3);
+}
+__device__ __forceinline__ void dbfly(double2 (&u)[7]) {
+    const double c1 = 0.62348980185873353053, c2 = -0.22252093395631440429, c3 = -0.90096886790241912624;
+    const double s1 = 0.78183148246802980871, s2 = 0.97492791218182360702, s3 = 0.43388373911755812048;
+    const double2 a1 = dadd(u[1], u[6]), a2 = dadd(u[2], u[5]), a3 = dadd(u[3], u[4]);
+    const double2 b1 = dsub(u[1], u[6]), b2 = dsub(u[2], u[5]), b3 = dsub(u[3], u[4]);
+    const double2 u0 = u[0];
+    // q = 1: cos(1,2,3)  sin(1,2,3);  q = 2: cos(2,4->3,6->1) sin(2, 4->-3, 6->-1);  q = 3: cos(3,6->1,9->2) sin(3, 6->-1, 9->2)
+    const double2 p1 = make_double2(u0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, u0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+    const double2 p2 = make_double2(u0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, u0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+    const double2 p3 = make_double2(u0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, u0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+    const double2 q1 = make_double2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
+    const double2 q2 = make_double2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
+    const double2 q3 = make_double2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
+    u[0] = dadd(dadd(u0, a1), dadd(a2, a3));
+    // X[q] = p - i q ; X[7-q] = p + i q
+    u[1] = make_double2(p1.x + q1.y, p1.y - q1.x); u[6] = make_double2(p1.x - q1.y, p1.y + q1.x);
+    u[2] = make_double2(p2.x + q2.y, p2.y - q2.x); u[5] = make_double2(p2.x - q2.y, p2.y + q2.x);
+    u[3] = make_double2(p3.x + q3.y, p3.y - q3.x); u[4] = make_double2(p3.x - q3.y, p3.y + q3.x);
+}
+
+// one Stockham stage over a length-M sequence in LDS (threads tid0, tid0+nthr, ... cooperate)
+template <int R>
+__device__ __forceinline__ void dstage(const double2* __restrict__ in, double2* __restrict__ out,
+                                       const double2* __restrict__ tw, int M, int p, int tid, int nthr) {
+    const int T = M / R;
+    const int step = M / (p * R);
+    for (int i = tid; i < T; i += nthr) {
+        const int k = i % p;
+        double2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            u[r] = in[i + r * T];
+            if (r > 0 && p > 1) u[r] = dmul(u[r], tw[r * k * step]);
+        }
+        dbfly(u);
+        const int j = (i - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) out[j + q * p] = u[q];
+    }
+}
+
+// forward FFT of the sequence in buf a (scratch b); returns the buffer that holds the result.
+// Callers must __syncthreads()-separate groups: `sync` = workgroup barrier functor is implicit (all threads of the
+// workgroup call this together, possibly on different sequences).
+__device__ __forceinline__ double2* dfft(double2* a, double2* b, const double2* tw, const FftPlan& pl, int tid,
+                                         int nthr) {
+    int p = 1;
+    for (int s = 0; s < pl.nst; ++s) {
+        const int R = pl.radix[s];
+        if (R == 4) dstage<4>(a, b, tw, pl.M, p, tid, nthr);
+        else if (R == 2) dstage<2>(a, b, tw, pl.M, p, tid, nthr);
+        else if (R == 3) dstage<3>(a, b, tw, pl.M, p, tid, nthr);
+        else dstage<7>(a, b, tw, pl.M, p, tid, nthr);
+        __syncthreads();
+        double2* t = a; a = b; b = t;
+        p *= R;
+    }
+    return a;
+}
+
+// ----------------------------------------------------------------------------- height map
+// h[px] = sum_k c[k] * Z[k][px]   (Lens.py:176; fp64 accumulate, one rounding to f32)
+__global__ __launch_bounds__(256) void zernike_contract_kernel(const float* __restrict__ Z, const float* __restrict__ c,
+                                                               float* __restrict__ h, int K, long npx4) {
+    extern __shared__ float s_c[];
+    for (int k = threadIdx.x; k < K; k += 256) s_c[k] = c[k];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx4) return;
+    const float4* z = reinterpret_cast<const float4*>(Z) + i;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) {
+        const float4 v = z[(long)k * npx4];
+        const float ck = s_c[k];
+        a0 += (double)(ck * v.x); a1 += (double)(ck * v.y); a2 += (double)(ck * v.z); a3 += (double)(ck * v.w);
+    }
+    reinterpret_cast<float4*>(h)[i] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+}
+
+// gc_partial[wg][k] = sum_{px in tile} Z[k][px] * gh[px]
+__global__ __launch_bounds__(256) void zernike_grad_kernel(const float* __restrict__ Z, const float* __restrict__ gh,
+                                                           double* __restrict__ part, int K, long npx4) {
+    __shared__ double s_red[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < npx4;
+    const float4 g = ok ? reinterpret_cast<const float4*>(gh)[i] : make_float4(0, 0, 0, 0);
+    const float4* z = reinterpret_cast<const float4*>(Z) + (ok ? i : 0);
+    for (int k = 0; k < K; ++k) {
+        const float4 v = z[(long)k * npx4];
+        double a = ok ? ((double)v.x * g.x + (double)v.y * g.y + (double)v.z * g.z + (double)v.w * g.w) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) part[(long)blockIdx.x * K + k] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, float* __restrict__ out,
+                                                           int nwg, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    double a = 0;
+    for (int w = 0; w < nwg; ++w) a += part[(long)w * K + k];
+    out[k] = (float)a;
+}
+
+// ----------------------------------------------------------------------------- field at the phase plate
+// F0[l][y][x] = aperture * sph[y][x][l] * c64(exp(i * kdn[l] * (h + noise)))      (c64 product, promoted to c128)
+__global__ __launch_bounds__(256) void ic_field_kernel(const float* __restrict__ h, const float* __restrict__ noise,
+                                                       const float2* __restrict__ sph, double2* __restrict__ F0,
+                                                       int RR, double kdn0, double kdn1, double kdn2, float tol,
+                                                       int use_tol) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long npx = (long)RR * RR;
+    if (idx >= npx) return;
+    const int y = (int)(idx / RR), x = (int)(idx % RR);
+    float hh = h[idx];
+    if (use_tol) hh = __fadd_rn(hh, __fadd_rn(__fmul_rn(-tol - tol, noise[idx]), tol));   // f32, no FMA (Utils.py:403-406)
+    const long yy = y - RR / 2, xx = x - RR / 2;
+    const long rmax = RR / 2 - 1;
+    const bool open = (yy * yy + xx * xx) < rmax * rmax;
+    const double kd[3] = {kdn0, kdn1, kdn2};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        double2 f = make_double2(0.0, 0.0);
+        if (open) {
+            double s, c;
+            sincos(kd[l] * (double)hh, &s, &c);
+            const float2 pl = make_float2((float)c, (float)s);
+            const float2 sp = sph[idx * 3 + l];
+            f = make_double2((double)__fsub_rn(__fmul_rn(sp.x, pl.x), __fmul_rn(sp.y, pl.y)),
+                             (double)__fadd_rn(__fmul_rn(sp.x, pl.y), __fmul_rn(sp.y, pl.x)));
+        }
+        F0[(long)l * npx + idx] = f;
+    }
+}
+
+// gh[px] = sum_l kdn[l] * Im(GF * conj(F0))
+__global__ __launch_bounds__(256) void ic_field_bwd_kernel(const double2* __restrict__ GF, const double2* __restrict__ F0,
+                                                           float* __restrict__ gh, long npx, double kdn0, double kdn1,
+                                                           double kdn2) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npx) return;
+    const double kd[3] = {kdn0, kdn1, kdn2};
+    double a = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const double2 g = GF[(long)l * npx + idx], f = F0[(long)l * npx + idx];
+        a += kd[l] * (g.y * f.x - g.x * f.y);
+    }
+    gh[idx] = (float)a;
+}
+
+// ----------------------------------------------------------------------------- Fresnel FFT passes
+// rows: in [L][RR][RR] placed at column offset pad inside a zero row of length M -> out [L][RR][M]
+__global__ __launch_bounds__(256) void dfft_rows_kernel(const double2* __restrict__ in, double2* __restrict__ out,
+                                                        const double2* __restrict__ twg, FftPlan pl, int RR, int pad) {
+    __shared__ double2 s_tw[MAXM];
+    __shared__ double2 s_a[MAXM];
+    __shared__ double2 s_b[MAXM];
+    const int tid = threadIdx.x, M = pl.M;
+    const long row = blockIdx.x;          // l * RR + y
+    for (int i = tid; i < M; i += 256) {
+        s_tw[i] = twg[i];
+        const int x = i - pad;
+        s_a[i] = (x >= 0 && x < RR) ? in[row * RR + x] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const double2* r = dfft(s_a, s_b, s_tw, pl, tid, 256);
+    for (int i = tid; i < M; i += 256) out[row * M + i] = r[i];
+}
+
+// cols: two columns per workgroup.  T1 [L][RR][M] rows placed at row offset pad -> column FFT -> x Ht[l][kx][ky]
+// (c64 table, conj for the adjoint) -> inverse column FFT -> rows pad..pad+RR-1 -> T2 [L][RR][M], scaled.
+__global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restrict__ T1, double2* __restrict__ T2,
+                                                        const float2* __restrict__ Ht,
+                                                        const double2* __restrict__ twg, FftPlan pl, int RR, int pad,
+                                                        int conj_h, double scale) {
+    __shared__ double2 s_tw[MAXM];
+    __shared__ double2 s_a[2][MAXM];
+    __shared__ double2 s_b[2][MAXM];
+    const int tid = threadIdx.x, M = pl.M;
+    const int l = blockIdx.y, kx0 = blockIdx.x * 2;
+    const int col = tid >> 8, t = tid & 255;
+    const int kx = kx0 + col;
+    for (int i = tid; i < M; i += 512) s_tw[i] = twg[i];
+    for (int i = t; i < M; i += 256) {
+        const int y = i - pad;
+        s_a[col][i] = (y >= 0 && y < RR) ? T1[((long)l * RR + y) * M + kx] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double2* r = dfft(s_a[col], s_b[col], s_tw, pl, t, 256);
+    double2* o = (r == s_a[col]) ? s_b[col] : s_a[col];
+    const float2* hcol = Ht + ((long)l * M + kx) * M;
+    for (int i = t; i < M; i += 256) {
+        const float2 hf = hcol[i];
+        const double2 hv = make_double2((double)hf.x, conj_h ? -(double)hf.y : (double)hf.y);
+        const double2 v = dmul(r[i], hv);
+        r[i] = make_double2(v.x, -v.y);                  // conj for the inverse transform
+    }
+    __syncthreads();
+    const double2* z = dfft(r, o, s_tw, pl, t, 256);
+    for (int i = t; i < RR; i += 256) {
+        const double2 v = z[i + pad];
+        T2[((long)l * RR + i) * M + kx] = make_double2(v.x * scale, -v.y * scale);
+    }
+}
+
+// inverse rows: T2 [L][RR][M] -> crop columns pad..pad+RR-1 -> U [L][RR][RR] (c128), optional intensity f32
+__global__ __launch_bounds__(256) void difft_rows_kernel(const double2* __restrict__ T2, double2* __restrict__ U,
+                                                         float* __restrict__ I32, const double2* __restrict__ twg,
+                                                         FftPlan pl, int RR, int pad) {
+    __shared__ double2 s_tw[MAXM];
+    __shared__ double2 s_a[MAXM];
+    __shared__ double2 s_b[MAXM];
+    const int tid = threadIdx.x, M = pl.M;
+    const long row = blockIdx.x;
+    for (int i = tid; i < M; i += 256) {
+        s_tw[i] = twg[i];
+        const double2 v = T2[row * M + i];
+        s_a[i] = make_double2(v.x, -v.y);
+    }
+    __syncthreads();
+    const double2* r = dfft(s_a, s_b, s_tw, pl, tid, 256);
+    for (int i = tid; i < RR; i += 256) {
+        const double2 v = make_double2(r[i + pad].x, -r[i + pad].y);
+        U[row * RR + i] = v;
+        if (I32) I32[row * RR + i] = (float)(v.x * v.x + v.y * v.y);      // Utils.py:208-209, cast Utils.py:218
+    }
+}
+
+// ----------------------------------------------------------------------------- area down-sample (Utils.py:216-248)
+// raw[Y][X][l] = (1/up^2) * sum_{a,b<up} I32[l][src(up*Y+a)][src(up*X+b)],  src(U) = min(floor(U*scale), RR-1)
+__global__ __launch_bounds__(256) void area_down_kernel(const float* __restrict__ I32, float* __restrict__ raw,
+                                                        double* __restrict__ sums, int RR, int P, int up, float scale) {
+    __shared__ double s_red[4][3];
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = idx < (long)P * P;
+    const int Y = ok ? (int)(idx / P) : 0, X = ok ? (int)(idx % P) : 0;
+    double acc[3] = {0, 0, 0};
+    if (ok) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float* src = I32 + (long)l * RR * RR;
+            float s = 0.f;
+            for (int a = 0; a < up; ++a) {
+                const int r = min((int)floorf((float)(up * Y + a) * scale), RR - 1);
+                for (int b = 0; b < up; ++b) {
+                    const int c = min((int)floorf((float)(up * X + b) * scale), RR - 1);
+                    s += src[(long)r * RR + c];
+                }
+            }
+            s = s / (float)(up * up);
+            raw[idx * 3 + l] = s;
+            acc[l] = (double)s;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        double a = acc[l];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][l] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int l = threadIdx.x;
+        atomicAdd(&sums[l], s_red[0][l] + s_red[1][l] + s_red[2][l] + s_red[3][l]);
+    }
+}
+
+// psf_n = raw / sum (f32, Lens.py:239);  loss_acc += sum((psf_n*m1 - psf_n)^2) (f64, Lens.py:271);
+// psf_m = psf_n * m2 (f64, Lens.py:274).  m1 / m2 / psf_m / loss_acc may be null.
+__global__ __launch_bounds__(256) void psf_finalize_kernel(const float* __restrict__ raw, const double* __restrict__ sums,
+                                                           const double* __restrict__ m1, const double* __restrict__ m2,
+                                                           float* __restrict__ psf_n, double* __restrict__ psf_m,
+                                                           double* __restrict__ loss_acc, long n) {
+    __shared__ double s_red[4];
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    double a = 0;
+    if (idx < n) {
+        const int l = (int)(idx % 3);
+        const float v = raw[idx] / (float)sums[l];
+        psf_n[idx] = v;
+        if (m1) {
+            const double d = (double)v * m1[idx] - (double)v;
+            a = d * d;
+        }
+        if (psf_m) psf_m[idx] = (double)v * m2[idx];
+    }
+    if (loss_acc) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(loss_acc, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    }
+}
+
+// backward of finalize: g_n = g_psf_m*m2 + g_psf_n + g_loss * psf_n*(m1-1)^2 / loss;  dots[l] += sum g_n * psf_n
+__global__ __launch_bounds__(256) void psf_finalize_bwd1_kernel(const float* __restrict__ psf_n,
+                                                                const double* __restrict__ m1,
+                                                                const double* __restrict__ m2,
+                                                                const double* __restrict__ g_psf_m,
+                                                                const float* __restrict__ g_psf_n,
+                                                                const double* __restrict__ g_loss,
+                                                                const double* __restrict__ loss, double* __restrict__ g_n,
+                                                                double* __restrict__ dots, long n) {
+    __shared__ double s_red[4][3];
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    double acc[3] = {0, 0, 0};
+    if (idx < n) {
+        const int l = (int)(idx % 3);
+        const double v = (double)psf_n[idx];
+        double g = 0;
+        if (g_psf_m) g += g_psf_m[idx] * m2[idx];
+        if (g_psf_n) g += (double)g_psf_n[idx];
+        if (g_loss && m1) {
+            const double d = m1[idx] - 1.0;
+            const double L = *loss;
+            if (L > 0) g += (*g_loss) * v * d * d / L;
+        }
+        g_n[idx] = g;
+        acc[l] = g * v;
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        double a = acc[l];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][l] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int l = threadIdx.x;
+        atomicAdd(&dots[l], s_red[0][l] + s_red[1][l] + s_red[2][l] + s_red[3][l]);
+    }
+}
+
+// g_raw = (g_n - dot_l) / sum_l ; then adjoint of area_down fused with the intensity adjoint:
+// GU[l][r][c] = 2 * U[l][r][c] * (1/up^2) * sum_{U0: src(U0)=r} sum_{V0: src(V0)=c} g_raw[U0/up][V0/up][l]
+__global__ __launch_bounds__(256) void area_down_bwd_kernel(const double* __restrict__ g_n, const double* __restrict__ dots,
+                                                            const double* __restrict__ sums,
+                                                            const double2* __restrict__ U, double2* __restrict__ GU,
+                                                            int RR, int P, int up, float scale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)RR * RR) return;
+    const int r = (int)(idx / RR), c = (int)(idx % RR);
+    const int ulo = max(0, (int)floorf((float)r / scale) - 2), uhi = min(up * P - 1, (int)floorf((float)(r + 1) / scale) + 2);
+    const int vlo = max(0, (int)floorf((float)c / scale) - 2), vhi = min(up * P - 1, (int)floorf((float)(c + 1) / scale) + 2);
+    double g[3] = {0, 0, 0};
+    for (int u0 = ulo; u0 <= uhi; ++u0) {
+        if (min((int)floorf((float)u0 * scale), RR - 1) != r) continue;
+        for (int v0 = vlo; v0 <= vhi; ++v0) {
+            if (min((int)floorf((float)v0 * scale), RR - 1) != c) continue;
+            const long o = ((long)(u0 / up) * P + (v0 / up)) * 3;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) g[l] += (g_n[o + l] - dots[l]) / (double)(float)sums[l];
+        }
+    }
+    const double inv = 1.0 / (double)(up * up);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const double2 u = U[(long)l * RR * RR + idx];
+        const double w = 2.0 * g[l] * inv;
+        GU[(long)l * RR * RR + idx] = make_double2(w * u.x, w * u.y);
+    }
+}
+
+}  // namespace ppv
+
+// =============================================================================== host side
+using namespace ppv;
+
+namespace {
+
+int make_plan(int M, FftPlan* pl) {
+    if (M > MAXM || M < 8) return PPV_ERR_BAD_SIZE;
+    pl->M = M;
+    pl->nst = 0;
+    int m = M;
+    while (m % 4 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 4; m /= 4; }
+    while (m % 2 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 2; m /= 2; }
+    while (m % 3 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 3; m /= 3; }
+    while (m % 7 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 7; m /= 7; }
+    return m == 1 ? PPV_OK : PPV_ERR_BAD_SIZE;
+}
+
+struct IcWs {            // carve-up of the caller's persistent state buffer (saved for backward)
+    float* h;            // [RR*RR]
+    double2* F0;         // [3][RR][RR]
+    double2* U;          // [3][RR][RR]
+    double2* T1;         // [3][RR][M]
+    double2* T2;         // [3][RR][M]
+    float* I32;          // [3][RR][RR]
+    float* raw;          // [P][P][3]
+    double* sums;        // [3] + dots[3] + loss_acc[1] + pad
+    double* g_n;         // [P*P*3]
+    double* part;        // [nwg][K]
+    float* gh;           // [RR*RR]
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t carve(IcWs* w, char* base, int RR, int P, int K) {
+    const int M = RR + 2 * (RR / 4);
+    const size_t npx = (size_t)RR * RR;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    w->h = (float*)take(npx * 4);
+    w->F0 = (double2*)take(3 * npx * 16);
+    w->U = (double2*)take(3 * npx * 16);
+    w->T1 = (double2*)take((size_t)3 * RR * M * 16);
+    w->T2 = (double2*)take((size_t)3 * RR * M * 16);
+    w->I32 = (float*)take(3 * npx * 4);
+    w->raw = (float*)take((size_t)P * P * 3 * 4);
+    w->sums = (double*)take(8 * 8);
+    w->g_n = (double*)take((size_t)P * P * 3 * 8);
+    const size_t nwg = (npx / 4 + 255) / 256;
+    w->part = (double*)take(nwg * K * 8);
+    w->gh = (float*)take(npx * 4);
+    return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ppv_ic_psf_state_bytes(int RR, int P, int K) {
+    IcWs w;
+    return carve(&w, nullptr, RR, P, K);
+}
+
+// Forward PSF generation (Lens.py:158-274).
+//   Z [K][RR][RR] f32, coeffs [K] f32, noise [RR*RR] f32 U[0,1) (may be null when tol < 0),
+//   sph [RR][RR][3] c64 (Lens.py:191-210, cached constant), Ht [3][M][M] c64 = Fresnel transfer function transposed
+//   (kx-major; Utils.py:339-373, cached constant), kdn[3] = 2 pi / lambda * (n - 1) on the HOST,
+//   m1/m2 [P][P][3] f64 or null; outputs psf_n [P][P][3] f32, psf_m [P][P][3] f64 (if m2), loss_acc [1] f64 (if m1;
+//   = sum of squares, caller takes sqrt).  `state` (ppv_ic_psf_state_bytes) keeps what backward needs.
+int ppv_ic_psf_fwd(const float* Z, const float* coeffs, const float* noise, const void* sph, const void* Ht,
+                   const double* kdn, float tol, const double* m1, const double* m2, float* psf_n, double* psf_m,
+                   double* loss_acc, void* state, int RR, int P, int K, int up, float up_scale, hipStream_t stream) {
+    if (!Z || !coeffs || !sph || !Ht || !kdn || !psf_n || !state) return PPV_ERR_NULL;
+    if (RR % 4 || (RR * (long)RR) % 4) return PPV_ERR_BAD_SIZE;
+    const int pad = RR / 4, M = RR + 2 * pad;
+    FftPlan pl;
+    if (int e = make_plan(M, &pl)) return e;
+    const double2* tw = (const double2*)ppv_twiddles_f64(M);
+    if (!tw) return PPV_ERR_INIT;
+    IcWs w;
+    carve(&w, (char*)state, RR, P, K);
+    const long npx = (long)RR * RR, npx4 = npx / 4;
+    (void)hipMemsetAsync(w.sums, 0, 64, stream);
+    if (loss_acc) (void)hipMemsetAsync(loss_acc, 0, 8, stream);
+    zernike_contract_kernel<<<(unsigned)((npx4 + 255) / 256), 256, K * sizeof(float), stream>>>(Z, coeffs, w.h, K, npx4);
+    ic_field_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.h, noise, (const float2*)sph, w.F0, RR, kdn[0],
+                                                                     kdn[1], kdn[2], tol, (tol >= 0.f && noise) ? 1 : 0);
+    dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
+    dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, 0,
+                                                        1.0 / ((double)M * (double)M));
+    difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
+    area_down_kernel<<<(unsigned)(((long)P * P + 255) / 256), 256, 0, stream>>>(w.I32, w.raw, w.sums, RR, P, up, up_scale);
+    const long n = (long)P * P * 3;
+    psf_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(w.raw, w.sums, m1, m2, psf_n, psf_m,
+                                                                       m1 ? loss_acc : nullptr, n);
+    return ppv_last_error();
+}
+
+// Backward: given g_psf_m (f64, grad of the masked psf; null if unused), g_psf_n (f32, grad of the un-masked
+// normalised psf; null if unused), g_loss (device scalar f64, grad of the loss = sqrt(loss_acc); null if unused) and
+// loss (device scalar f64 = sqrt(loss_acc)), writes g_coeffs [K] f32.  Uses the state left by ppv_ic_psf_fwd.
+int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const double* m1, const double* m2,
+                   const float* psf_n, const double* g_psf_m, const float* g_psf_n, const double* g_loss,
+                   const double* loss, float* g_coeffs, void* state, int RR, int P, int K, int up, float up_scale,
+                   hipStream_t stream) {
+    if (!Z || !Ht || !kdn || !psf_n || !g_coeffs || !state) return PPV_ERR_NULL;
+    const int pad = RR / 4, M = RR + 2 * pad;
+    FftPlan pl;
+    if (int e = make_plan(M, &pl)) return e;
+    const double2* tw = (const double2*)ppv_twiddles_f64(M);
+    if (!tw) return PPV_ERR_INIT;
+    IcWs w;
+    carve(&w, (char*)state, RR, P, K);
+    const long npx = (long)RR * RR, npx4 = npx / 4, n = (long)P * P * 3;
+    double* dots = w.sums + 3;
+    (void)hipMemsetAsync(dots, 0, 24, stream);
+    psf_finalize_bwd1_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(psf_n, m1, m2, g_psf_m, g_psf_n, g_loss, loss,
+                                                                            w.g_n, dots, n);
+    double2* GU = w.T2;      // T2 is dead after forward and holds 3*RR*M >= 3*RR*RR elements; U and F0 stay intact
+    area_down_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.g_n, dots, w.sums, w.U, GU, RR, P, up, up_scale);
+    dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
+    // cols: T1 -> T2 would overwrite GU while reading T1 only: fine (GU no longer needed)
+    dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, 1,
+                                                        1.0 / ((double)M * (double)M));
+    double2* GF = w.T1;                                            // T1 dead again
+    difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
+    ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
+    const unsigned nwg = (unsigned)((npx4 + 255) / 256);
+    zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, w.gh, w.part, K, npx4);
+    sum_partials_kernel<<<(K + 255) / 256, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg, K);
+    return ppv_last_error();
+}
+
+// debug / parity taps into the saved state
+int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0, size_t* off_U, size_t* off_I32,
+                             size_t* off_raw) {
+    IcWs w;
+    carve(&w, (char*)256, RR, P, K);
+    *off_h = (size_t)((char*)w.h - (char*)256);
+    *off_F0 = (size_t)((char*)w.F0 - (char*)256);
+    *off_U = (size_t)((char*)w.U - (char*)256);
+    *off_I32 = (size_t)((char*)w.I32 - (char*)256);
+    *off_raw = (size_t)((char*)w.raw - (char*)256);
+    return PPV_OK;
+}
+
+}  // extern "C"

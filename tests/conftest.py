@@ -31,7 +31,17 @@ def volume_896():
     return v
 
 
+def _np(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu()
+        if x.is_complex():
+            import torch
+            x = torch.view_as_real(x.resolve_conj())
+        x = x.numpy()
+    return np.asarray(x, dtype=np.float64)
+
+
 def rel_err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a = _np(a)
+    b = _np(b)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)

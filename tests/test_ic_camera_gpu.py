@@ -1,0 +1,146 @@
+"""GPU parity of the OpticsZernike drop-in (PSF generation + sensor image, forward and backward) against the CPU
+oracle on the same seeded inputs and against the goldens captured from the reference."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star: PSF and activations within 1e-3 rel fp32
+
+
+def _taps(cam):
+    from ppv_amd import _lib
+    RR, P, K = cam.wave_res[0], cam.patch_size, cam.zernike_volume.shape[0]
+    offs = [ctypes.c_size_t() for _ in range(5)]
+    _lib.lib().ppv_ic_psf_state_offsets(RR, P, K, *[ctypes.byref(o) for o in offs])
+    st = cam._state
+    npx = RR * RR
+
+    def view(off, dtype, n):
+        return st[off.value: off.value + n * torch.empty(0, dtype=dtype).element_size()].view(dtype)
+
+    return dict(h=view(offs[0], torch.float32, npx).reshape(RR, RR),
+                F0=view(offs[1], torch.complex128, 3 * npx).reshape(3, RR, RR),
+                U=view(offs[2], torch.complex128, 3 * npx).reshape(3, RR, RR),
+                I32=view(offs[3], torch.float32, 3 * npx).reshape(3, RR, RR))
+
+
+def test_zernike_volume_matches_oracle_generator():
+    from ppv_amd.zernike import zernike_volume
+    from oracle import zernike as oz
+    for res, k in ((112, 15), (448, 36), (257, 66)):
+        got = zernike_volume(res, k, "cuda").cpu().numpy()
+        want = oz.zernike_volume(res, k).astype(np.float32)
+        assert np.abs(got - want).max() <= 2e-7 * np.abs(want).max()
+        assert (got[:, 0, 0] == 0).all()
+
+
+def _mid_cam(layout="B", prueba_masks=False):
+    from ppv_amd.camera_lens import OpticsZernike
+    cam = OpticsZernike(input_shape=[None, 128, 128, 3], device=torch.device("cuda"), zernike_terms=36,
+                        patch_size=128, height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[448, 448],
+                        sample_interval=3e-06, upsample=False, coeff_layout=layout)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        c = (torch.rand(33, 1, 1, generator=g) - 0.5) * 0.4
+        c[0] = -11.0
+        cam.zernike_coeffs_train.copy_(c)
+    return cam
+
+
+def test_mid_size_every_stage_and_grads():
+    """RR=448 (FFT 672 = 2^5*3*7), P=128 (FFT 256), K=36: same code paths as 896/1344/256, oracle-sized."""
+    from oracle import ic_camera as ic
+    cam = _mid_cam()
+    img = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(0))
+    w = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(5))
+    noise = torch.rand(1, 448, 448, 1, generator=torch.Generator().manual_seed(1))
+    vol = cam.zernike_volume.cpu()
+    # oracle
+    co = cam._concat().detach().cpu().requires_grad_(True)
+    s_o, psf_o, _, inter = ic.forward(img, co, vol, noise, prueba=None, height_tolerance=2e-8,
+                                      sensor_distance=0.025, sample_interval=3e-6, return_intermediates=True)
+    (s_o * w).sum().backward()
+    # product
+    sensor, psf, coeffs, loss = cam(img.cuda(), None, None, noise_u01=noise.cuda())
+    assert loss is None and psf.dtype == torch.float32 and psf.shape == (1, 128, 128, 3)
+    t = _taps(cam)
+    assert rel_err(t["h"].cpu(), inter["height_map"][0, :, :, 0]) < 1e-6
+    assert rel_err(torch.view_as_real(t["F0"].cpu()), torch.view_as_real(inter["field"][0].permute(2, 0, 1).contiguous())) < 5e-4   # f32 height map: a few ulp of h = 1e-4 rad
+    assert rel_err(torch.view_as_real(t["U"].cpu()), torch.view_as_real(inter["sensor_field"][0].permute(2, 0, 1).contiguous())) < 5e-4
+    assert rel_err(t["I32"].cpu(), inter["intensity"][0].permute(2, 0, 1)) < TOL
+    assert rel_err(psf.cpu(), psf_o.detach()) < TOL
+    assert rel_err(sensor.cpu(), s_o.detach()) < TOL
+    (sensor * w.cuda()).sum().backward()
+    got = cam.zernike_coeffs_train.grad.reshape(-1).cpu()
+    assert rel_err(got, co.grad.reshape(-1)[3:]) < TOL
+
+
+def test_mid_size_grad_wrt_image():
+    from oracle import ic_camera as ic
+    cam = _mid_cam()
+    img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(0))
+    w = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(5))
+    noise = torch.rand(1, 448, 448, 1, generator=torch.Generator().manual_seed(1))
+    io = img.clone().requires_grad_(True)
+    s_o, _, _ = ic.forward(io, cam._concat().detach().cpu(), cam.zernike_volume.cpu(), noise, prueba=None,
+                           height_tolerance=2e-8, sensor_distance=0.025, sample_interval=3e-6)
+    (s_o * w).sum().backward()
+    ig = img.cuda().requires_grad_(True)
+    sensor, _, _, _ = cam(ig, None, None, noise_u01=noise.cuda())
+    (sensor * w.cuda()).sum().backward()
+    assert rel_err(ig.grad.cpu(), io.grad) < TOL
+
+
+@pytest.mark.parametrize("tag", ["init", "modelpth"])
+def test_real_size_against_reference_golden(tag):
+    """train.py:64-66 configuration (896/350/256, prueba '3'); golden = the reference's own output."""
+    from ppv_amd.camera_lens import OpticsZernike
+    g = load_golden("ic_real.npz")
+    cam = OpticsZernike(input_shape=[None, 256, 256, 3], device=torch.device("cuda"), zernike_terms=350,
+                        patch_size=256, height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[896, 896],
+                        sample_interval=3e-06, upsample=False)
+    assert rel_err(cam.zernike_volume[:, ::16, ::16].cpu(), g["volume_sub"]) < 1e-6
+    c = torch.tensor(g[f"{tag}_coeffs"]).reshape(-1, 1, 1)
+    sd = {"zernike_coeffs_no_train": c[:3], "zernike_coeffs_train": c[3:]}        # layout B (Model.pth)
+    cam.load_state_dict(sd)
+    assert cam.coeff_layout == "B" and cam.zernike_coeffs_train.shape == (347, 1, 1)
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = torch.rand([1, 896, 896, 1])
+    img = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    w = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    sensor, psf, coeffs, loss = cam(img.cuda(), None, "3", noise_u01=noise.cuda())
+    assert psf.dtype == torch.float64 and loss.dtype == torch.float64 and sensor.dtype == torch.float32
+    assert psf.shape == (1, 256, 256, 3) and sensor.shape == (2, 3, 256, 256) and coeffs.shape == (350, 1, 1)
+    assert rel_err(psf.cpu(), g[f"{tag}_psf"]) < TOL
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) < TOL * float(g[f"{tag}_loss"])
+    assert rel_err(sensor[:, :, ::8, ::8].cpu(), g[f"{tag}_sensor_sub"]) < TOL
+    assert rel_err(sensor[:, :, :3, :].cpu(), g[f"{tag}_sensor_edge"]) < TOL
+    st = g[f"{tag}_sensor_stats"]
+    assert abs(sensor.double().sum().item() - st[0]) < TOL * abs(st[0]) and sensor.max().item() == 1.0
+    gs, = torch.autograd.grad((sensor * w.cuda()).sum(), cam.zernike_coeffs_train, retain_graph=True)
+    gl, = torch.autograd.grad(loss, cam.zernike_coeffs_train)
+    assert rel_err(gs.reshape(-1).cpu(), g[f"{tag}_grad_sensor_w"]) < 5 * TOL
+    assert rel_err(gl.reshape(-1).cpu(), g[f"{tag}_grad_loss"]) < 5 * TOL
+
+
+def test_layout_a_and_optimizer_survives_checkpoint_switch():
+    from ppv_amd.camera_lens import OpticsZernike
+    cam = OpticsZernike(input_shape=[None, 128, 128, 3], device=torch.device("cuda"), zernike_terms=36,
+                        patch_size=128, height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[448, 448],
+                        sample_interval=3e-06)
+    assert cam.coeff_layout == "A" and cam.zernike_coeffs_train.shape == (1, 1)
+    assert sorted(cam.state_dict()) == ["zernike_coeffs_no_train", "zernike_coeffs_no_train2", "zernike_coeffs_train"]
+    opt = torch.optim.Adam([p for p in cam.parameters() if p.requires_grad], lr=1e-3)
+    cam.load_state_dict({"zernike_coeffs_no_train": torch.zeros(3, 1, 1), "zernike_coeffs_train": torch.zeros(33, 1, 1)})
+    assert sorted(cam.state_dict()) == ["zernike_coeffs_no_train", "zernike_coeffs_train"]
+    img = torch.rand(1, 3, 128, 128, device="cuda")
+    sensor, _, _, _ = cam(img, None, None)
+    sensor.mean().backward()
+    before = cam.zernike_coeffs_train.detach().clone()
+    opt.step()
+    assert not torch.equal(before, cam.zernike_coeffs_train.detach())

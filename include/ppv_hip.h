@@ -77,6 +77,43 @@ int ppv_zernike_basis(const void* terms, const double* coefs, float* out, int K,
                       double outside, ppv_stream_t stream);
 int ppv_zernike_max_order(void);
 
+/* ---- ResNet-101 trunk (Image_Caption/models.py:13-41 Encoder -> torchvision ResNet-101) -----
+ * NHWC bf16 implicit-GEMM convolution on MFMA; serves forward and data-gradient (see csrc/conv_gemm.hip).
+ *   forward: a = stride, off = -pad, div = 1, Wt = [Cout][R][S][Cin];
+ *   dgrad:   a = 1, off = -(k-1-pad), div = stride, Wt = [Cin][R][S][Cout] taps flipped.
+ * stat_part [ceil(M/128)][2][N]: per-row-tile (sum, sum of squares) of the bf16-rounded outputs (train-mode BN)
+ * or NULL; addend [M][N] bf16 is added before rounding (residual-gradient accumulation) or NULL. */
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend,
+                  const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a,
+                  int off, int div, int out_f32, ppv_stream_t stream);
+int ppv_conv_stat_tiles(long M);
+int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, ppv_stream_t stream);
+
+/* weight gradient (layer2..4 trainable, models.py:43-54): dW [N][R][S][Cs] f32 += ...; then to torch [N][Cs][R][S] */
+int ppv_conv_wgrad(const void* G, const void* X, float* dW, const void* zero_page, int B, int Hs, int Ws, int Cs,
+                   int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream);
+int ppv_wgrad_to_torch(const float* dW, float* out, int N, int C, int R, int S, ppv_stream_t stream);
+/* stem 7x7/2 conv (resnet.0), f32 NCHW sensor image in, NHWC bf16 out; data gradient via ppv_conv_gemm (N = 16) */
+int ppv_stem_weight_layout(const float* w, void* out, int mode, ppv_stream_t stream);
+int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int B, int H, int W,
+                  ppv_stream_t stream);
+int ppv_stem_dgrad_scatter(const float* t, float* g, int B, int Ho, int Wo, ppv_stream_t stream);
+/* train-mode BatchNorm2d (+ residual, + ReLU), forward and backward */
+int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float momentum, float eps, float* coef, int C, ppv_stream_t stream);
+int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, long n, int C,
+               int res_mode, int relu, ppv_stream_t stream);
+int ppv_bn_bwd_blocks(long rows, int C);
+int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
+               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, ppv_stream_t stream);
+/* stem BN + ReLU + MaxPool 3x3/2 (resnet.1-3) and AdaptiveAvgPool2d(36) (models.py:27,39-40) */
+int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, int B, int H, int W, int C,
+                        ppv_stream_t stream);
+int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* gpre, int B, int H, int W, int C,
+                         ppv_stream_t stream);
+int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, ppv_stream_t stream);
+int ppv_adaptive_pool_bwd(const void* gy, void* gx, int B, int H, int W, int C, int E, int g_f32, ppv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,162 @@
+"""torch-facing wrappers of the trunk kernels (csrc/conv_gemm.hip, conv_wgrad_stem.hip, trunk_ops.hip).
+Activations are NHWC bfloat16; statistics, BN coefficients and weight gradients are float32."""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+_zero_pages = {}
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def zero_page(device):
+    key = (device.type, device.index)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+def L():
+    return _lib.lib()
+
+
+# ----------------------------------------------------------------------------- convolution
+def weight_layout(w, mode):
+    """w [Cout,Cin,R,S] f32 -> bf16 GEMM rows: mode 0 forward [Cout,R,S,Cin]; mode 1 dgrad [Cin,R,S,Cout] flipped."""
+    Cout, Cin, R, S = w.shape
+    shape = (Cout, R, S, Cin) if mode == 0 else (Cin, R, S, Cout)
+    out = torch.empty(shape, dtype=BF16, device=w.device)
+    check(L().ppv_weight_layout(ptr(w.contiguous()), ptr(out), Cout, Cin, R, S, mode, stream_ptr()), "ppv_weight_layout")
+    return out
+
+
+def stat_tiles(M):
+    return L().ppv_conv_stat_tiles(M)
+
+
+def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
+    """x [B,H,W,Cin] bf16, wt [Cout,R,S,Cin] bf16 -> [B,Ho,Wo,Cout]; stat_part [tiles,2,Cout] f32 BN partials."""
+    B, H, W, Cin = x.shape
+    Cout, R, S, _ = wt.shape
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=F32 if out_f32 else BF16, device=x.device)
+    check(L().ppv_conv_gemm(ptr(x), ptr(wt), ptr(out), ptr(stat_part), None, ptr(zero_page(x.device)), B, H, W, Cin,
+                            Ho, Wo, Cout, R, S, stride, -pad, 1, int(out_f32), stream_ptr()), "ppv_conv_gemm")
+    return out
+
+
+def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False):
+    """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend)."""
+    B, Ho, Wo, Cout = g.shape
+    Cin, R, S, _ = wd.shape
+    H, W = in_hw
+    out = torch.empty((B, H, W, Cin), dtype=F32 if out_f32 else BF16, device=g.device)
+    check(L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
+                            H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), stream_ptr()), "ppv_conv_gemm")
+    return out
+
+
+def conv_wgrad(g, x, R, S, stride, pad):
+    """g [B,Ho,Wo,Cout] bf16, x [B,H,W,Cin] bf16 -> dW in torch layout [Cout,Cin,R,S] f32."""
+    B, Ho, Wo, Cout = g.shape
+    _, H, W, Cin = x.shape
+    acc = torch.zeros((Cout, R, S, Cin), dtype=F32, device=g.device)
+    check(L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(acc), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S, stride,
+                             pad, stream_ptr()), "ppv_conv_wgrad")
+    out = torch.empty((Cout, Cin, R, S), dtype=F32, device=g.device)
+    check(L().ppv_wgrad_to_torch(ptr(acc), ptr(out), Cout, Cin, R, S, stream_ptr()), "ppv_wgrad_to_torch")
+    return out
+
+
+# ----------------------------------------------------------------------------- stem
+def stem_weight_layout(w, mode):
+    out = torch.empty((64, 24, 8) if mode == 0 else (16, 4, 4, 64), dtype=BF16, device=w.device)
+    check(L().ppv_stem_weight_layout(ptr(w.contiguous()), ptr(out), mode, stream_ptr()), "ppv_stem_weight_layout")
+    return out
+
+
+def stem_conv(img, wst, stat_part=None):
+    """img [B,3,H,W] f32 NCHW -> raw [B,H/2,W/2,64] bf16."""
+    B, _, H, W = img.shape
+    out = torch.empty((B, H // 2, W // 2, 64), dtype=BF16, device=img.device)
+    check(L().ppv_stem_conv(ptr(img), ptr(wst), ptr(out), ptr(stat_part), B, H, W, stream_ptr()), "ppv_stem_conv")
+    return out
+
+
+def stem_dgrad(g_raw, wsd):
+    """g_raw [B,Ho,Wo,64] bf16 -> d/d(img) [B,3,2Ho,2Wo] f32 NCHW."""
+    B, Ho, Wo, _ = g_raw.shape
+    tmp = torch.empty((B * Ho * Wo, 16), dtype=F32, device=g_raw.device)
+    check(L().ppv_conv_gemm(ptr(g_raw), ptr(wsd), ptr(tmp), None, None, ptr(zero_page(g_raw.device)), B, Ho, Wo, 64,
+                            Ho, Wo, 16, 4, 4, 1, -1, 1, 1, stream_ptr()), "ppv_conv_gemm(stem dgrad)")
+    out = torch.empty((B, 3, 2 * Ho, 2 * Wo), dtype=F32, device=g_raw.device)
+    check(L().ppv_stem_dgrad_scatter(ptr(tmp), ptr(out), B, Ho, Wo, stream_ptr()), "ppv_stem_dgrad_scatter")
+    return out
+
+
+# ----------------------------------------------------------------------------- batch norm
+def bn_finalize(stat_part, count, gamma, beta, run_mean, run_var, momentum=0.1, eps=1e-5):
+    """-> coef [4,C] f32 = scale, shift, mean, invstd; running stats updated in place (may be None)."""
+    T, _, C = stat_part.shape
+    coef = torch.empty((4, C), dtype=F32, device=stat_part.device)
+    check(L().ppv_bn_finalize(ptr(stat_part), T, float(count), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_var),
+                              momentum, eps, ptr(coef), C, stream_ptr()), "ppv_bn_finalize")
+    return coef
+
+
+def bn_act(x, coef, res=None, coef_res=None, relu=True):
+    y = torch.empty_like(x)
+    mode = 0 if res is None else (1 if coef_res is None else 2)
+    check(L().ppv_bn_act(ptr(x), ptr(coef), ptr(res), ptr(coef_res), ptr(y), x.numel(), x.shape[-1], mode, int(relu),
+                         stream_ptr()), "ppv_bn_act")
+    return y
+
+
+def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True):
+    """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dev = x.device
+    gx = torch.empty_like(x)
+    gpre = torch.empty_like(x) if want_gpre else None
+    dg = torch.empty(C, dtype=F32, device=dev) if want_affine else None
+    db = torch.empty(C, dtype=F32, device=dev) if want_affine else None
+    nb = L().ppv_bn_bwd_blocks(rows, C)
+    part = torch.empty(nb * 2 * C, dtype=F32, device=dev)
+    kc = torch.empty(3 * C, dtype=F32, device=dev)
+    check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
+                         ptr(kc), rows, C, int(relu), stream_ptr()), "ppv_bn_bwd")
+    return gx, gpre, dg, db
+
+
+# ----------------------------------------------------------------------------- pools
+def bn_relu_maxpool(x, coef):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    arg = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
+    check(L().ppv_bn_relu_maxpool(ptr(x), ptr(coef), ptr(y), ptr(arg), B, H, W, C, stream_ptr()), "ppv_bn_relu_maxpool")
+    return y, arg
+
+
+def maxpool_relu_bwd(gy, y, arg, in_hw):
+    B, Ho, Wo, C = gy.shape
+    H, W = in_hw
+    g = torch.empty((B, H, W, C), dtype=BF16, device=gy.device)
+    check(L().ppv_maxpool_relu_bwd(ptr(gy), ptr(y), ptr(arg), ptr(g), B, H, W, C, stream_ptr()), "ppv_maxpool_relu_bwd")
+    return g
+
+
+def adaptive_pool_fwd(x, E, out_dtype=F32):
+    B, H, W, C = x.shape
+    y = torch.empty((B, E, E, C), dtype=out_dtype, device=x.device)
+    check(L().ppv_adaptive_pool_fwd(ptr(x), ptr(y), B, H, W, C, E, int(out_dtype == F32), stream_ptr()), "ppv_adaptive_pool_fwd")
+    return y
+
+
+def adaptive_pool_bwd(gy, in_hw):
+    B, E, _, C = gy.shape
+    H, W = in_hw
+    gx = torch.empty((B, H, W, C), dtype=BF16, device=gy.device)
+    check(L().ppv_adaptive_pool_bwd(ptr(gy.contiguous()), ptr(gx), B, H, W, C, E, int(gy.dtype == F32), stream_ptr()),
+          "ppv_adaptive_pool_bwd")
+    return gx

@@ -1,0 +1,304 @@
+// NHWC bf16 implicit-GEMM convolution on MFMA (v_mfma_f32_16x16x32_bf16), gfx950.
+//
+// One kernel serves the forward convolution and the data gradient of every ResNet-101 bottleneck conv
+// (reference Image_Caption/models.py:17-21 -> torchvision ResNet-101: 1x1 / 3x3, stride 1 / 2):
+//
+//   out[m][n] = sum_{r,s,c} src[b, (ho*a + r + off)/div, (wo*a + s + off)/div, c] * wt[n][r][s][c]
+//
+//   forward : a = stride, off = -pad,        div = 1,      wt = W[cout][r][s][cin]
+//   dgrad   : a = 1,      off = -(k-1-pad),  div = stride, wt = W^T flipped [cin][k-1-r][k-1-s][cout]
+//             (taps whose numerator is not divisible by `div`, or that fall outside, read a zero page)
+//
+// Tiling: 128 (M) x BN (N) x 64 (K) per 256-thread workgroup, 2 x 2 waves, 16 (BN=128) or 8 (BN=64) 16x16
+// accumulators per wave.  A rows are 128-byte channel runs gathered straight into LDS with
+// global_load_lds_dwordx4 (per-lane SOURCE address carries both the gather and the XOR swizzle
+// chunk ^= row & 7, which makes every ds_read_b128 fragment read bank-conflict free); two LDS stages.
+// Epilogue: bf16 rounding, per-channel sum / sum-of-squares of the ROUNDED values (train-mode BatchNorm
+// statistics) via one f32 atomic per channel per wave, tile transposed through LDS and stored
+// as whole 16-byte chunks.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include "ppv_common.h"
+
+namespace ppv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+struct ConvGeom {
+    int B, Hs, Ws, Cs;   // source tensor NHWC
+    int Ho, Wo;          // output pixels per image (GEMM rows m = (b, ho, wo))
+    int N;               // GEMM columns (output channels)
+    int R, S;            // taps
+    int a, off, sh;      // source step, tap offset, log2(div)
+    long M;              // B * Ho * Wo
+};
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+
+#define GLDS16(gptr, lptr)                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                  \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// stat_part: [tiles_m][2][N] f32 per-row-tile partial (sum, sum of squares) of the bf16-rounded outputs, or null.
+// addend: optional bf16 [M][N] tensor added to the result before rounding (residual-gradient accumulation).
+template <int BN, int WM, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+                                                           void* __restrict__ Out, float* __restrict__ stat_part,
+                                                           const bf16_t* __restrict__ addend,
+                                                           const bf16_t* __restrict__ zero_page, ConvGeom g,
+                                                           int tiles_n) {
+    constexpr int BM = 128, BK = 64, WN = 4 / WM;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16 x 16 fragments per wave
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;           // stage s: A at s*STAGE_BYTES, B right behind it
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // XCD-aware tile order: blocks that share an XCD (bid % 8) walk a contiguous run of tiles, n fastest
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- per-thread staging roles: 4 A rows (+ NI*? B rows), one 16-byte chunk each
+    const int rl = lane >> 3, p = lane & 7, cch = p ^ rl;       // global chunk that lands at LDS chunk p of row rl
+    int a_h0[4], a_w0[4];
+    long a_pix[4];
+    bool a_ok[4];
+    const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + i * 32 + wave * 8 + rl;
+        a_ok[i] = m < g.M;
+        const long mm = a_ok[i] ? m : 0;
+        const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
+        const int ho = rem / g.Wo, wo = rem % g.Wo;
+        a_h0[i] = ho * g.a + g.off;
+        a_w0[i] = wo * g.a + g.off;
+        a_pix[i] = (long)b * g.Hs * g.Ws;
+    }
+    const int ktaps = g.R * g.S, kc = g.Cs / BK, nk = ktaps * kc;
+    const long wrow = (long)ktaps * g.Cs;                       // elements per weight row
+
+    auto stage = [&](int buf, int kstep) {
+        const int tap = kstep / kc, c0 = (kstep % kc) * BK;
+        const int r = tap / g.S, s = tap % g.S;
+        const int dm = (1 << g.sh) - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hn = a_h0[i] + r, wn = a_w0[i] + s;
+            const int hq = hn >> g.sh, wq = wn >> g.sh;
+            const bool ok = a_ok[i] && hn >= 0 && wn >= 0 && ((hn | wn) & dm) == 0 && hq < g.Hs && wq < g.Ws;
+            const bf16_t* src = ok ? X + ((a_pix[i] + (long)hq * g.Ws + wq) * g.Cs + c0 + cch * 8) : zero_page + cch * 8;
+            GLDS16(src, smem + buf * STAGE_BYTES + (i * 32 + wave * 8) * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < (BN + 31) / 32; ++i) {
+            if (BN >= 32 || wave < BN / 8) {
+                const int n = n0 + i * 32 + wave * 8 + rl;
+                const bf16_t* src = Wt + ((long)n * wrow + (long)tap * g.Cs + c0 + cch * 8);
+                GLDS16(src, smem + buf * STAGE_BYTES + A_BYTES + (i * 32 + wave * 8) * 128);
+            }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave / WN, wn = wave % WN;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+            const int chunk = ((kk * 4 + fq) ^ (fr & 7)) * 16;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const bf16x8*>(smem + buf * STAGE_BYTES + (wm * WROWS + mi * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                bfr[ni] = *reinterpret_cast<const bf16x8*>(smem + buf * STAGE_BYTES + A_BYTES + (wn * WCOLS + ni * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nk - 1; ++t) {
+        stage(cur ^ 1, t + 1);
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- epilogue
+    if (OUT_F32) {
+        float* out = reinterpret_cast<float*>(Out);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long m = m0 + wm * WROWS + mi * 16 + fq * 4 + j;
+                    const int n = n0 + wn * WCOLS + ni * 16 + fr;
+                    if (m < g.M) out[m * g.N + n] = acc[mi][ni][j];
+                }
+        return;
+    }
+    constexpr int LDO = BN * 2 + 16;                           // bytes per staged output row
+    char* sO = smem;                                           // 128 * LDO bytes
+    float* sStat = reinterpret_cast<float*>(smem + BM * LDO);  // [WM][2][BN]
+    constexpr int CPR = BN / 8;                                // 16-byte chunks per row
+    if (addend) {                                              // acc += addend, fragment-wise (bf16 reads, L2 resident or streamed once)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long m = m0 + wm * WROWS + mi * 16 + fq * 4 + j;
+                    const int n = n0 + wn * WCOLS + ni * 16 + fr;
+                    if (m < g.M) acc[mi][ni][j] += bf2f(addend[m * g.N + n]);
+                }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        float s1 = 0.f, s2 = 0.f;
+        const int col = wn * WCOLS + ni * 16 + fr;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t h = f2bf(acc[mi][ni][j]);
+                const float v = bf2f(h);
+                s1 += v;
+                s2 += v * v;
+                *reinterpret_cast<bf16_t*>(sO + (wm * WROWS + mi * 16 + fq * 4 + j) * LDO + col * 2) = h;
+            }
+        if (stat_part) {
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (fq == 0) {
+                sStat[(wm * 2 + 0) * BN + col] = s1;
+                sStat[(wm * 2 + 1) * BN + col] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (stat_part && tid < 2 * BN) {
+        const int which = tid / BN, col = tid % BN;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += sStat[(w * 2 + which) * BN + col];
+        stat_part[((long)tile_m * 2 + which) * g.N + n0 + col] = v;
+    }
+    bf16_t* out = reinterpret_cast<bf16_t*>(Out);
+#pragma unroll
+    for (int it = 0; it < (BM * CPR + 255) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx / CPR, ch = idx % CPR;
+        const long m = m0 + row;
+        if (idx < BM * CPR && m < g.M)
+            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+    }
+}
+
+// ----------------------------------------------------------------------------- weight re-layouts
+// torch [Cout][Cin][R][S] f32 -> forward GEMM rows [Cout][R][S][Cin] bf16
+__global__ __launch_bounds__(256) void weight_fwd_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ o, int Cout,
+                                                                int Cin, int R, int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)Cout * Cin * R * S;
+    if (i >= tot) return;
+    const int c = (int)(i % Cin);
+    const int s = (int)((i / Cin) % S), r = (int)((i / ((long)Cin * S)) % R);
+    const int n = (int)(i / ((long)Cin * S * R));
+    o[i] = f2bf(w[(((long)n * Cin + c) * R + r) * S + s]);
+}
+
+// torch [Cout][Cin][R][S] f32 -> dgrad GEMM rows [Cin][R][S][Cout] bf16, taps flipped
+__global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ o,
+                                                                  int Cout, int Cin, int R, int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)Cout * Cin * R * S;
+    if (i >= tot) return;
+    const int n = (int)(i % Cout);
+    const int s = (int)((i / Cout) % S), r = (int)((i / ((long)Cout * S)) % R);
+    const int c = (int)(i / ((long)Cout * S * R));
+    o[i] = f2bf(w[(((long)n * Cin + c) * R + (R - 1 - r)) * S + (S - 1 - s)]);
+}
+
+}  // namespace ppv
+
+using namespace ppv;
+
+extern "C" {
+
+// Generic NHWC bf16 gather-GEMM convolution (see file header).  X [B,Hs,Ws,Cs] bf16, Wt [N][R*S*Cs] bf16,
+// out [B*Ho*Wo][N] bf16 (out_f32 = 0) or f32 (out_f32 = 1: parity tests and the stem data gradient),
+// stat_part [ceil(M/128)][2][N] f32 per-row-tile BN partials (may be null), addend [M][N] bf16 (may be null),
+// zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* zero_page,
+                  int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
+                  int out_f32, hipStream_t stream) {
+    if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
+    if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
+    ConvGeom g;
+    g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
+    g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
+    g.M = (long)B * Ho * Wo;
+    const int tiles_m = (int)((g.M + 127) / 128);
+    const bf16_t* x = (const bf16_t*)X;
+    const bf16_t* w = (const bf16_t*)Wt;
+    const bf16_t* ad = (const bf16_t*)addend;
+    const bf16_t* z = (const bf16_t*)zero_page;
+#define PPV_LAUNCH(BN_, WM_, TN_)                                                                                       \
+    do {                                                                                                                \
+        if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_); \
+        else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_);        \
+    } while (0)
+    if (N == 16) PPV_LAUNCH(16, 4, 1);
+    else if (N % 128 == 0) PPV_LAUNCH(128, 2, N / 128);
+    else PPV_LAUNCH(64, 2, N / 64);
+#undef PPV_LAUNCH
+    return ppv_last_error();
+}
+
+int ppv_conv_stat_tiles(long M) { return (int)((M + 127) / 128); }
+
+// mode 0: [Cout][Cin][R][S] f32 -> [Cout][R][S][Cin] bf16 (forward);  mode 1: -> [Cin][R][S][Cout] bf16 flipped (dgrad)
+int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, hipStream_t stream) {
+    if (!w || !out) return PPV_ERR_NULL;
+    const long tot = (long)Cout * Cin * R * S;
+    const unsigned gb = (unsigned)((tot + 255) / 256);
+    if (mode == 0) weight_fwd_layout_kernel<<<gb, 256, 0, stream>>>(w, (bf16_t*)out, Cout, Cin, R, S);
+    else weight_dgrad_layout_kernel<<<gb, 256, 0, stream>>>(w, (bf16_t*)out, Cout, Cin, R, S);
+    return ppv_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// Element-wise / reduction kernels of the ResNet-101 trunk around the MFMA convolutions, NHWC bf16, gfx950.
+//
+// Train-mode BatchNorm2d + ReLU (+ residual) forward and backward (batch statistics in ALL 104 BNs,
+// eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased for the running estimate), the stem's fused
+// BN + ReLU + MaxPool 3x3/2, and the Encoder's AdaptiveAvgPool2d(36) on an 8x8 map (models.py:27,39-40; output is
+// already NHWC so the reference's permute disappears).  All HBM-bound: 16-byte accesses, fp32 math.
+#include <hip/hip_runtime.h>
+#include "ppv_common.h"
+
+namespace ppv {
+
+typedef unsigned short bf16_t;
+__device__ __forceinline__ bf16_t f2bf_(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bf2f_(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
+struct bf8 { bf16_t v[8]; };
+__device__ __forceinline__ void load8(const bf16_t* p, float (&f)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf_(f[2 * i]) | ((unsigned)f2bf_(f[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ----------------------------------------------------------------------------- BN statistics -> coefficients
+// part [T][2][C] (sum, sumsq of the bf16 conv output) -> coef [4][C] = scale, shift, mean, invstd; running stats updated.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int T, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           float momentum, float eps, float* __restrict__ coef, int C) {
+    __shared__ double s_s[16][64], s_q[16][64];
+    const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0, q = 0;
+    for (int t = tg; t < T; t += 16) {
+        s += (double)part[((long)t * 2 + 0) * C + c];
+        q += (double)part[((long)t * 2 + 1) * C + c];
+    }
+    s_s[tg][cl] = s; s_q[tg][cl] = q;
+    __syncthreads();
+    if (tg == 0) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { s += s_s[i][cl]; q += s_q[i][cl]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        coef[c] = sc;
+        coef[C + c] = beta[c] - (float)mean * sc;
+        coef[2 * C + c] = (float)mean;
+        coef[3 * C + c] = invstd;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+            const double unb = count > 1 ? var * count / (count - 1.0) : var;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- BN apply (+ residual) (+ ReLU)
+// y = act(x*s1 + t1 + res),  res = 0 | r | r*s2 + t2
+template <int RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ x, const float* __restrict__ coef1,
+                                                     const bf16_t* __restrict__ r, const float* __restrict__ coef2,
+                                                     bf16_t* __restrict__ y, long n8, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int c0 = (int)((i * 8) % C);
+    float xv[8], rv[8], o[8];
+    load8(x + i * 8, xv);
+    if (RES) load8(r + i * 8, rv);
+    const float4 sa = *reinterpret_cast<const float4*>(coef1 + c0), sb = *reinterpret_cast<const float4*>(coef1 + c0 + 4);
+    const float4 ta = *reinterpret_cast<const float4*>(coef1 + C + c0), tb = *reinterpret_cast<const float4*>(coef1 + C + c0 + 4);
+    const float s1[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float t1[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = xv[k] * s1[k] + t1[k];
+        if (RES == 1) v += rv[k];
+        if (RES == 2) v += rv[k] * coef2[c0 + k] + coef2[C + c0 + k];
+        o[k] = RELU ? fmaxf(v, 0.f) : v;
+    }
+    store8(y + i * 8, o);
+}
+
+// ----------------------------------------------------------------------------- BN backward
+// pass 1: per-channel partial sums of g_pre and g_pre * x, g_pre = g_y * (y > 0) [RELU] ; part [nblk][2][C]
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                            const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                            long rows, int C, int rows_per_blk) {
+    __shared__ float s_red[256][17];
+    const int tpr = C / 8;                         // threads per row
+    const int rpp = 256 / tpr;                     // rows per pass
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const long r0 = (long)blockIdx.x * rows_per_blk;
+    const long r1 = min(rows, r0 + rows_per_blk);
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = b[k] = 0.f;
+    if (tr < rpp) {
+        for (long row = r0 + tr; row < r1; row += rpp) {
+            const long o = row * C + tc * 8;
+            float g[8], xv[8], yv[8];
+            load8(gy + o, g);
+            load8(x + o, xv);
+            if (RELU) load8(y + o, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gp = (RELU && !(yv[k] > 0.f)) ? 0.f : g[k];
+                a[k] += gp;
+                b[k] += gp * xv[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s_red[threadIdx.x][k] = a[k]; s_red[threadIdx.x][8 + k] = b[k]; }
+    __syncthreads();
+    // thread t < 2*C handles (which = t / C, channel = t % C)
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        const int which = t / C, c = t % C;
+        const int tcc = c / 8, k = c % 8;
+        float v = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) v += s_red[rr * tpr + tcc][which * 8 + k];
+        part[((long)blockIdx.x * 2 + which) * C + c] = v;
+    }
+}
+
+// reduce the partials, emit per-channel backward coefficients kc [3][C] (g_x = kc0*g_pre + kc1*x + kc2) and, if
+// requested, the affine-parameter gradients dgamma / dbeta (f32 [C]).
+__global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(const float* __restrict__ part, int nblk, double count,
+                                                           const float* __restrict__ coef, float* __restrict__ kc,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+    __shared__ double s_a[16][64], s_b[16][64];
+    const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a = 0, b = 0;
+    for (int t = tg; t < nblk; t += 16) {
+        a += (double)part[((long)t * 2 + 0) * C + c];
+        b += (double)part[((long)t * 2 + 1) * C + c];
+    }
+    s_a[tg][cl] = a; s_b[tg][cl] = b;
+    __syncthreads();
+    if (tg == 0) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { a += s_a[i][cl]; b += s_b[i][cl]; }
+        const double scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
+        const double dbeta_ = a;                               // sum g_pre
+        const double dgam = invstd * (b - mean * a);           // sum g_pre * xhat
+        // g_x = scale * (g_pre - dbeta/cnt - xhat * dgam/cnt),  xhat = (x - mean) * invstd
+        kc[c] = (float)scale;
+        kc[C + c] = (float)(-scale * invstd * dgam / count);
+        kc[2 * C + c] = (float)(-scale * dbeta_ / count + scale * invstd * mean * dgam / count);
+        if (dgamma) dgamma[c] = (float)dgam;
+        if (dbeta) dbeta[c] = (float)dbeta_;
+    }
+}
+
+// pass 2: g_x = kc0*g_pre + kc1*x + kc2 ; optionally also store g_pre (the residual branch's gradient)
+template <bool RELU, bool WRITE_GPRE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ x, const float* __restrict__ kc,
+                                                           bf16_t* __restrict__ gx, bf16_t* __restrict__ gpre, long n8,
+                                                           int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int c0 = (int)((i * 8) % C);
+    float g[8], xv[8], yv[8], o[8], gp[8];
+    load8(gy + i * 8, g);
+    load8(x + i * 8, xv);
+    if (RELU) load8(y + i * 8, yv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        gp[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : g[k];
+        o[k] = kc[c0 + k] * gp[k] + kc[C + c0 + k] * xv[k] + kc[2 * C + c0 + k];
+    }
+    store8(gx + i * 8, o);
+    if (WRITE_GPRE) store8(gpre + i * 8, gp);
+}
+
+// ----------------------------------------------------------------------------- stem: BN + ReLU + MaxPool 3x3/2 pad 1
+// raw [B,H,W,C] bf16 -> pooled [B,H/2,W/2,C] bf16 (+ argmax tap 0..8, first maximum in scan order as torch)
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const bf16_t* __restrict__ x, const float* __restrict__ coef,
+                                                              bf16_t* __restrict__ y, unsigned char* __restrict__ arg,
+                                                              int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)B * Ho * Wo * c8n;
+    if (i >= tot) return;
+    const int c0 = (int)(i % c8n) * 8;
+    const int wo = (int)((i / c8n) % Wo), ho = (int)((i / ((long)c8n * Wo)) % Ho), b = (int)(i / ((long)c8n * Wo * Ho));
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int h = 2 * ho - 1 + r, w = 2 * wo - 1 + s;
+            if (h < 0 || w < 0 || h >= H || w >= W) continue;
+            float xv[8];
+            load8(x + (((long)b * H + h) * W + w) * C + c0, xv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // the activation is stored as bf16 downstream: compare the ROUNDED values
+                const float v = bf2f_(f2bf_(fmaxf(xv[k] * coef[c0 + k] + coef[C + c0 + k], 0.f)));
+                if (v > best[k]) { best[k] = v; bi[k] = r * 3 + s; }
+            }
+        }
+    store8(y + i * 8, best);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) packed |= (unsigned long long)bi[k] << (8 * k);
+    *reinterpret_cast<unsigned long long*>(arg + i * 8) = packed;
+}
+
+// backward of the above down to the ReLU input: g_pre[b,h,w,c] = sum over the <= 4 windows that picked (h,w)
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                               const unsigned char* __restrict__ arg,
+                                                               bf16_t* __restrict__ gpre, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)B * H * W * c8n;
+    if (i >= tot) return;
+    const int c0 = (int)(i % c8n) * 8;
+    const int w = (int)((i / c8n) % W), h = (int)((i / ((long)c8n * W)) % H), b = (int)(i / ((long)c8n * W * H));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    // windows (ho,wo) with 2ho-1+r = h  ->  ho in {(h+1)/2 - 1 .. (h+1)/2}, r = h + 1 - 2 ho in [0,2]
+    for (int ho = (h + 1) / 2 - 1; ho <= (h + 1) / 2; ++ho) {
+        const int r = h + 1 - 2 * ho;
+        if (ho < 0 || ho >= Ho || r < 0 || r > 2) continue;
+        for (int wo = (w + 1) / 2 - 1; wo <= (w + 1) / 2; ++wo) {
+            const int s = w + 1 - 2 * wo;
+            if (wo < 0 || wo >= Wo || s < 0 || s > 2) continue;
+            const long o = (((long)b * Ho + ho) * Wo + wo) * C + c0;
+            const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(arg + o);
+            float g[8], yv[8];
+            load8(gy + o, g);
+            load8(y + o, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((int)((packed >> (8 * k)) & 0xff) == r * 3 + s && yv[k] > 0.f) acc[k] += g[k];
+        }
+    }
+    store8(gpre + i * 8, acc);
+}
+
+// ----------------------------------------------------------------------------- AdaptiveAvgPool2d(E) on [B,H,W,C]
+// window of output i: [floor(i*H/E), ceil((i+1)*H/E))  (torch adaptive pooling)
+template <typename TO>
+__global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const bf16_t* __restrict__ x, TO* __restrict__ y, int B, int H,
+                                                                int W, int C, int E) {
+    const int c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)B * E * E * c8n;
+    if (i >= tot) return;
+    const int c0 = (int)(i % c8n) * 8;
+    const int ox = (int)((i / c8n) % E), oy = (int)((i / ((long)c8n * E)) % E), b = (int)(i / ((long)c8n * E * E));
+    const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E, w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) {
+            float v[8];
+            load8(x + (((long)b * H + h) * W + w) * C + c0, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+    TO* o = y + i * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (TO)(acc[k] * inv);
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const TG* __restrict__ gy, bf16_t* __restrict__ gx, int B, int H,
+                                                                int W, int C, int E) {
+    const int c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)B * H * W * c8n;
+    if (i >= tot) return;
+    const int c0 = (int)(i % c8n) * 8;
+    const int w = (int)((i / c8n) % W), h = (int)((i / ((long)c8n * W)) % H), b = (int)(i / ((long)c8n * W * H));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    // outputs whose window contains h: oy in [floor(h*E/H) - 1, ceil((h+1)*E/H)]
+    const int oy_lo = max(0, (h * E) / H - 1), oy_hi = min(E - 1, ((h + 1) * E + H - 1) / H);
+    const int ox_lo = max(0, (w * E) / W - 1), ox_hi = min(E - 1, ((w + 1) * E + W - 1) / W);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E;
+        if (h < h0 || h >= h1) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const int w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
+            if (w < w0 || w >= w1) continue;
+            const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+            const TG* g = gy + ((((long)b * E + oy) * E + ox) * C + c0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += (float)g[k] * inv;
+        }
+    }
+    store8(gx + i * 8, acc);
+}
+
+}  // namespace ppv
+
+using namespace ppv;
+
+extern "C" {
+
+int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float momentum, float eps, float* coef, int C, hipStream_t stream) {
+    if (!part || !gamma || !beta || !coef) return PPV_ERR_NULL;
+    if (C % 64) return PPV_ERR_BAD_SIZE;
+    bn_finalize_kernel<<<C / 64, 1024, 0, stream>>>(part, T, count, gamma, beta, run_mean, run_var, momentum, eps, coef, C);
+    return ppv_last_error();
+}
+
+// y = act(x*s1+t1 + res);  res_mode 0 none, 1 identity r, 2 r*s2+t2 (coef2)
+int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, long n, int C, int res_mode,
+               int relu, hipStream_t stream) {
+    if (!x || !coef1 || !y || (res_mode && !r) || (res_mode == 2 && !coef2)) return PPV_ERR_NULL;
+    if (C % 8 || n % 8) return PPV_ERR_BAD_SIZE;
+    const long n8 = n / 8;
+    const unsigned gb = (unsigned)((n8 + 255) / 256);
+    const bf16_t *xx = (const bf16_t*)x, *rr = (const bf16_t*)r;
+    bf16_t* yy = (bf16_t*)y;
+    if (res_mode == 0 && relu) bn_act_kernel<0, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    else if (res_mode == 0) bn_act_kernel<0, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    else if (res_mode == 1 && relu) bn_act_kernel<1, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    else if (res_mode == 1) bn_act_kernel<1, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    else if (relu) bn_act_kernel<2, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    else bn_act_kernel<2, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    return ppv_last_error();
+}
+
+int ppv_bn_bwd_blocks(long rows, int C) {
+    const int rpp = 256 / (C / 8);
+    long rpb = (long)rpp * 16;
+    long nb = (rows + rpb - 1) / rpb;
+    while (nb > 2048) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
+    return (int)nb;
+}
+
+// Train-mode BN backward (+ ReLU mask from y when relu != 0).  Writes g_x (bf16), optionally g_pre (bf16, may be
+// null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= ppv_bn_bwd_blocks * 2 * C floats; kc: scratch 3*C.
+int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
+               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, hipStream_t stream) {
+    if (!gy || !x || !coef || !gx || !part || !kc || (relu && !y)) return PPV_ERR_NULL;
+    if (C % 64 || C > 2048) return PPV_ERR_BAD_SIZE;
+    const int rpp = 256 / (C / 8);
+    long rpb = (long)rpp * 16;
+    long nb = (rows + rpb - 1) / rpb;
+    while (nb > 2048) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
+    const bf16_t *g = (const bf16_t*)gy, *yy = (const bf16_t*)y, *xx = (const bf16_t*)x;
+    if (relu) bn_bwd_reduce_kernel<true><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
+    else bn_bwd_reduce_kernel<false><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
+    bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, (int)nb, count, coef, kc, dgamma, dbeta, C);
+    const long n8 = rows * C / 8;
+    const unsigned gb = (unsigned)((n8 + 255) / 256);
+    bf16_t *ox = (bf16_t*)gx, *op = (bf16_t*)gpre;
+    if (relu && gpre) bn_bwd_apply_kernel<true, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
+    else if (relu) bn_bwd_apply_kernel<true, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
+    else if (gpre) bn_bwd_apply_kernel<false, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
+    else bn_bwd_apply_kernel<false, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
+    return ppv_last_error();
+}
+
+int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, int B, int H, int W, int C,
+                        hipStream_t stream) {
+    if (!x || !coef || !y || !arg) return PPV_ERR_NULL;
+    if (C % 8 || H % 2 || W % 2) return PPV_ERR_BAD_SIZE;
+    const long tot = (long)B * (H / 2) * (W / 2) * (C / 8);
+    bn_relu_maxpool_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)x, coef, (bf16_t*)y,
+                                                                             (unsigned char*)arg, B, H, W, C);
+    return ppv_last_error();
+}
+
+int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* gpre, int B, int H, int W, int C,
+                         hipStream_t stream) {
+    if (!gy || !y || !arg || !gpre) return PPV_ERR_NULL;
+    const long tot = (long)B * H * W * (C / 8);
+    maxpool_relu_bwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y,
+                                                                              (const unsigned char*)arg, (bf16_t*)gpre, B, H, W, C);
+    return ppv_last_error();
+}
+
+int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, hipStream_t stream) {
+    if (!x || !y) return PPV_ERR_NULL;
+    if (C % 8) return PPV_ERR_BAD_SIZE;
+    const long tot = (long)B * E * E * (C / 8);
+    const unsigned gb = (unsigned)((tot + 255) / 256);
+    if (out_f32) adaptive_pool_fwd_kernel<float><<<gb, 256, 0, stream>>>((const bf16_t*)x, (float*)y, B, H, W, C, E);
+    else adaptive_pool_fwd_kernel<__bf16><<<gb, 256, 0, stream>>>((const bf16_t*)x, (__bf16*)y, B, H, W, C, E);
+    return ppv_last_error();
+}
+
+int ppv_adaptive_pool_bwd(const void* gy, void* gx, int B, int H, int W, int C, int E, int g_f32, hipStream_t stream) {
+    if (!gy || !gx) return PPV_ERR_NULL;
+    const long tot = (long)B * H * W * (C / 8);
+    const unsigned gb = (unsigned)((tot + 255) / 256);
+    if (g_f32) adaptive_pool_bwd_kernel<float><<<gb, 256, 0, stream>>>((const float*)gy, (bf16_t*)gx, B, H, W, C, E);
+    else adaptive_pool_bwd_kernel<__bf16><<<gb, 256, 0, stream>>>((const __bf16*)gy, (bf16_t*)gx, B, H, W, C, E);
+    return ppv_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""GPU parity of the trunk kernels around the convolutions: weight gradient, stem conv (+ data gradient), train-mode
+BatchNorm (+ residual + ReLU) forward/backward, stem max-pool and the adaptive average pool -- each against torch
+CPU fp32 on the same bf16-rounded operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BF = 2 ** -8 + 1e-3      # one bf16 rounding of the stored result + north_star 1e-3
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def r16(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", [(4, 16, 128, 128, 3, 1), (2, 16, 256, 128, 1, 1), (3, 16, 128, 256, 3, 2),
+                                                   (2, 8, 256, 512, 1, 2), (9, 8, 128, 128, 3, 1)])
+def test_conv_wgrad(B, H, Cin, Cout, k, stride):
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(0)
+    x = r16(torch.randn(B, Cin, H, H, generator=g0))
+    w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    pad = (k - 1) // 2
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    g = r16(torch.randn(y.shape, generator=g0))
+    y.backward(g)
+    got = co.conv_wgrad(nhwc(g).cuda().bfloat16(), nhwc(x).cuda().bfloat16(), k, k, stride, pad)
+    assert rel_err(got, w.grad) < 1e-3
+
+
+def test_stem_forward_and_data_gradient():
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(0)
+    B, H = 3, 64
+    img = torch.rand(B, 3, H, H, generator=g0)
+    w = r16(torch.randn(64, 3, 7, 7, generator=g0) * 0.1)
+    x = r16(img).requires_grad_(True)                       # the kernel rounds the f32 sensor image to bf16 operands
+    y = F.conv2d(x, w, stride=2, padding=3)
+    tiles = co.stat_tiles(B * (H // 2) ** 2)
+    part = torch.zeros(tiles, 2, 64, device="cuda")
+    got = co.stem_conv(img.cuda(), co.stem_weight_layout(w.cuda(), 0), part)
+    assert rel_err(got.float(), nhwc(y)) < BF
+    gf = got.float().reshape(-1, 64)
+    assert rel_err(part.sum(0)[0], gf.sum(0)) < 1e-4 and rel_err(part.sum(0)[1], (gf * gf).sum(0)) < 1e-4
+    g = r16(torch.randn(y.shape, generator=g0))
+    y.backward(g)
+    gd = co.stem_dgrad(nhwc(g).cuda().bfloat16(), co.stem_weight_layout(w.cuda(), 1))
+    assert rel_err(gd, x.grad) < 1e-3
+
+
+@pytest.mark.parametrize("C,res_mode", [(64, 0), (256, 1), (512, 2), (2048, 1)])
+def test_batchnorm_train_forward_backward(C, res_mode):
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(1)
+    B, H = 4, 8
+    x = r16(torch.randn(B, C, H, H, generator=g0) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g0) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g0) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    res = r16(torch.randn(B, C, H, H, generator=g0)) if res_mode else None
+    z = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if res_mode == 1:
+        z = z + res
+    if res_mode == 2:
+        g2, b2 = torch.rand(C, generator=g0) + 0.5, torch.randn(C, generator=g0) * 0.1
+        z = z + res * g2.view(1, C, 1, 1) + b2.view(1, C, 1, 1)
+    y = F.relu(z)
+    gy = r16(torch.randn(y.shape, generator=g0))
+    y.backward(gy)
+    # product: statistics come from the conv epilogue; emulate its partials from the bf16 tensor
+    xd = nhwc(x.detach()).cuda().bfloat16()
+    xf = xd.float().reshape(-1, C)
+    part = torch.stack([xf.sum(0), (xf * xf).sum(0)])[None].contiguous()
+    rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    coef = co.bn_finalize(part, xf.shape[0], gamma.detach().cuda(), beta.detach().cuda(), rmd, rvd)
+    assert rel_err(rmd, rm) < 1e-4 and rel_err(rvd, rv) < 1e-4
+    resd = nhwc(res).cuda().bfloat16() if res_mode else None
+    coef2 = torch.stack([g2, b2, g2, g2]).cuda().contiguous() if res_mode == 2 else None
+    yd = co.bn_act(xd, coef, resd, coef2, relu=True)
+    assert rel_err(yd.float(), nhwc(y.detach())) < BF
+    gx, gpre, dg, db = co.bn_bwd(nhwc(gy).cuda().bfloat16(), yd, xd, coef, relu=True, want_gpre=True)
+    assert rel_err(gx.float(), nhwc(x.grad)) < 2 * BF
+    assert rel_err(dg, gamma.grad) < 5e-3 and rel_err(db, beta.grad) < 5e-3
+    mask = (nhwc(y.detach()) > 0).float()
+    assert rel_err(gpre.float() * mask.cuda(), nhwc(gy) * mask) < BF
+
+
+def test_stem_bn_relu_maxpool_forward_backward():
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(2)
+    B, H, C = 2, 16, 64
+    x = r16(torch.randn(B, C, H, H, generator=g0))
+    scale, shift = torch.rand(C, generator=g0) + 0.5, torch.randn(C, generator=g0) * 0.2
+    a = r16(F.relu(x * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1))).requires_grad_(True)
+    y = F.max_pool2d(a, 3, stride=2, padding=1)
+    gy = r16(torch.randn(y.shape, generator=g0))
+    y.backward(gy)
+    coef = torch.stack([scale, shift, scale, scale]).cuda().contiguous()
+    yd, arg = co.bn_relu_maxpool(nhwc(x).cuda().bfloat16(), coef)
+    assert rel_err(yd.float(), nhwc(y.detach())) < 1e-6
+    gpre = co.maxpool_relu_bwd(nhwc(gy).cuda().bfloat16(), yd, arg, (H, H))
+    want = nhwc(a.grad * (a.detach() > 0))
+    assert rel_err(gpre.float(), want) < BF
+
+
+def test_adaptive_pool_8_to_36():
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(3)
+    x = r16(torch.randn(2, 2048, 8, 8, generator=g0)).requires_grad_(True)
+    y = F.adaptive_avg_pool2d(x, 36)
+    gy = torch.randn(y.shape, generator=g0)
+    y.backward(gy)
+    yd = co.adaptive_pool_fwd(nhwc(x.detach()).cuda().bfloat16(), 36)
+    assert yd.shape == (2, 36, 36, 2048) and yd.dtype == torch.float32
+    assert rel_err(yd, nhwc(y.detach())) < 1e-6
+    gx = co.adaptive_pool_bwd(nhwc(gy).cuda(), (8, 8))
+    assert rel_err(gx.float(), nhwc(x.grad)) < BF

@@ -1,0 +1,245 @@
+"""Drop-in for reference ``Image_Caption/models.py:8 Encoder`` (torchvision ResNet-101 trunk) on MI355X.
+
+Same constructor, ``forward(images) -> [B, E, E, 2048]``, ``fine_tune()``, attribute ``.resnet`` with
+torchvision-compatible ``state_dict`` keys (``resnet.0.weight``, ``resnet.1.*``, ``resnet.4..7.<i>.conv1.weight`` ...)
+and ``.adaptive_pool``.  The ``torch.nn`` sub-modules are PARAMETER HOLDERS only: the whole trunk runs as one
+``torch.autograd.Function`` whose forward/backward launch the hand-written HIP kernels of libppv_hip.so on NHWC
+bfloat16 activations (fp32 accumulation, fp32 BatchNorm statistics, fp32 weight gradients).
+"""
+import torch
+from torch import nn
+
+from . import convops as co
+
+LAYERS = (3, 4, 23, 3)
+PLANES = (64, 128, 256, 512)
+
+
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck parameter layout (v1.5: stride on conv2)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("parameter holder: the trunk runs through ppv_amd.encoder.Encoder.forward")
+
+
+def _make_trunk(layers):
+    inplanes = 64
+    mods = [nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, stride=2, padding=1)]
+    for i, (planes, n) in enumerate(zip(PLANES, layers)):
+        stride = 1 if i == 0 else 2
+        blocks = []
+        for b in range(n):
+            ds = None
+            if b == 0 and (stride != 1 or inplanes != planes * 4):
+                ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+            blocks.append(Bottleneck(inplanes, planes, stride if b == 0 else 1, ds))
+            inplanes = planes * 4
+        mods.append(nn.Sequential(*blocks))
+    net = nn.Sequential(*mods)
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return net
+
+
+class _ConvRec:
+    """one conv + its BatchNorm, with cached bf16 kernel layouts keyed on the parameter version."""
+    __slots__ = ("conv", "bn", "k", "stride", "pad", "_wt", "_wd", "_ver_t", "_ver_d", "stem")
+
+    def __init__(self, conv, bn, stem=False):
+        self.conv, self.bn = conv, bn
+        self.k, self.stride, self.pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        self._wt = self._wd = None
+        self._ver_t = self._ver_d = -1
+        self.stem = stem
+
+    def wt(self):
+        w = self.conv.weight
+        if self._wt is None or self._ver_t != w._version or self._wt.device != w.device:
+            self._wt = co.stem_weight_layout(w.detach(), 0) if self.stem else co.weight_layout(w.detach(), 0)
+            self._ver_t = w._version
+        return self._wt
+
+    def wd(self):
+        w = self.conv.weight
+        if self._wd is None or self._ver_d != w._version or self._wd.device != w.device:
+            self._wd = co.stem_weight_layout(w.detach(), 1) if self.stem else co.weight_layout(w.detach(), 1)
+            self._ver_d = w._version
+        return self._wd
+
+
+def _bn_coef(rec, stat_part, count):
+    bn = rec.bn
+    if bn.training:
+        return co.bn_finalize(stat_part, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                              bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight.detach() * invstd
+    return torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
+
+
+class _TrunkFn(torch.autograd.Function):
+    """(images f32 NCHW, *params) -> [B,E,E,2048] f32.  params follow Encoder._param_list()."""
+
+    @staticmethod
+    def forward(ctx, enc, images, *params):
+        images = images.contiguous().float()
+        B, _, H, W = images.shape
+        dev = images.device
+        train = enc.resnet[1].training
+        saved = {}
+
+        def part_for(M, C):
+            return torch.empty((co.stat_tiles(M), 2, C), dtype=torch.float32, device=dev) if train else None
+
+        # ---- stem: conv 7x7/2 + BN + ReLU + maxpool 3x3/2  (resnet.0-3)
+        st = enc._stem
+        Ho, Wo = H // 2, W // 2
+        p0 = part_for(B * Ho * Wo, 64)
+        raw0 = co.stem_conv(images, st.wt(), p0)
+        c0 = _bn_coef(st, p0, B * Ho * Wo)
+        y0, arg0 = co.bn_relu_maxpool(raw0, c0)
+        saved["stem"] = (raw0, c0, y0, arg0)
+        x = y0
+        blocks = []
+        for blk in enc._blocks:
+            xin = x
+            r1, r2, r3, rd = blk
+            Bn, Hin, Win, _ = xin.shape
+            p = part_for(Bn * Hin * Win, r1.conv.out_channels)
+            x1 = co.conv_fwd(xin, r1.wt(), 1, 0, p)
+            c1 = _bn_coef(r1, p, Bn * Hin * Win)
+            y1 = co.bn_act(x1, c1)
+            H2, W2 = Hin // r2.stride, Win // r2.stride
+            p = part_for(Bn * H2 * W2, r2.conv.out_channels)
+            x2 = co.conv_fwd(y1, r2.wt(), r2.stride, 1, p)
+            c2 = _bn_coef(r2, p, Bn * H2 * W2)
+            y2 = co.bn_act(x2, c2)
+            p = part_for(Bn * H2 * W2, r3.conv.out_channels)
+            x3 = co.conv_fwd(y2, r3.wt(), 1, 0, p)
+            c3 = _bn_coef(r3, p, Bn * H2 * W2)
+            if rd is not None:
+                p = part_for(Bn * H2 * W2, rd.conv.out_channels)
+                xd = co.conv_fwd(xin, rd.wt(), rd.stride, 0, p)
+                cd = _bn_coef(rd, p, Bn * H2 * W2)
+                yout = co.bn_act(x3, c3, res=xd, coef_res=cd)
+            else:
+                xd = cd = None
+                yout = co.bn_act(x3, c3, res=xin)
+            blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout))
+            x = yout
+        out = co.adaptive_pool_fwd(x, enc.enc_image_size)
+        if train:
+            torch._foreach_add_(enc._nbt, 1)
+        ctx.enc, ctx.saved, ctx.blocks, ctx.train = enc, saved, blocks, train
+        ctx.img_shape, ctx.last_hw = images.shape, (x.shape[1], x.shape[2])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        enc = ctx.enc
+        if not ctx.train:
+            raise NotImplementedError("backward through eval-mode BatchNorm is outside the reference's use (validate() "
+                                      "runs under no_grad, train.py:355-451)")
+        grads = {}
+
+        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False):
+            trainable = rec.conv.weight.requires_grad
+            gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad)
+            if trainable:
+                grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad)
+            if rec.bn.weight.requires_grad:
+                grads[rec.bn.weight], grads[rec.bn.bias] = dg, db
+            return gx, gpre
+
+        g = co.adaptive_pool_bwd(g_out.contiguous(), ctx.last_hw)
+        taps = getattr(enc, "_debug_block_grads", None)      # tests: per-block (g_out, g_in) taps, last block first
+        for blk, sv in zip(reversed(enc._blocks), reversed(ctx.blocks)):
+            g_blk_out = g
+            r1, r2, r3, rd = blk
+            xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout = sv
+            hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
+            gx3, gpre = conv_bn_bwd(r3, g, yout, x3, c3, y2, True, want_gpre=True)
+            gy2 = co.conv_dgrad(gx3, r3.wd(), 1, 0, hw_mid)
+            gx2, _ = conv_bn_bwd(r2, gy2, y2, x2, c2, y1, True)
+            gy1 = co.conv_dgrad(gx2, r2.wd(), r2.stride, 1, hw_in)
+            gx1, _ = conv_bn_bwd(r1, gy1, y1, x1, c1, xin, True)
+            if rd is not None:
+                gxd, _ = conv_bn_bwd(rd, gpre, None, xd, cd, xin, False)
+                gin = co.conv_dgrad(gxd, rd.wd(), rd.stride, 0, hw_in)
+                g = co.conv_dgrad(gx1, r1.wd(), 1, 0, hw_in, addend=gin)
+            else:
+                g = co.conv_dgrad(gx1, r1.wd(), 1, 0, hw_in, addend=gpre)
+            if taps is not None:
+                taps.append((g_blk_out, g))
+        g_img = None
+        needs_img = ctx.needs_input_grad[1]
+        if needs_img or enc._stem.bn.weight.requires_grad or enc._stem.conv.weight.requires_grad:
+            raw0, c0, y0, arg0 = ctx.saved["stem"]
+            gpre0 = co.maxpool_relu_bwd(g, y0, arg0, (raw0.shape[1], raw0.shape[2]))
+            st = enc._stem
+            if st.conv.weight.requires_grad:
+                raise NotImplementedError("the stem convolution is frozen in the reference (models.py:43-54)")
+            gx0, _, dg, db = co.bn_bwd(gpre0, None, raw0, c0, False, want_affine=st.bn.weight.requires_grad)
+            if st.bn.weight.requires_grad:
+                grads[st.bn.weight], grads[st.bn.bias] = dg, db
+            if needs_img:
+                g_img = co.stem_dgrad(gx0, st.wd())
+        return (None, g_img) + tuple(grads.get(p) for p in enc._param_list())
+
+
+class Encoder(nn.Module):
+    """Encoder (models.py:8-54).  ``layers`` (extra, keyword) shrinks the trunk for tests; default = ResNet-101."""
+
+    def __init__(self, encoded_image_size=36, *, layers=LAYERS):
+        super().__init__()
+        self.enc_image_size = encoded_image_size
+        # the reference loads ImageNet weights (models.py:17); offline there are none: torchvision's random init
+        self.resnet = _make_trunk(layers)
+        self.adaptive_pool = nn.AdaptiveAvgPool2d((encoded_image_size, encoded_image_size))
+        self._index()
+        self.fine_tune()
+
+    def _index(self):
+        r = self.resnet
+        object.__setattr__(self, "_stem", _ConvRec(r[0], r[1], stem=True))
+        blocks = []
+        for li in range(4, 8):
+            for b in r[li]:
+                rd = _ConvRec(b.downsample[0], b.downsample[1]) if b.downsample is not None else None
+                blocks.append((_ConvRec(b.conv1, b.bn1), _ConvRec(b.conv2, b.bn2), _ConvRec(b.conv3, b.bn3), rd))
+        object.__setattr__(self, "_blocks", blocks)
+
+    def _param_list(self):
+        return list(self.resnet.parameters())
+
+    @property
+    def _nbt(self):
+        return [m.num_batches_tracked for m in self.resnet.modules() if isinstance(m, nn.BatchNorm2d)]
+
+    def forward(self, images):
+        if not images.is_cuda:
+            raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
+        return _TrunkFn.apply(self, images, *self._param_list())
+
+    def fine_tune(self, fine_tune=True):
+        """models.py:43-54: freeze everything, then un-freeze children [5:] (layer2..4)."""
+        for p in self.resnet.parameters():
+            p.requires_grad = False
+        for c in list(self.resnet.children())[5:]:
+            for p in c.parameters():
+                p.requires_grad = fine_tune

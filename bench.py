@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/sec, forward + backward (+ optimiser), learned-optics Camera + ResNet-101
+encoder at 256 x 256 on N MI355X (BASELINE.json metric).  One process per GPU; RCCL gradient all-reduce for N > 1.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step reproduces reference Image_Caption/train.py:259-323 without the caption decoder (a "next" row):
+camera(imgs, None, "3") -> encoder(sensor) -> loss = 0.4 * head(enc_out) + 6 * (1 - MSE(imgs, sensor)) + 30 * loss_psf
+-> zero_grad -> backward -> camera Adam(5e-7) -> clamp encoder grads to +-5 -> encoder Adam(1e-4) -> clamp coeffs.
+Rank 0 prints ONE JSON line (contract in the task statement), with `roofline` (the dominant MFMA conv kernel, timed
+live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0          # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+TRUNK_GFLOP_PER_IMG = 59.07              # SURVEY 8d / BASELINE.md: fwd 20.37 + dgrad 20.37 + wgrad 18.32 (layer2-4)
+
+
+def build(device, global_max_sync):
+    import ppv_amd  # noqa: F401
+    from ppv_amd.camera_lens import OpticsZernike
+    from ppv_amd.encoder import Encoder
+    camera = OpticsZernike(input_shape=[None, 256, 256, 3], device=device, zernike_terms=350, patch_size=256,
+                           height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[896, 896],
+                           sample_interval=3e-06, upsample=False, coeff_layout="B", global_max_sync=global_max_sync)
+    gold = os.path.join(ROOT, "tests", "golden", "ic_real.npz")
+    if os.path.exists(gold):                                   # the coefficients of the reference's Camera/Model.pth
+        c = torch.tensor(np.load(gold)["modelpth_coeffs"]).reshape(-1, 1, 1)
+        camera.load_state_dict({"zernike_coeffs_no_train": c[:3], "zernike_coeffs_train": c[3:]})
+    torch.manual_seed(2)
+    encoder = Encoder().to(device)
+    encoder.train()
+    camera.train()
+    return camera, encoder
+
+
+class GradSync:
+    """Data-parallel gradient averaging over RCCL (torch.distributed 'nccl'), bucketed, on a side HIP stream."""
+
+    def __init__(self, params, bucket_mb=64):
+        self.params = params
+        self.world = dist.get_world_size()
+        self.stream = torch.cuda.Stream()
+        self.bucket_bytes = bucket_mb << 20
+
+    def run(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            bucket, size = [], 0
+            for p in reversed(self.params):                    # reverse layer order: the order backward produced them
+                if p.grad is None:
+                    continue
+                bucket.append(p.grad)
+                size += p.grad.numel() * 4
+                if size >= self.bucket_bytes:
+                    self._reduce(bucket)
+                    bucket, size = [], 0
+            if bucket:
+                self._reduce(bucket)
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+    def _reduce(self, grads):
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def make_step(camera, encoder, batch, device, sync):
+    enc_params = [p for p in encoder.parameters() if p.requires_grad]
+    cam_params = [p for p in camera.parameters() if p.requires_grad]
+    opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True)
+    opt_cam = torch.optim.Adam(cam_params, lr=5e-7)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    imgs = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(device)
+
+    def step():
+        sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
+        enc_out = encoder(sensor)
+        # stand-in for CE + attention regulariser (the decoder is a next row): one read forward, one write backward
+        loss_head = torch.linalg.vector_norm(enc_out) ** 2 / enc_out.numel()
+        loss_cam = 1 - torch.nn.functional.mse_loss(imgs, sensor)
+        loss = 0.4 * loss_head + 6 * loss_cam + 30 * loss_psf
+        opt_enc.zero_grad(set_to_none=True)
+        opt_cam.zero_grad(set_to_none=True)
+        loss.backward()
+        if sync is not None:
+            sync.run()
+        opt_cam.step()
+        grads = [p.grad for p in enc_params]                                      # clip_gradient, train.py:311-316
+        torch._foreach_clamp_min_(grads, -5.0)
+        torch._foreach_clamp_max_(grads, 5.0)
+        opt_enc.step()
+        camera.zernike_coeffs_train[1:].data.clamp_(-1, 1)                        # train.py:322-323
+        return loss
+
+    return step, enc_params + cam_params
+
+
+def roofline_of_dominant_kernel(step):
+    """One extra instrumented step: every conv launch is bracketed by HIP events on its own stream."""
+    import ppv_amd.convops as co
+    torch.cuda.synchronize()
+    co.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    rec, co.PROFILE = co.PROFILE, None
+    agg = {}
+    for kind, flops, e0, e1 in rec:
+        a = agg.setdefault(kind, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    dom = max(agg, key=lambda k: agg[k][0])
+    fl, sec, n = agg[dom]
+    achieved = fl / sec / 1e12
+    detail = {k: {"launches": v[2], "tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3)} for k, v in agg.items()}
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+            "avg_launch_us": round(sec / n * 1e6, 2), "per_kernel": detail}
+
+
+def cpu_baseline(camera):
+    """The CPU oracle (oracle/: torch-CPU restatement of the reference camera + torch.nn ResNet-101) on B = 4 images."""
+    from oracle import ic_camera as ic
+    from oracle.resnet import Encoder as OEncoder
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 4
+    vol = camera.zernike_volume.cpu()
+    coeffs = camera._concat().detach().cpu().requires_grad_(True)
+    m1, m2 = ic.disk_masks()
+    torch.manual_seed(2)
+    enc = OEncoder()
+    enc.train()
+    img = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    noise = torch.rand(1, 896, 896, 1, generator=torch.Generator().manual_seed(1))
+
+    def once():
+        for p in enc.parameters():
+            p.grad = None
+        coeffs.grad = None
+        sensor, psf, loss_psf = ic.forward(img, coeffs, vol, noise, prueba="3", mask_1=m1, mask_2=m2, height_tolerance=2e-8,
+                                           sensor_distance=0.025, sample_interval=3e-6)
+        out = enc(sensor)
+        loss = 0.4 * (out * out).mean() + 6 * (1 - torch.nn.functional.mse_loss(img, sensor)) + 30 * loss_psf
+        loss.backward()
+
+    once()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[0]
+    return {"value": round(B / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"camera (896/350/256, prueba '3') + ResNet-101 fwd+bwd fp32, B={B} @256x256, best of 2 after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    rank = dist.get_rank() if world > 1 else 0
+
+    camera, encoder = build(device, global_max_sync=world > 1)
+    step, params = make_step(camera, encoder, args.batch, device, None)
+    sync = GradSync(params) if world > 1 else None
+    if sync is not None:
+        step, _ = make_step(camera, encoder, args.batch, device, sync)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None if args.no_roofline else roofline_of_dominant_kernel(step)
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        line = {
+            "metric": "images/sec fwd+bwd, Camera+ResNet-101 @256^2", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "IC OpticsZernike camera (896^2 wave grid, 350 Zernike terms, prueba '3') + ResNet-101 "
+                                   "Encoder, fwd+bwd+Adam, 256x256; camera fp32/fp64, trunk bf16 storage + fp32 accumulate; "
+                                   "caption decoder not included (next row)",
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "trunk_mfma_frac_of_peak": round(value / world * TRUNK_GFLOP_PER_IMG * 1e9 / (PEAK_BF16_DENSE_TFLOPS * 1e12), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(camera)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,11 +81,11 @@ int ppv_zernike_max_order(void);
  * NHWC bf16 implicit-GEMM convolution on MFMA; serves forward and data-gradient (see csrc/conv_gemm.hip).
  *   forward: a = stride, off = -pad, div = 1, Wt = [Cout][R][S][Cin];
  *   dgrad:   a = 1, off = -(k-1-pad), div = stride, Wt = [Cin][R][S][Cout] taps flipped.
- * stat_part [ceil(M/128)][2][N]: per-row-tile (sum, sum of squares) of the bf16-rounded outputs (train-mode BN)
- * or NULL; addend [M][N] bf16 is added before rounding (residual-gradient accumulation) or NULL. */
+ * stat_part [stat_rows][2][N]: PRE-ZEROED partial (sum, sum of squares) of the bf16-rounded outputs (train-mode BN;
+ * row tiles fold into row tile % stat_rows with f32 atomics; ppv_conv_stat_tiles(M) gives stat_rows) or NULL; addend [M][N] bf16 is added before rounding (residual-gradient accumulation) or NULL. */
 int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend,
                   const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a,
-                  int off, int div, int out_f32, ppv_stream_t stream);
+                  int off, int div, int out_f32, int stat_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, ppv_stream_t stream);
 
@@ -95,8 +95,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW, const void* zero_pag
 int ppv_wgrad_to_torch(const float* dW, float* out, int N, int C, int R, int S, ppv_stream_t stream);
 /* stem 7x7/2 conv (resnet.0), f32 NCHW sensor image in, NHWC bf16 out; data gradient via ppv_conv_gemm (N = 16) */
 int ppv_stem_weight_layout(const float* w, void* out, int mode, ppv_stream_t stream);
-int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int B, int H, int W,
-                  ppv_stream_t stream);
+int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int stat_rows, int B, int H,
+                  int W, ppv_stream_t stream);
 int ppv_stem_dgrad_scatter(const float* t, float* g, int B, int Ho, int Wo, ppv_stream_t stream);
 /* train-mode BatchNorm2d (+ residual, + ReLU), forward and backward */
 int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,

@@ -33,13 +33,13 @@ PROTOTYPES = {
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
     "ppv_zernike_max_order": (_I, []),
-    "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P]),
+    "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
     "ppv_conv_wgrad": (_I, [_P, _P, _P, _P] + [_I] * 11 + [_P]),
     "ppv_wgrad_to_torch": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ppv_stem_weight_layout": (_I, [_P, _P, _I, _P]),
-    "ppv_stem_conv": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ppv_stem_conv": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_stem_dgrad_scatter": (_I, [_P, _P, _I, _I, _I, _P]),
     "ppv_bn_finalize": (_I, [_P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

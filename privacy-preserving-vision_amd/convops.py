@@ -20,6 +20,21 @@ def L():
     return _lib.lib()
 
 
+# bench.py sets PROFILE = [] to collect (kernel, algorithmic flops, start event, end event) per conv launch
+PROFILE = None
+
+
+def _timed(kind, flops, launch):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = launch()
+    e1.record()
+    PROFILE.append((kind, flops, e0, e1))
+    return r
+
+
 # ----------------------------------------------------------------------------- convolution
 def weight_layout(w, mode):
     """w [Cout,Cin,R,S] f32 -> bf16 GEMM rows: mode 0 forward [Cout,R,S,Cin]; mode 1 dgrad [Cin,R,S,Cout] flipped."""
@@ -40,8 +55,11 @@ def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
     Cout, R, S, _ = wt.shape
     Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=F32 if out_f32 else BF16, device=x.device)
-    check(L().ppv_conv_gemm(ptr(x), ptr(wt), ptr(out), ptr(stat_part), None, ptr(zero_page(x.device)), B, H, W, Cin,
-                            Ho, Wo, Cout, R, S, stride, -pad, 1, int(out_f32), stream_ptr()), "ppv_conv_gemm")
+    kind = "conv_gemm<128>" if Cout % 128 == 0 else "conv_gemm<64>"
+    _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
+        L().ppv_conv_gemm(ptr(x), ptr(wt), ptr(out), ptr(stat_part), None, ptr(zero_page(x.device)), B, H, W, Cin,
+                          Ho, Wo, Cout, R, S, stride, -pad, 1, int(out_f32),
+                          0 if stat_part is None else stat_part.shape[0], stream_ptr()), "ppv_conv_gemm"))
     return out
 
 
@@ -51,18 +69,24 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False):
     Cin, R, S, _ = wd.shape
     H, W = in_hw
     out = torch.empty((B, H, W, Cin), dtype=F32 if out_f32 else BF16, device=g.device)
-    check(L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
-                            H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), stream_ptr()), "ppv_conv_gemm")
+    kind = "conv_gemm<128>" if Cin % 128 == 0 else "conv_gemm<64>"
+    # algorithmic flops of the data gradient = those of the forward conv it differentiates
+    _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
+        L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
+                          H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), 0, stream_ptr()), "ppv_conv_gemm"))
     return out
 
 
-def conv_wgrad(g, x, R, S, stride, pad):
-    """g [B,Ho,Wo,Cout] bf16, x [B,H,W,Cin] bf16 -> dW in torch layout [Cout,Cin,R,S] f32."""
+def conv_wgrad(g, x, R, S, stride, pad, acc=None):
+    """g [B,Ho,Wo,Cout] bf16, x [B,H,W,Cin] bf16 -> dW in torch layout [Cout,Cin,R,S] f32.
+    acc: optional PRE-ZEROED f32 scratch of Cout*R*S*Cin elements (else allocated + zeroed here)."""
     B, Ho, Wo, Cout = g.shape
     _, H, W, Cin = x.shape
-    acc = torch.zeros((Cout, R, S, Cin), dtype=F32, device=g.device)
-    check(L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(acc), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S, stride,
-                             pad, stream_ptr()), "ppv_conv_wgrad")
+    if acc is None:
+        acc = torch.zeros((Cout, R, S, Cin), dtype=F32, device=g.device)
+    _timed("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
+        L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(acc), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S, stride,
+                           pad, stream_ptr()), "ppv_conv_wgrad"))
     out = torch.empty((Cout, Cin, R, S), dtype=F32, device=g.device)
     check(L().ppv_wgrad_to_torch(ptr(acc), ptr(out), Cout, Cin, R, S, stream_ptr()), "ppv_wgrad_to_torch")
     return out
@@ -79,7 +103,8 @@ def stem_conv(img, wst, stat_part=None):
     """img [B,3,H,W] f32 NCHW -> raw [B,H/2,W/2,64] bf16."""
     B, _, H, W = img.shape
     out = torch.empty((B, H // 2, W // 2, 64), dtype=BF16, device=img.device)
-    check(L().ppv_stem_conv(ptr(img), ptr(wst), ptr(out), ptr(stat_part), B, H, W, stream_ptr()), "ppv_stem_conv")
+    check(L().ppv_stem_conv(ptr(img), ptr(wst), ptr(out), ptr(stat_part), 0 if stat_part is None else stat_part.shape[0],
+                            B, H, W, stream_ptr()), "ppv_stem_conv")
     return out
 
 
@@ -88,7 +113,7 @@ def stem_dgrad(g_raw, wsd):
     B, Ho, Wo, _ = g_raw.shape
     tmp = torch.empty((B * Ho * Wo, 16), dtype=F32, device=g_raw.device)
     check(L().ppv_conv_gemm(ptr(g_raw), ptr(wsd), ptr(tmp), None, None, ptr(zero_page(g_raw.device)), B, Ho, Wo, 64,
-                            Ho, Wo, 16, 4, 4, 1, -1, 1, 1, stream_ptr()), "ppv_conv_gemm(stem dgrad)")
+                            Ho, Wo, 16, 4, 4, 1, -1, 1, 1, 0, stream_ptr()), "ppv_conv_gemm(stem dgrad)")
     out = torch.empty((B, 3, 2 * Ho, 2 * Wo), dtype=F32, device=g_raw.device)
     check(L().ppv_stem_dgrad_scatter(ptr(tmp), ptr(out), B, Ho, Wo, stream_ptr()), "ppv_stem_dgrad_scatter")
     return out
@@ -121,8 +146,7 @@ def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True):
     gpre = torch.empty_like(x) if want_gpre else None
     dg = torch.empty(C, dtype=F32, device=dev) if want_affine else None
     db = torch.empty(C, dtype=F32, device=dev) if want_affine else None
-    nb = L().ppv_bn_bwd_blocks(rows, C)
-    part = torch.empty(nb * 2 * C, dtype=F32, device=dev)
+    part = torch.empty(64 * C, dtype=F32, device=dev)
     kc = torch.empty(3 * C, dtype=F32, device=dev)
     check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
                          ptr(kc), rows, C, int(relu), stream_ptr()), "ppv_bn_bwd")

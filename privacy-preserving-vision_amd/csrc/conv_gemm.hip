@@ -46,14 +46,15 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                  \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// stat_part: [tiles_m][2][N] f32 per-row-tile partial (sum, sum of squares) of the bf16-rounded outputs, or null.
+// stat_part: [stat_rows][2][N] f32 partial (sum, sum of squares) of the bf16-rounded outputs (pre-zeroed; row tiles
+// fold into row tile_m % stat_rows with f32 atomics), or null.
 // addend: optional bf16 [M][N] tensor added to the result before rounding (residual-gradient accumulation).
 template <int BN, int WM, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                            void* __restrict__ Out, float* __restrict__ stat_part,
                                                            const bf16_t* __restrict__ addend,
                                                            const bf16_t* __restrict__ zero_page, ConvGeom g,
-                                                           int tiles_n) {
+                                                           int tiles_n, int stat_rows) {
     constexpr int BM = 128, BK = 64, WN = 4 / WM;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16 x 16 fragments per wave
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) v += sStat[(w * 2 + which) * BN + col];
-        stat_part[((long)tile_m * 2 + which) * g.N + n0 + col] = v;
+        // rows are shared by tile_m % stat_rows: <= tiles_m / stat_rows adders per address, 256-byte runs
+        atomicAdd(&stat_part[((long)(tile_m % stat_rows) * 2 + which) * g.N + n0 + col], v);
     }
     bf16_t* out = reinterpret_cast<bf16_t*>(Out);
 #pragma unroll
@@ -261,13 +263,14 @@ extern "C" {
 
 // Generic NHWC bf16 gather-GEMM convolution (see file header).  X [B,Hs,Ws,Cs] bf16, Wt [N][R*S*Cs] bf16,
 // out [B*Ho*Wo][N] bf16 (out_f32 = 0) or f32 (out_f32 = 1: parity tests and the stem data gradient),
-// stat_part [ceil(M/128)][2][N] f32 per-row-tile BN partials (may be null), addend [M][N] bf16 (may be null),
+// stat_part [stat_rows][2][N] f32 BN partial sums, PRE-ZEROED by the caller (may be null), addend [M][N] bf16 (may be null),
 // zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
 int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* zero_page,
                   int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
-                  int out_f32, hipStream_t stream) {
+                  int out_f32, int stat_rows, hipStream_t stream) {
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
+    if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
@@ -279,8 +282,8 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     const bf16_t* z = (const bf16_t*)zero_page;
 #define PPV_LAUNCH(BN_, WM_, TN_)                                                                                       \
     do {                                                                                                                \
-        if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_); \
-        else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_);        \
+        if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows); \
+        else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows);        \
     } while (0)
     if (N == 16) PPV_LAUNCH(16, 4, 1);
     else if (N % 128 == 0) PPV_LAUNCH(128, 2, N / 128);
@@ -289,7 +292,11 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     return ppv_last_error();
 }
 
-int ppv_conv_stat_tiles(long M) { return (int)((M + 127) / 128); }
+// rows of the BN partial buffer a conv with M output pixels should use
+int ppv_conv_stat_tiles(long M) {
+    const long t = (M + 127) / 128;
+    return (int)(t < 32 ? t : 32);
+}
 
 // mode 0: [Cout][Cin][R][S] f32 -> [Cout][R][S][Cin] bf16 (forward);  mode 1: -> [Cin][R][S][Cout] bf16 flipped (dgrad)
 int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, hipStream_t stream) {

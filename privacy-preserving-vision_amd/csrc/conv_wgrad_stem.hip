@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void stem_weight_layout_kernel(const float* __
 
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wst,
                                                            bf16_t* __restrict__ out, float* __restrict__ stat_part, int B,
-                                                           int H, int W, int tiles) {
+                                                           int H, int W, int tiles, int stat_rows) {
     constexpr int LDA = 384;                                   // bytes per A / W row (192 bf16)
     __shared__ __attribute__((aligned(16))) char sA[128 * LDA];
     __shared__ __attribute__((aligned(16))) char sW[64 * LDA];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
         __syncthreads();
         if (stat_part && tid < 128) {
             const int which = tid >> 6, col = tid & 63;
-            stat_part[((long)tile * 2 + which) * 64 + col] = sStat[0][which][col] + sStat[1][which][col];
+            atomicAdd(&stat_part[((long)(tile % stat_rows) * 2 + which) * 64 + col], sStat[0][which][col] + sStat[1][which][col]);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -317,8 +317,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW, const void* zero_pag
     g.M = (long)B * Ho * Wo;
     const long stages = (g.M + 63) / 64;
     const int tiles = (N / 128) * (R * S * (Cs / 128));
-    long splits = (1536 + tiles - 1) / tiles;                  // aim at ~1.5k workgroups
-    if (splits > stages / 4) splits = stages / 4;              // keep >= 4 stages per slice
+    long splits = (512 + tiles - 1) / tiles;                   // ~2 workgroups per CU: every extra slice costs a full
+    if (splits > stages / 8) splits = stages / 8;              // tile of f32 atomics (1.3 TB/s chip-wide); >= 8 stages each
     if (splits < 1) splits = 1;
     g.stages_per_split = (int)((stages + splits - 1) / splits);
     splits = (stages + g.stages_per_split - 1) / g.stages_per_split;
@@ -342,14 +342,15 @@ int ppv_stem_weight_layout(const float* w, void* out, int mode, hipStream_t stre
     return ppv_last_error();
 }
 
-// img [B,3,H,W] f32 NCHW -> raw [B,H/2,W/2,64] bf16 (+ BN partials [tiles][2][64], tiles = ceil(B*H/2*W/2 / 128))
-int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int B, int H, int W, hipStream_t stream) {
+// img [B,3,H,W] f32 NCHW -> raw [B,H/2,W/2,64] bf16 (+ BN partial sums [stat_rows][2][64], pre-zeroed)
+int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int stat_rows, int B, int H, int W,
+                  hipStream_t stream) {
     if (!img || !wst || !out) return PPV_ERR_NULL;
     if (H % 2 || W % 2) return PPV_ERR_BAD_SIZE;
     const long M = (long)B * (H / 2) * (W / 2);
     const int tiles = (int)((M + 127) / 128);
     const int grid = tiles < 1024 ? tiles : 1024;
-    stem_conv_kernel<<<grid, 256, 0, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles);
+    stem_conv_kernel<<<grid, 256, 0, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles, stat_rows < 1 ? 1 : stat_rows);
     return ppv_last_error();
 }
 

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------- BN backward
-// pass 1: per-channel partial sums of g_pre and g_pre * x, g_pre = g_y * (y > 0) [RELU] ; part [nblk][2][C]
+// pass 1: per-channel partial sums of g_pre and g_pre * x, g_pre = g_y * (y > 0) [RELU] ; part [32][2][C] pre-zeroed,
+// block b adds into row b & 31
 template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
                                                             const bf16_t* __restrict__ x, float* __restrict__ part,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
         const int tcc = c / 8, k = c % 8;
         float v = 0.f;
         for (int rr = 0; rr < rpp; ++rr) v += s_red[rr * tpr + tcc][which * 8 + k];
-        part[((long)blockIdx.x * 2 + which) * C + c] = v;
+        atomicAdd(&part[((long)(blockIdx.x & 31) * 2 + which) * C + c], v);
     }
 }
 
@@ -356,7 +357,7 @@ int ppv_bn_bwd_blocks(long rows, int C) {
 }
 
 // Train-mode BN backward (+ ReLU mask from y when relu != 0).  Writes g_x (bf16), optionally g_pre (bf16, may be
-// null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= ppv_bn_bwd_blocks * 2 * C floats; kc: scratch 3*C.
+// null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats (zeroed here); kc: scratch 3*C.
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, hipStream_t stream) {
     if (!gy || !x || !coef || !gx || !part || !kc || (relu && !y)) return PPV_ERR_NULL;
@@ -366,9 +367,10 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
     long nb = (rows + rpb - 1) / rpb;
     while (nb > 2048) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
     const bf16_t *g = (const bf16_t*)gy, *yy = (const bf16_t*)y, *xx = (const bf16_t*)x;
+    (void)hipMemsetAsync(part, 0, sizeof(float) * 64 * C, stream);
     if (relu) bn_bwd_reduce_kernel<true><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
     else bn_bwd_reduce_kernel<false><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
-    bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, (int)nb, count, coef, kc, dgamma, dbeta, C);
+    bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, 32, count, coef, kc, dgamma, dbeta, C);
     const long n8 = rows * C / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
     bf16_t *ox = (bf16_t*)gx, *op = (bf16_t*)gpre;

@@ -67,15 +67,27 @@ class _ConvRec:
         self._ver_t = self._ver_d = -1
         self.stem = stem
 
-    def wt(self):
+    # Frozen weights are converted once; trainable ones every step (fused optimisers update ``.data`` without a
+    # reliable version bump, so the cache key is (version, step token)).
+    def wt(self, token=0):
         w = self.conv.weight
+        if w.requires_grad:
+            if self._wt is None or self._ver_t != token:
+                self._wt = co.weight_layout(w.detach(), 0)
+                self._ver_t = token
+            return self._wt
         if self._wt is None or self._ver_t != w._version or self._wt.device != w.device:
             self._wt = co.stem_weight_layout(w.detach(), 0) if self.stem else co.weight_layout(w.detach(), 0)
             self._ver_t = w._version
         return self._wt
 
-    def wd(self):
+    def wd(self, token=0):
         w = self.conv.weight
+        if w.requires_grad:
+            if self._wd is None or self._ver_d != token:
+                self._wd = co.weight_layout(w.detach(), 1)
+                self._ver_d = token
+            return self._wd
         if self._wd is None or self._ver_d != w._version or self._wd.device != w.device:
             self._wd = co.stem_weight_layout(w.detach(), 1) if self.stem else co.weight_layout(w.detach(), 1)
             self._ver_d = w._version
@@ -103,14 +115,26 @@ class _TrunkFn(torch.autograd.Function):
         train = enc.resnet[1].training
         saved = {}
 
+        enc._step_token += 1
+        tok = enc._step_token
+        # one zeroed f32 pool for every conv's BN partial sums of this step ([rows<=32][2][C] each)
+        pool = torch.zeros(enc._stat_pool_elems(B, H, W), dtype=torch.float32, device=dev) if train else None
+        pool_off = [0]
+
         def part_for(M, C):
-            return torch.empty((co.stat_tiles(M), 2, C), dtype=torch.float32, device=dev) if train else None
+            if not train:
+                return None
+            rows = co.stat_tiles(M)
+            n = rows * 2 * C
+            v = pool[pool_off[0]:pool_off[0] + n].view(rows, 2, C)
+            pool_off[0] += n
+            return v
 
         # ---- stem: conv 7x7/2 + BN + ReLU + maxpool 3x3/2  (resnet.0-3)
         st = enc._stem
         Ho, Wo = H // 2, W // 2
         p0 = part_for(B * Ho * Wo, 64)
-        raw0 = co.stem_conv(images, st.wt(), p0)
+        raw0 = co.stem_conv(images, st.wt(tok), p0)
         c0 = _bn_coef(st, p0, B * Ho * Wo)
         y0, arg0 = co.bn_relu_maxpool(raw0, c0)
         saved["stem"] = (raw0, c0, y0, arg0)
@@ -121,20 +145,20 @@ class _TrunkFn(torch.autograd.Function):
             r1, r2, r3, rd = blk
             Bn, Hin, Win, _ = xin.shape
             p = part_for(Bn * Hin * Win, r1.conv.out_channels)
-            x1 = co.conv_fwd(xin, r1.wt(), 1, 0, p)
+            x1 = co.conv_fwd(xin, r1.wt(tok), 1, 0, p)
             c1 = _bn_coef(r1, p, Bn * Hin * Win)
             y1 = co.bn_act(x1, c1)
             H2, W2 = Hin // r2.stride, Win // r2.stride
             p = part_for(Bn * H2 * W2, r2.conv.out_channels)
-            x2 = co.conv_fwd(y1, r2.wt(), r2.stride, 1, p)
+            x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
             c2 = _bn_coef(r2, p, Bn * H2 * W2)
             y2 = co.bn_act(x2, c2)
             p = part_for(Bn * H2 * W2, r3.conv.out_channels)
-            x3 = co.conv_fwd(y2, r3.wt(), 1, 0, p)
+            x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
             c3 = _bn_coef(r3, p, Bn * H2 * W2)
             if rd is not None:
                 p = part_for(Bn * H2 * W2, rd.conv.out_channels)
-                xd = co.conv_fwd(xin, rd.wt(), rd.stride, 0, p)
+                xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, p)
                 cd = _bn_coef(rd, p, Bn * H2 * W2)
                 yout = co.bn_act(x3, c3, res=xd, coef_res=cd)
             else:
@@ -145,7 +169,7 @@ class _TrunkFn(torch.autograd.Function):
         out = co.adaptive_pool_fwd(x, enc.enc_image_size)
         if train:
             torch._foreach_add_(enc._nbt, 1)
-        ctx.enc, ctx.saved, ctx.blocks, ctx.train = enc, saved, blocks, train
+        ctx.enc, ctx.saved, ctx.blocks, ctx.train, ctx.tok = enc, saved, blocks, train, tok
         ctx.img_shape, ctx.last_hw = images.shape, (x.shape[1], x.shape[2])
         return out
 
@@ -156,12 +180,19 @@ class _TrunkFn(torch.autograd.Function):
             raise NotImplementedError("backward through eval-mode BatchNorm is outside the reference's use (validate() "
                                       "runs under no_grad, train.py:355-451)")
         grads = {}
+        tok = ctx.tok
+        # one zeroed f32 scratch for every trainable conv's [N][R][S][C] atomic accumulation of this step
+        wsz = sum(r.conv.weight.numel() for blk in enc._blocks for r in blk if r is not None and r.conv.weight.requires_grad)
+        wpool = torch.zeros(wsz, dtype=torch.float32, device=g_out.device)
+        woff = [0]
 
         def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False):
             trainable = rec.conv.weight.requires_grad
             gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad)
             if trainable:
-                grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad)
+                n = rec.conv.weight.numel()
+                grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, acc=wpool[woff[0]:woff[0] + n])
+                woff[0] += n
             if rec.bn.weight.requires_grad:
                 grads[rec.bn.weight], grads[rec.bn.bias] = dg, db
             return gx, gpre
@@ -174,16 +205,16 @@ class _TrunkFn(torch.autograd.Function):
             xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout = sv
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
             gx3, gpre = conv_bn_bwd(r3, g, yout, x3, c3, y2, True, want_gpre=True)
-            gy2 = co.conv_dgrad(gx3, r3.wd(), 1, 0, hw_mid)
+            gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
             gx2, _ = conv_bn_bwd(r2, gy2, y2, x2, c2, y1, True)
-            gy1 = co.conv_dgrad(gx2, r2.wd(), r2.stride, 1, hw_in)
+            gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
             gx1, _ = conv_bn_bwd(r1, gy1, y1, x1, c1, xin, True)
             if rd is not None:
                 gxd, _ = conv_bn_bwd(rd, gpre, None, xd, cd, xin, False)
-                gin = co.conv_dgrad(gxd, rd.wd(), rd.stride, 0, hw_in)
-                g = co.conv_dgrad(gx1, r1.wd(), 1, 0, hw_in, addend=gin)
+                gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin)
             else:
-                g = co.conv_dgrad(gx1, r1.wd(), 1, 0, hw_in, addend=gpre)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gpre)
             if taps is not None:
                 taps.append((g_blk_out, g))
         g_img = None
@@ -198,7 +229,7 @@ class _TrunkFn(torch.autograd.Function):
             if st.bn.weight.requires_grad:
                 grads[st.bn.weight], grads[st.bn.bias] = dg, db
             if needs_img:
-                g_img = co.stem_dgrad(gx0, st.wd())
+                g_img = co.stem_dgrad(gx0, st.wd(tok))
         return (None, g_img) + tuple(grads.get(p) for p in enc._param_list())
 
 
@@ -212,6 +243,7 @@ class Encoder(nn.Module):
         self.resnet = _make_trunk(layers)
         self.adaptive_pool = nn.AdaptiveAvgPool2d((encoded_image_size, encoded_image_size))
         self._index()
+        self._step_token = 0
         self.fine_tune()
 
     def _index(self):
@@ -223,6 +255,18 @@ class Encoder(nn.Module):
                 rd = _ConvRec(b.downsample[0], b.downsample[1]) if b.downsample is not None else None
                 blocks.append((_ConvRec(b.conv1, b.bn1), _ConvRec(b.conv2, b.bn2), _ConvRec(b.conv3, b.bn3), rd))
         object.__setattr__(self, "_blocks", blocks)
+
+    def _stat_pool_elems(self, B, H, W):
+        """f32 elements of the per-step BN partial-sum pool for a [B,3,H,W] input."""
+        tot = co.stat_tiles(B * (H // 2) * (W // 2)) * 2 * 64
+        h, w = H // 4, W // 4
+        for r1, r2, r3, rd in self._blocks:
+            tot += co.stat_tiles(B * h * w) * 2 * r1.conv.out_channels
+            h, w = h // r2.stride, w // r2.stride
+            for r in (r2, r3, rd):
+                if r is not None:
+                    tot += co.stat_tiles(B * h * w) * 2 * r.conv.out_channels
+        return tot
 
     def _param_list(self):
         return list(self.resnet.parameters())

@@ -87,6 +87,7 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
                   const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a,
                   int off, int div, int out_f32, int stat_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
+int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
 int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, ppv_stream_t stream);
 
 /* weight gradient (layer2..4 trainable, models.py:43-54): dW [N][R][S][Cs] f32 += ...; then to torch [N][Cs][R][S] */

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
+    "ppv_conv_set_variant": (_I, [_I]),
     "ppv_conv_wgrad": (_I, [_P, _P, _P, _P] + [_I] * 11 + [_P]),
     "ppv_wgrad_to_torch": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ppv_stem_weight_layout": (_I, [_P, _P, _I, _P]),

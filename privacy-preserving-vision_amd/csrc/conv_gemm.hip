@@ -230,6 +230,224 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
     }
 }
 
+// ============================================================================= multi-stage pipeline
+// Same math as conv_gemm_kernel, restructured for latency hiding (the two-stage kernel above is latency-bound: one
+// 64-deep K-step of prefetch covers ~0.5 us of compute against >1 us of L2/HBM latency):
+//   * NSTAGE LDS stages, NSTAGE-1 K-steps of global_load_lds in flight, ONE raw s_barrier per K-step and a COUNTED
+//     s_waitcnt vmcnt(L) (L = loads per thread per stage) so younger stages stay in flight across the barrier
+//     (__syncthreads() would drain them: cdna_hip_programming.md "Pipelining across barriers");
+//   * BM = 256 variant (8 waves, 48 KB per stage) halves the W-panel re-reads and cuts L2->LDS bytes per flop by 25 %;
+//   * incremental (tap, channel) counters instead of per-stage integer divisions.
+// RAW: a stage is read one barrier after every wave's counted wait retired its own loads of that stage.
+// WAR: stage t+NSTAGE-1 overwrites the buffer last read in compute(t-1), which every wave finished before barrier t.
+template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int NSTAGE, bool OUT_F32>
+__global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+                                                                   void* __restrict__ Out, float* __restrict__ stat_part,
+                                                                   const bf16_t* __restrict__ addend,
+                                                                   const bf16_t* __restrict__ zero_page, ConvGeom g,
+                                                                   int tiles_n, int stat_rows) {
+    constexpr int BK = 64, NT = BM * 2, NWAVE = NT / 64;
+    constexpr int WN = BN / 64 > 0 ? BN / 64 : 1, WM = NWAVE / WN;        // wave grid; each wave owns 64 x (BN / WN)
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN, MI = WROWS / 16, NI = WCOLS / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int RPR = NT / 8;                                            // rows staged per round
+    constexpr int ASLOTS = BM / RPR, BSLOTS = BN / RPR, L = ASLOTS + BSLOTS;
+    static_assert(BN % RPR == 0 && WM * WN == NWAVE && MI * 16 == WROWS, "tile / wave grid mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int rl = lane >> 3, p = lane & 7, cch = p ^ rl;
+    int a_h0[ASLOTS], a_w0[ASLOTS], a_pix[ASLOTS];
+    bool a_ok[ASLOTS];
+    const long zdelta = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+    const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i) {
+        const long m = m0 + i * RPR + wave * 8 + rl;
+        a_ok[i] = m < g.M;
+        const long mm = a_ok[i] ? m : 0;
+        const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
+        const int ho = rem / g.Wo, wo = rem % g.Wo;
+        a_h0[i] = ho * g.a + g.off;
+        a_w0[i] = wo * g.a + g.off;
+        a_pix[i] = b * g.Hs * g.Ws;
+    }
+    const int ktaps = g.R * g.S, kc = g.Cs / BK, nk = ktaps * kc;
+    const long wrow = (long)ktaps * g.Cs;
+    const int dm = (1 << g.sh) - 1;
+    const bf16_t* wbase[BSLOTS];
+#pragma unroll
+    for (int i = 0; i < BSLOTS; ++i) wbase[i] = Wt + (long)(n0 + i * RPR + wave * 8 + rl) * wrow + cch * 8;
+
+    // staging cursor (advances one K-step per call): tap (sr, ss), channel offset sc0, weight offset skoff
+    int sr = 0, ss = 0, sc0 = 0;
+    long skoff = 0;
+    auto stage = [&](int buf) {
+        char* sa = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i) {
+            const int hn = a_h0[i] + sr, wn = a_w0[i] + ss;
+            const int hq = hn >> g.sh, wq = wn >> g.sh;
+            // branch-free validity (unsigned compares fold the >= 0 tests) and a 64-bit select between the gathered
+            // row and the zero page: no divergent control flow around the LDS-DMA
+            const bool ok = a_ok[i] & ((unsigned)hq < (unsigned)g.Hs) & ((unsigned)wq < (unsigned)g.Ws) & (((hn | wn) & dm) == 0);
+            const long eoff = (long)(a_pix[i] + hq * g.Ws + wq) * g.Cs + sc0;
+            const long boff = ok ? eoff * 2 : zdelta;
+            GLDS16(reinterpret_cast<const char*>(X) + boff + cch * 16, sa + (i * RPR + wave * 8) * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) GLDS16(wbase[i] + skoff, sa + A_BYTES + (i * RPR + wave * 8) * 128);
+        skoff += BK;
+        sc0 += BK;
+        if (sc0 == g.Cs) {
+            sc0 = 0;
+            if (++ss == g.S) { ss = 0; ++sr; }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+            const int chunk = ((kk * 4 + fq) ^ (fr & 7)) * 16;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sa + (wm * WROWS + mi * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (wn * WCOLS + ni * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // prologue: NSTAGE-1 stages in flight
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nk) stage(s0);
+    int rd = 0, wr = (NSTAGE - 1) % NSTAGE;
+    for (int t = 0; t < nk; ++t) {
+        // stages issued so far: min(nk, t + NSTAGE - 1); those younger than stage t may stay in flight
+        const int younger = min(nk, t + NSTAGE - 1) - (t + 1);
+        if (NSTAGE >= 3 && younger >= NSTAGE - 2) wait_vmcnt_le<(NSTAGE - 2) * L>();
+        else if (NSTAGE >= 4 && younger == NSTAGE - 3) wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
+        else wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nk) stage(wr);
+        compute(rd);
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- epilogue (as conv_gemm_kernel)
+    if (OUT_F32) {
+        float* out = reinterpret_cast<float*>(Out);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long m = m0 + wm * WROWS + mi * 16 + fq * 4 + j;
+                    const int n = n0 + wn * WCOLS + ni * 16 + fr;
+                    if (m < g.M) out[m * g.N + n] = acc[mi][ni][j];
+                }
+        return;
+    }
+    constexpr int LDO = BN * 2 + 16;
+    char* sO = smem;
+    float* sStat = reinterpret_cast<float*>(smem + BM * LDO);
+    constexpr int CPR = BN / 8;
+    if (addend) {
+        // the addend tile comes in as whole 16-byte chunks (coalesced), is parked in LDS behind the output staging
+        // area and added fragment-wise in f32: one rounding of (acc + addend), no 2-byte global gathers
+        char* sAdd = smem + BM * LDO + 2048;
+        static_assert(2 * BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "addend staging does not fit the stage ring");
+#pragma unroll
+        for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / CPR, ch = idx % CPR;
+            const long m = m0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < BM * CPR && m < g.M) v = *reinterpret_cast<const uint4*>(addend + m * g.N + n0 + ch * 8);
+            if (idx < BM * CPR) *reinterpret_cast<uint4*>(sAdd + row * LDO + ch * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * WROWS + mi * 16 + fq * 4 + j, col = wn * WCOLS + ni * 16 + fr;
+                    acc[mi][ni][j] += bf2f(*reinterpret_cast<const bf16_t*>(sAdd + row * LDO + col * 2));
+                }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        float s1 = 0.f, s2 = 0.f;
+        const int col = wn * WCOLS + ni * 16 + fr;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t h = f2bf(acc[mi][ni][j]);
+                const float v = bf2f(h);
+                s1 += v;
+                s2 += v * v;
+                *reinterpret_cast<bf16_t*>(sO + (wm * WROWS + mi * 16 + fq * 4 + j) * LDO + col * 2) = h;
+            }
+        if (stat_part) {
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (fq == 0) {
+                sStat[(wm * 2 + 0) * BN + col] = s1;
+                sStat[(wm * 2 + 1) * BN + col] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (stat_part && tid < 2 * BN) {
+        const int which = tid / BN, col = tid % BN;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += sStat[(w * 2 + which) * BN + col];
+        atomicAdd(&stat_part[((long)(tile_m % stat_rows) * 2 + which) * g.N + n0 + col], v);
+    }
+    bf16_t* out = reinterpret_cast<bf16_t*>(Out);
+#pragma unroll
+    for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
+        const int idx = it * NT + tid;
+        const int row = idx / CPR, ch = idx % CPR;
+        const long m = m0 + row;
+        if (idx < BM * CPR && m < g.M)
+            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+    }
+}
+
 // ----------------------------------------------------------------------------- weight re-layouts
 // torch [Cout][Cin][R][S] f32 -> forward GEMM rows [Cout][R][S][Cin] bf16
 __global__ __launch_bounds__(256) void weight_fwd_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ o, int Cout,
@@ -259,7 +477,12 @@ __global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const float* _
 
 using namespace ppv;
 
+static int g_conv_variant = 0;
+
 extern "C" {
+
+// tuning / A-B hook: 0 auto, 1 two-stage, 2 = 128x128x4-stage, 3 = 256x128x3-stage
+int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
 
 // Generic NHWC bf16 gather-GEMM convolution (see file header).  X [B,Hs,Ws,Cs] bf16, Wt [N][R*S*Cs] bf16,
 // out [B*Ho*Wo][N] bf16 (out_f32 = 0) or f32 (out_f32 = 1: parity tests and the stem data gradient),
@@ -285,10 +508,36 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
         if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows); \
         else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows);        \
     } while (0)
-    if (N == 16) PPV_LAUNCH(16, 4, 1);
+#define PPV_LAUNCH_PIPE(BM_, BN_, NS_)                                                                                  \
+    do {                                                                                                                \
+        constexpr int lds = NS_ * (BM_ + BN_) * 128;                                                                    \
+        const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;                                                      \
+        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, false>;                                                          \
+        auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, true>;                                                           \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
+            (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, z, g, tn, stat_rows);              \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, z, g, tn, stat_rows);                      \
+    } while (0)
+    // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages
+    const int CUS = 256;
+    int v = g_conv_variant;
+    if (N == 16 || N % 128) v = 1;
+    if (v == 0) {
+        const long t256 = ((g.M + 255) / 256) * (N / 128);
+        v = (t256 >= CUS) ? 3 : 2;              // the 256-row tile only when it still fills the chip
+    }
+    if (v == 3) PPV_LAUNCH_PIPE(256, 128, 3);
+    else if (v == 2) PPV_LAUNCH_PIPE(128, 128, 4);
+    else if (N == 16) PPV_LAUNCH(16, 4, 1);
     else if (N % 128 == 0) PPV_LAUNCH(128, 2, N / 128);
     else PPV_LAUNCH(64, 2, N / 64);
 #undef PPV_LAUNCH
+#undef PPV_LAUNCH_PIPE
     return ppv_last_error();
 }
 

@@ -1,4 +1,4 @@
-"""Micro-benchmark of the conv GEMM kernel on the ResNet-101 shapes at B images."""
+"""Micro-benchmark of the conv GEMM kernel variants on the ResNet-101 shapes at B images."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,18 +11,24 @@ SHAPES = [(64, 64, 1, 1, 64), (64, 64, 3, 1, 64), (64, 256, 1, 1, 64), (256, 64,
 for cin, cout, k, st, h in SHAPES:
     x = torch.randn(B, h, h, cin, device="cuda").bfloat16()
     w = co.weight_layout(torch.randn(cout, cin, k, k, device="cuda") * 0.05, 0)
-    ho_ = h // st; part = torch.zeros(co.stat_tiles(B * ho_ * ho_), 2, cout, device="cuda")
-    for _ in range(3):
-        y = co.conv_fwd(x, w, st, (k - 1) // 2, stat_part=part)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
-    e0.record()
-    for _ in range(n):
-        y = co.conv_fwd(x, w, st, (k - 1) // 2, stat_part=part)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
     ho = h // st
+    part = torch.zeros(co.stat_tiles(B * ho * ho), 2, cout, device="cuda")
     fl = 2.0 * B * ho * ho * cout * cin * k * k
-    byts = (x.numel() + y.numel() + w.numel()) * 2
-    print(f"cin {cin:5d} cout {cout:5d} k{k} s{st} h{h:3d}: {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TF/s  {byts/ms/1e6:8.1f} GB/s")
+    line = f"cin {cin:5d} cout {cout:5d} k{k} s{st} h{h:3d}:"
+    for variant in (1, 2, 3):
+        if cout % 128 and variant > 1:
+            continue
+        co.L().ppv_conv_set_variant(variant)
+        for _ in range(3):
+            y = co.conv_fwd(x, w, st, (k - 1) // 2, stat_part=part)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            y = co.conv_fwd(x, w, st, (k - 1) // 2, stat_part=part)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        line += f"  v{variant} {ms*1e3:7.1f} us {fl/ms/1e9:6.0f} TF"
+    print(line)
+co.L().ppv_conv_set_variant(0)

@@ -115,6 +115,15 @@ int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* g
 int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, ppv_stream_t stream);
 int ppv_adaptive_pool_bwd(const void* gy, void* gx, int B, int H, int W, int C, int E, int g_f32, ppv_stream_t stream);
 
+/* ---- FD camera PSF: Face-DeId/Camera/Optics.py:92-120 (+ losses :113,:124-125), complex64, N in {256, 512} ------
+ * base = rad*(t*focus), chirp1, chirp3 [3][N][N] c64 and chirp2T [3][kx][ky] c64 are cached constants (Optics.py:94-107);
+ * kf[3] HOST floats k*flmb (Optics.py:89-90).  acc[4] f64 = {sum (rho psf)^2, centering rows, centering cols, total}. */
+int ppv_zernike_contract(const float* Z, const float* coeffs, float* h, int K, long npx, ppv_stream_t stream);
+size_t ppv_fd_psf_workspace_bytes(int N);
+int ppv_fd_psf_fwd(const float* h, const void* base, const void* chirp1, const void* chirp2T, const void* chirp3,
+                   const float* rho, const float* kf, float lratio, float amp, float* psf, double* acc,
+                   void* workspace, int N, ppv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

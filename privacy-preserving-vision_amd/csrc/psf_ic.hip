@@ -553,6 +553,15 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
     return ppv_last_error();
 }
 
+// h[px] = sum_k c[k] Z[k][px]  (IC Lens.py:176 / FD Optics.py:79-83); npx % 4 == 0
+int ppv_zernike_contract(const float* Z, const float* coeffs, float* h, int K, long npx, hipStream_t stream) {
+    if (!Z || !coeffs || !h) return PPV_ERR_NULL;
+    if (npx % 4) return PPV_ERR_BAD_SIZE;
+    const long npx4 = npx / 4;
+    zernike_contract_kernel<<<(unsigned)((npx4 + 255) / 256), 256, K * sizeof(float), stream>>>(Z, coeffs, h, K, npx4);
+    return ppv_last_error();
+}
+
 // debug / parity taps into the saved state
 int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0, size_t* off_U, size_t* off_I32,
                              size_t* off_raw) {

@@ -1,0 +1,31 @@
+"""GPU parity of the Face-DeId Camera drop-in (forward) against the goldens captured from the reference and the
+CPU oracle on the same parameters."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_fd_camera_forward_against_reference_golden(n):
+    from ppv_amd.camera_optics import Camera
+    g = load_golden("fd.npz")
+    t = f"n{n}"
+    cam = Camera(device="cuda", N=n, zernike_terms=300)
+    with torch.no_grad():
+        cam.Zer_train.copy_(torch.tensor(g[f"{t}_zer_train"]))
+    assert sorted(cam.state_dict()) == ["Zer_no_train", "Zer_train", "ca"]
+    img = torch.rand(2, 3, n, n, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    sensor = cam(img.cuda())
+    assert sensor.shape == (2, 3, n, n) and cam.psfs.shape == (1, 3, n, n)
+    assert rel_err(cam.psfs, g[f"{t}_psfs"]) < TOL
+    assert abs(cam.loss_rad.item() - float(g[f"{t}_loss_rad"])) < TOL * float(g[f"{t}_loss_rad"])
+    assert abs(cam.centering_loss.item() - float(g[f"{t}_centering_loss"])) < 5 * TOL * float(g[f"{t}_centering_loss"])
+    s = n // 32
+    assert rel_err(sensor[:, :, ::s, ::s], g[f"{t}_sensor_sub"]) < TOL
+    st = g[f"{t}_sensor_stats"]
+    assert abs(sensor.double().sum().item() - st[0]) < 2e-3 * abs(st[1]) ** 0.5 * 10
+    assert sensor.amax((1, 2, 3)).cpu().tolist() == [1.0, 1.0]

@@ -47,42 +47,6 @@ def build(device, global_max_sync):
     return camera, encoder
 
 
-class GradSync:
-    """Data-parallel gradient averaging over RCCL (torch.distributed 'nccl'), bucketed, on a side HIP stream."""
-
-    def __init__(self, params, bucket_mb=64):
-        self.params = params
-        self.world = dist.get_world_size()
-        self.stream = torch.cuda.Stream()
-        self.bucket_bytes = bucket_mb << 20
-
-    def run(self):
-        ev = torch.cuda.Event()
-        ev.record()
-        self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            bucket, size = [], 0
-            for p in reversed(self.params):                    # reverse layer order: the order backward produced them
-                if p.grad is None:
-                    continue
-                bucket.append(p.grad)
-                size += p.grad.numel() * 4
-                if size >= self.bucket_bytes:
-                    self._reduce(bucket)
-                    bucket, size = [], 0
-            if bucket:
-                self._reduce(bucket)
-        torch.cuda.current_stream().wait_stream(self.stream)
-
-    def _reduce(self, grads):
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-
-
 def make_step(camera, encoder, batch, device, sync):
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
@@ -100,9 +64,9 @@ def make_step(camera, encoder, batch, device, sync):
         loss = 0.4 * loss_head + 6 * loss_cam + 30 * loss_psf
         opt_enc.zero_grad(set_to_none=True)
         opt_cam.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward()                        # encoder gradients are all-reduced inside backward (side stream)
         if sync is not None:
-            sync.run()
+            sync.reduce_now([p.grad for p in cam_params])
         opt_cam.step()
         grads = [p.grad for p in enc_params]                                      # clip_gradient, train.py:311-316
         torch._foreach_clamp_min_(grads, -5.0)
@@ -186,18 +150,26 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PPV_FORCE_DEVICE0"):                          # rehearsal: several ranks on one GPU
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("PPV_DIST_BACKEND", "nccl")        # "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     rank = dist.get_rank() if world > 1 else 0
 
     camera, encoder = build(device, global_max_sync=world > 1)
-    step, params = make_step(camera, encoder, args.batch, device, None)
-    sync = GradSync(params) if world > 1 else None
-    if sync is not None:
-        step, _ = make_step(camera, encoder, args.batch, device, sync)
+    sync = None
+    if world > 1:
+        from ppv_amd.dist_sync import GradSync
+        sync = GradSync(bucket_mb=32)
+        encoder.grad_sync = sync
+    step, params = make_step(camera, encoder, args.batch, device, sync)
 
     for _ in range(args.warmup):
         step()

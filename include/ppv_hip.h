@@ -90,10 +90,11 @@ int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
 int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, ppv_stream_t stream);
 
-/* weight gradient (layer2..4 trainable, models.py:43-54): dW [N][R][S][Cs] f32 += ...; then to torch [N][Cs][R][S] */
-int ppv_conv_wgrad(const void* G, const void* X, float* dW, const void* zero_page, int B, int Hs, int Ws, int Cs,
-                   int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream);
-int ppv_wgrad_to_torch(const float* dW, float* out, int N, int C, int R, int S, ppv_stream_t stream);
+/* weight gradient (layer2..4 trainable, models.py:43-54): torch layout [N][Cs][R][S] f32 out; per-slice slabs in scratch */
+size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs);
+int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs,
+                   int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream);
+int ppv_wgrad_set_variant(int v);  /* tuning hook, see csrc/conv_wgrad_stem.hip */
 /* stem 7x7/2 conv (resnet.0), f32 NCHW sensor image in, NHWC bf16 out; data gradient via ppv_conv_gemm (N = 16) */
 int ppv_stem_weight_layout(const float* w, void* out, int mode, ppv_stream_t stream);
 int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int stat_rows, int B, int H,

@@ -40,8 +40,9 @@ PROTOTYPES = {
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
     "ppv_conv_set_variant": (_I, [_I]),
-    "ppv_conv_wgrad": (_I, [_P, _P, _P, _P] + [_I] * 11 + [_P]),
-    "ppv_wgrad_to_torch": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ppv_conv_wgrad_scratch_bytes": (_Z, [_L, _I, _I, _I, _I]),
+    "ppv_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "ppv_wgrad_set_variant": (_I, [_I]),
     "ppv_stem_weight_layout": (_I, [_P, _P, _I, _P]),
     "ppv_stem_conv": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_stem_dgrad_scatter": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -77,18 +77,22 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False):
     return out
 
 
-def conv_wgrad(g, x, R, S, stride, pad, acc=None):
+def wgrad_scratch_bytes(M, N, R, S, Cs):
+    return L().ppv_conv_wgrad_scratch_bytes(M, N, R, S, Cs)
+
+
+def conv_wgrad(g, x, R, S, stride, pad, scratch=None):
     """g [B,Ho,Wo,Cout] bf16, x [B,H,W,Cin] bf16 -> dW in torch layout [Cout,Cin,R,S] f32.
-    acc: optional PRE-ZEROED f32 scratch of Cout*R*S*Cin elements (else allocated + zeroed here)."""
+    scratch: optional uint8 buffer of >= wgrad_scratch_bytes(...) (reused across convs; no zeroing needed)."""
     B, Ho, Wo, Cout = g.shape
     _, H, W, Cin = x.shape
-    if acc is None:
-        acc = torch.zeros((Cout, R, S, Cin), dtype=F32, device=g.device)
-    _timed("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
-        L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(acc), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S, stride,
-                           pad, stream_ptr()), "ppv_conv_wgrad"))
+    need = wgrad_scratch_bytes(B * Ho * Wo, Cout, R, S, Cin)
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
     out = torch.empty((Cout, Cin, R, S), dtype=F32, device=g.device)
-    check(L().ppv_wgrad_to_torch(ptr(acc), ptr(out), Cout, Cin, R, S, stream_ptr()), "ppv_wgrad_to_torch")
+    _timed("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
+        L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(out), ptr(scratch), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S,
+                           stride, pad, stream_ptr()), "ppv_conv_wgrad"))
     return out
 
 

@@ -36,6 +36,9 @@ struct WgradGeom {
     int R, S, st, pad;
     long M;              // B*Ho*Wo
     int stages_per_split;  // 64-row stages each m-slice walks
+    int splits;            // number of m-slices
+    int xcd_group;         // 1: tiles of one m-slice share an XCD (1-D grid decode)
+    long slab_elems;       // > 0: slice z stores its tile plainly into dW + z * slab_elems (no atomics)
 };
 
 // 32-byte block swizzle key of a staged row (conflict-free ds_read_b64_tr_b16: see file header)
@@ -148,14 +151,192 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t* __rest
             }
 }
 
-// [N][R][S][C] f32 -> torch [N][C][R][S] f32
+
+// ---- inline-asm transposed reads for the pipelined kernel.  hipcc (ROCm 7.2) places s_waitcnt vmcnt(0) in front of
+// every __builtin_amdgcn_ds_read_tr16_b64 while a global_load_lds is in flight (it cannot prove the LDS-DMA does not
+// alias the read), which drains the prefetch ring every stage.  The asm form is invisible to that pass; completion is
+// tracked by hand: tr_wait_all() = s_waitcnt lgkmcnt(0) + sched_barrier (cdna_hip_programming.md 5.7 item 1 (iii), rule 18).
+__device__ __forceinline__ void tr_issue(s16x4& lo, s16x4& hi, const char* tile, int k0, int colblock, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r0 = k0 + 8 * g + q, r1 = r0 + 4;
+    const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(tile + r0 * 256 + (colblock ^ trkey(r0)) * 32 + p * 8);
+    const unsigned a1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(tile + r1 * 256 + (colblock ^ trkey(r1)) * 32 + p * 8);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+}
+__device__ __forceinline__ void tr_wait_all() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 tr_pack(const s16x4& lo, const s16x4& hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// exact floor(n / d), n - q*d for 0 <= n < 2^24 via a float reciprocal and one correction step
+__device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int& r) {
+    q = (int)((float)n * rcp);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
+// ----------------------------------------------------------------------------- multi-stage wgrad
+// Same tile maths as conv_wgrad_kernel with the latency-hiding structure of conv_gemm_pipe_kernel: NSTAGE LDS stages,
+// NSTAGE-1 stages of global_load_lds in flight, one raw s_barrier + one counted s_waitcnt vmcnt per 64-row stage,
+// one workgroup per CU (TN = 256: 8 waves, 48 KB stages x 3; TN = 128: 4 waves, 32 KB stages x 4).  Halving the
+// workgroup count against the two-stage kernel also halves the f32-atomic bytes (the other bound of this kernel).
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TN, int NSTAGE>
+__global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                                    float* __restrict__ dW,
+                                                                    const bf16_t* __restrict__ zero_page, WgradGeom g) {
+    constexpr int NT = TN * 2, NW = NT / 64, NH = TN / 128;               // threads, waves, 128-column halves of G
+    constexpr int HALF = 64 * 256;                                        // one [64][128] bf16 tile
+    constexpr int STAGE_BYTES = (NH + 1) * HALF;
+    constexpr int GI = (NH * 16) / NW, XI = 16 / NW, L = GI + XI;         // wave-instructions per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // XCD-aware decode of a 1-D grid: every tile of one m-slice runs on the SAME XCD at the same time, so the G rows
+    // (shared by the c-tiles / taps) and the X rows (shared by the n-tiles) are fetched from HBM once and re-read from
+    // that XCD's L2 (measured before: L2 hit rate 1 %, 2.3x over-fetch).  blocks b and b+8 share an XCD (speed only).
+    const int ctiles = g.Cs / 128;
+    const int tiles_y = g.R * g.S * ctiles, tiles = (g.N / TN) * tiles_y;
+    int zslice, tl;
+    if (g.xcd_group) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        zslice = (idx / tiles) * 8 + xcd;
+        tl = idx % tiles;
+    } else {
+        zslice = blockIdx.x / tiles;
+        tl = blockIdx.x % tiles;
+    }
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % (g.N / TN)) * TN, by = tl / (g.N / TN);
+    const int tap = by / ctiles, c0 = (by % ctiles) * 128;
+    const int r = tap / g.S, s = tap % g.S;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    const int nst = (int)((m_end - m_begin + 63) / 64);
+    if (nst <= 0) return;
+    const int HoWo = g.Ho * g.Wo;
+    const int rli = lane >> 4, lch = lane & 15;
+    const long zdG = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(G);
+    const long zdX = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+    const float rcp_howo = 1.0f / (float)HoWo, rcp_wo = 1.0f / (float)g.Wo;
+
+    int st_next = 0;
+    auto stage = [&](int buf) {
+        char* sb = smem + buf * STAGE_BYTES;
+        const long mb = m_begin + (long)st_next * 64;
+        ++st_next;
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int q = i * NW + wave, half = q >> 4, row = (q & 15) * 4 + rli;
+            const long m = mb + row;
+            const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+            const long off = (m < m_end) ? (m * g.N + n0 + half * 128 + gch * 8) * 2 : zdG;
+            GLDS16W(reinterpret_cast<const char*>(G) + off, sb + half * HALF + (q & 15) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int q = i * NW + wave, row = q * 4 + rli;
+            const long m = mb + row;
+            const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+            const int mm = (int)((m < m_end) ? m : m_begin);
+            int b, rem, ho, wo;
+            fast_divmod(mm, HoWo, rcp_howo, b, rem);
+            fast_divmod(rem, g.Wo, rcp_wo, ho, wo);
+            const int hs = ho * g.st + r - g.pad, ws = wo * g.st + s - g.pad;
+            const bool ok = (m < m_end) & ((unsigned)hs < (unsigned)g.Hs) & ((unsigned)ws < (unsigned)g.Ws);
+            const long off = ok ? ((((long)b * g.Hs + hs) * g.Ws + ws) * g.Cs + c0 + gch * 8) * 2 : zdX;
+            GLDS16W(reinterpret_cast<const char*>(X) + off, sb + NH * HALF + q * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave >> 1, wn = wave & 1;                              // wm: 64-column group of n, wn: of c
+
+    auto compute = [&](int buf) {
+        const char* tg = smem + buf * STAGE_BYTES + (wm >> 1) * HALF;
+        const char* tx = smem + buf * STAGE_BYTES + NH * HALF;
+        s16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tr_issue(alo[0][mi], ahi[0][mi], tg, 0, (wm & 1) * 4 + mi, lane);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) tr_issue(blo[0][ni], bhi[0][ni], tx, 0, wn * 4 + ni, lane);
+        tr_wait_all();
+        // second half's reads fly under the first half's MFMAs
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tr_issue(alo[1][mi], ahi[1][mi], tg, 32, (wm & 1) * 4 + mi, lane);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) tr_issue(blo[1][ni], bhi[1][ni], tx, 32, wn * 4 + ni, lane);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1) tr_wait_all();
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[kk][mi], ahi[kk][mi]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bfr[ni] = tr_pack(blo[kk][ni], bhi[kk][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+        // the ring slot is re-filled after the next barrier: every read of it has retired (lgkmcnt(0) above)
+    };
+
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nst) stage(s0);
+    int rd = 0, wr = (NSTAGE - 1) % NSTAGE;
+    for (int t = 0; t < nst; ++t) {
+        const int younger = min(nst, t + NSTAGE - 1) - (t + 1);
+        if (NSTAGE >= 3 && younger >= NSTAGE - 2) wg_wait_vmcnt_le<(NSTAGE - 2) * L>();
+        else if (NSTAGE >= 4 && younger == NSTAGE - 3) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
+        else wg_wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nst) stage(wr);
+        compute(rd);
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const long wrow = (long)g.R * g.S * g.Cs;
+    float* dst = dW + (long)zslice * g.slab_elems;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wm * 64 + mi * 16 + fq * 4 + j;
+                const int c = c0 + wn * 64 + ni * 16 + fr;
+                float* q = &dst[(long)n * wrow + (long)tap * g.Cs + c];
+                if (g.slab_elems) *q = acc[mi][ni][j];        // per-slice slab: plain stores (4-5x the f32-atomic rate)
+                else atomicAdd(q, acc[mi][ni][j]);
+            }
+}
+
+// sum of nslab slabs [N][R][S][C] f32 -> torch [N][C][R][S] f32
 __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __restrict__ dW, float* __restrict__ out, int N, int C,
-                                                             int R, int S) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+                                                             int R, int S, int nslab) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;         // index in the [N][R][S][C] (source) order: coalesced reads
     const long tot = (long)N * C * R * S;
     if (i >= tot) return;
-    const int s = (int)(i % S), r = (int)((i / S) % R), c = (int)((i / ((long)S * R)) % C), n = (int)(i / ((long)S * R * C));
-    out[i] = dW[(((long)n * R + r) * S + s) * C + c];
+    const int c = (int)(i % C), s = (int)((i / C) % S), r = (int)((i / ((long)C * S)) % R), n = (int)(i / ((long)C * S * R));
+    float a = 0.f;
+    for (int k = 0; k < nslab; ++k) a += dW[(long)k * tot + i];
+    out[(((long)n * C + c) * R + r) * S + s] = a;
 }
 
 // ============================================================================= stem forward
@@ -305,34 +486,85 @@ __global__ __launch_bounds__(256) void stem_dgrad_scatter_kernel(const float* __
 
 using namespace ppv;
 
+static int g_wgrad_variant = 0;
+
 extern "C" {
 
-// dW [N][R][S][Cs] f32 += wgrad (caller zeroes dW).  G [B,Ho,Wo,N] bf16, X [B,Hs,Ws,Cs] bf16; N % 128 == 0, Cs % 128 == 0.
-int ppv_conv_wgrad(const void* G, const void* X, float* dW, const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho,
-                   int Wo, int N, int R, int S, int stride, int pad, hipStream_t stream) {
-    if (!G || !X || !dW || !zero_page) return PPV_ERR_NULL;
+static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN, long* splits, int* sps) {
+    const long stages = (M + 63) / 64;
+    int tn = (N % 256 == 0 && variant != 2) ? 256 : 128;
+    if (variant == 1) tn = 128;
+    const int tiles = (N / tn) * (R * S * (Cs / 128));
+    long sp = ((variant == 1 ? 512 : 256) + tiles - 1) / tiles;
+    if (sp > stages / 8) sp = stages / 8;
+    if (sp < 1) sp = 1;
+    *sps = (int)((stages + sp - 1) / sp);
+    *splits = (stages + *sps - 1) / *sps;
+    *TN = tn;
+}
+
+// bytes of f32 scratch ppv_conv_wgrad needs (per-slice slabs of the [N][R][S][Cs] gradient)
+size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
+    int TN, sps;
+    long splits;
+    int variant = g_wgrad_variant & 0xff;
+    if (variant == 0) variant = (N % 256 == 0) ? 3 : 1;
+    wgrad_plan(M, N, R, S, Cs, variant, &TN, &splits, &sps);
+    return (size_t)splits * N * R * S * Cs * sizeof(float);
+}
+
+// Weight gradient of a conv: G [B,Ho,Wo,N] bf16 (gradient of the conv output), X [B,Hs,Ws,Cs] bf16 (conv input) ->
+// dW_out in torch layout [N][Cs][R][S] f32.  scratch: ppv_conv_wgrad_scratch_bytes (no zeroing needed).
+// N % 128 == 0, Cs % 128 == 0.
+int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs, int Ws,
+                   int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, hipStream_t stream) {
+    if (!G || !X || !dW_out || !scratch || !zero_page) return PPV_ERR_NULL;
     if (N % 128 || Cs % 128) return PPV_ERR_BAD_SIZE;
     WgradGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S; g.st = stride; g.pad = pad;
     g.M = (long)B * Ho * Wo;
-    const long stages = (g.M + 63) / 64;
-    const int tiles = (N / 128) * (R * S * (Cs / 128));
-    long splits = (512 + tiles - 1) / tiles;                   // ~2 workgroups per CU: every extra slice costs a full
-    if (splits > stages / 8) splits = stages / 8;              // tile of f32 atomics (1.3 TB/s chip-wide); >= 8 stages each
-    if (splits < 1) splits = 1;
-    g.stages_per_split = (int)((stages + splits - 1) / splits);
-    splits = (stages + g.stages_per_split - 1) / g.stages_per_split;
-    conv_wgrad_kernel<<<dim3(N / 128, R * S * (Cs / 128), (unsigned)splits), 256, 0, stream>>>(
-        (const bf16_t*)G, (const bf16_t*)X, dW, (const bf16_t*)zero_page, g);
+    if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;            // fast_divmod range
+    int variant = g_wgrad_variant & 0xff;
+    g.xcd_group = (g_wgrad_variant & 0x100) ? 0 : 1;
+    if (variant == 0) {                                        // measured (tools/bench_wgrad.py, cold operands, B = 128):
+        variant = (N % 256 == 0) ? 3 : 1;                      //   256-wide pipelined tiles win where they exist,
+        g.xcd_group = (R * S == 1) ? 1 : 0;                    //   XCD grouping pays for 1x1 only
+    }
+    int TN, sps;
+    long splits;
+    wgrad_plan(g.M, N, R, S, Cs, variant, &TN, &splits, &sps);
+    g.stages_per_split = sps;
+    g.splits = (int)splits;
+    const long elems = (long)N * R * S * Cs;
+    float* slabs = (float*)scratch;
+    const int tiles = (N / TN) * (R * S * (Cs / 128));
+    if (variant == 1) {                                        // two-stage kernel, atomics into one zeroed accumulator
+        g.slab_elems = 0;
+        (void)hipMemsetAsync(slabs, 0, elems * sizeof(float), stream);
+        conv_wgrad_kernel<<<dim3(N / 128, R * S * (Cs / 128), (unsigned)splits), 256, 0, stream>>>(
+            (const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, 1);
+        return ppv_last_error();
+    }
+    g.slab_elems = elems;
+    const unsigned grid = g.xcd_group ? (unsigned)(8 * ((splits + 7) / 8) * tiles) : (unsigned)(splits * tiles);
+    if (TN == 256) {
+        constexpr int lds = 3 * 3 * 64 * 256;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        conv_wgrad_pipe_kernel<256, 3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+    } else {
+        constexpr int lds = 4 * 2 * 64 * 256;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        conv_wgrad_pipe_kernel<128, 4><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+    }
+    wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)splits);
     return ppv_last_error();
 }
 
-int ppv_wgrad_to_torch(const float* dW, float* out, int N, int C, int R, int S, hipStream_t stream) {
-    if (!dW || !out) return PPV_ERR_NULL;
-    const long tot = (long)N * C * R * S;
-    wgrad_to_torch_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(dW, out, N, C, R, S);
-    return ppv_last_error();
-}
+// tuning / A-B hook: low byte 0 auto, 1 two-stage, 2 pipe TN=128, 3 pipe TN=256; 0x100 disables XCD grouping
+int ppv_wgrad_set_variant(int v) { g_wgrad_variant = v; return PPV_OK; }
 
 // mode 0: forward layout [64][24][8] bf16; mode 1: data-gradient layout [16][4][4][64] bf16
 int ppv_stem_weight_layout(const float* w, void* out, int mode, hipStream_t stream) {

@@ -181,19 +181,21 @@ class _TrunkFn(torch.autograd.Function):
                                       "runs under no_grad, train.py:355-451)")
         grads = {}
         tok = ctx.tok
-        # one zeroed f32 scratch for every trainable conv's [N][R][S][C] atomic accumulation of this step
-        wsz = sum(r.conv.weight.numel() for blk in enc._blocks for r in blk if r is not None and r.conv.weight.requires_grad)
-        wpool = torch.zeros(wsz, dtype=torch.float32, device=g_out.device)
-        woff = [0]
+        # one scratch for the per-slice wgrad slabs, sized for the largest conv of this step and reused (stream order)
+        need = 0
+        for blk_, sv_ in zip(enc._blocks, ctx.blocks):
+            for rec_, gy_ in zip(blk_, (sv_[1], sv_[4], sv_[7], sv_[9])):
+                if rec_ is not None and rec_.conv.weight.requires_grad:
+                    w_ = rec_.conv.weight
+                    need = max(need, co.wgrad_scratch_bytes(gy_.numel() // gy_.shape[-1], w_.shape[0], rec_.k, rec_.k, w_.shape[1]))
+        wscratch = torch.empty(max(need, 16), dtype=torch.uint8, device=g_out.device)
 
         def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False):
             trainable = rec.conv.weight.requires_grad
             gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad)
             sync = enc.grad_sync
             if trainable:
-                n = rec.conv.weight.numel()
-                grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, acc=wpool[woff[0]:woff[0] + n])
-                woff[0] += n
+                grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch)
                 if sync is not None:
                     sync.push(grads[rec.conv.weight])
             if rec.bn.weight.requires_grad:

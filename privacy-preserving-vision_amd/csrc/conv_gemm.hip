@@ -291,21 +291,31 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) wbase[i] = Wt + (long)(n0 + i * RPR + wave * 8 + rl) * wrow + cch * 8;
 
-    // staging cursor (advances one K-step per call): tap (sr, ss), channel offset sc0, weight offset skoff
+    // staging cursor (advances one K-step per call).  The gather addresses are rebuilt only when the tap changes
+    // (once per Cs/64 K-steps); inside a tap every valid row just walks 128 bytes along its channel run, so the
+    // steady-state cost per K-step is one 64-bit add per slot instead of ~25 VALU instructions.
     int sr = 0, ss = 0, sc0 = 0;
     long skoff = 0;
-    auto stage = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES;
+    long a_off[ASLOTS];
+    int a_inc[ASLOTS];
+    auto retap = [&]() {
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
             const int hn = a_h0[i] + sr, wn = a_w0[i] + ss;
             const int hq = hn >> g.sh, wq = wn >> g.sh;
-            // branch-free validity (unsigned compares fold the >= 0 tests) and a 64-bit select between the gathered
-            // row and the zero page: no divergent control flow around the LDS-DMA
             const bool ok = a_ok[i] & ((unsigned)hq < (unsigned)g.Hs) & ((unsigned)wq < (unsigned)g.Ws) & (((hn | wn) & dm) == 0);
-            const long eoff = (long)(a_pix[i] + hq * g.Ws + wq) * g.Cs + sc0;
-            const long boff = ok ? eoff * 2 : zdelta;
-            GLDS16(reinterpret_cast<const char*>(X) + boff + cch * 16, sa + (i * RPR + wave * 8) * 128);
+            const long eoff = (long)(a_pix[i] + hq * g.Ws + wq) * g.Cs;
+            a_off[i] = (ok ? eoff * 2 : zdelta) + cch * 16;
+            a_inc[i] = ok ? BK * 2 : 0;
+        }
+    };
+    retap();
+    auto stage = [&](int buf) {
+        char* sa = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i) {
+            GLDS16(reinterpret_cast<const char*>(X) + a_off[i], sa + (i * RPR + wave * 8) * 128);
+            a_off[i] += a_inc[i];
         }
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i) GLDS16(wbase[i] + skoff, sa + A_BYTES + (i * RPR + wave * 8) * 128);
@@ -314,6 +324,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
         if (sc0 == g.Cs) {
             sc0 = 0;
             if (++ss == g.S) { ss = 0; ++sr; }
+            retap();
         }
     };
 

@@ -37,7 +37,7 @@ def fftconv_fwd(img, otf, mode, conj_otf=False, workspace=None):
     out = torch.empty_like(img)
     ppi = _lib.lib().ppv_fftconv_partials_per_image(C, N, mode)
     partial = torch.empty(B * ppi, dtype=torch.float32, device=dev)
-    signs = torch.empty(B * C * H * (N // 128), dtype=torch.int64, device=dev) if mode == 0 else None
+    signs = torch.zeros(B * C * H * (N // 128), dtype=torch.int64, device=dev) if mode == 0 else None   # row P-1 is never written
     check(_lib.lib().ppv_fftconv_fwd(ptr(img), ptr(otf), ptr(out), ptr(signs), ptr(partial), ptr(ws), B, C, N, mode,
                                      int(conj_otf), stream_ptr()), "ppv_fftconv_fwd")
     return out, signs, partial

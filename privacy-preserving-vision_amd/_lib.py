@@ -33,6 +33,9 @@ PROTOTYPES = {
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
     "ppv_zernike_max_order": (_I, []),
+    "ppv_corr_volume": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ppv_avgpool2": (_I, [_P, _P, _L, _I, _I, _P]),
+    "ppv_corr_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_zernike_contract": (_I, [_P, _P, _P, _I, _L, _P]),
     "ppv_fd_psf_workspace_bytes": (_Z, [_I]),
     "ppv_fd_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),

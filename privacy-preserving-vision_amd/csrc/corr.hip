@@ -1,0 +1,139 @@
+// RAFT all-pairs correlation volume, pyramid and windowed bilinear lookup (fp32), gfx950.
+//
+// Replaces reference Face-DeId/RAFT/core/corr.py:12-60 (CorrBlock.__init__/__call__/corr) and the
+// bilinear_sampler of RAFT/core/utils/utils.py:57-71 (grid_sample, align_corners=True, zeros padding):
+//   corr_volume   corr[b][i][j] = (1/sqrt(C)) sum_c f1[b][c][i] f2[b][c][j]      (corr.py:53-60)   fp32 MFMA 16x16x4
+//   avgpool2      3 pyramid levels                                               (corr.py:25-27)
+//   corr_lookup   out[b][l*81 + a*9 + d][h1][w1] = bilinear(corr_l[b,h1,w1], x/2^l + dy[a], y/2^l + dx[d])
+//                 -- the reference adds meshgrid(dy,dx) stacked as (...,2) to (x,y): x gets dy, y gets dx
+//                 (corr.py:37-43); reproduced literally.
+// The alt_cuda_corr CUDA extension vendored by the reference (never called there) is NOT translated.
+#include <hip/hip_runtime.h>
+#include "ppv_common.h"
+
+namespace ppv {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4c;
+
+// D[i][j] = scale * sum_k A[k][i] * B[k][j];  A = f1[b] as [C][HW], B = f2[b] as [C][HW]; 128 x 128 tile, 4 waves (2 x 2),
+// K chunk 16 through LDS.  HW % 128 == 0, C % 16 == 0.
+__global__ __launch_bounds__(256) void corr_volume_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          float* __restrict__ out, int C, int HW, float scale) {
+    __shared__ float sA[16][128 + 4], sB[16][128 + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const float* A = f1 + (long)b * C * HW;
+    const float* Bm = f2 + (long)b * C * HW;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fk = lane >> 4;
+    f32x4c acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < C; k0 += 16) {
+        __syncthreads();
+        for (int idx = tid; idx < 16 * 32; idx += 256) {
+            const int k = idx >> 5, c4 = idx & 31;
+            const float4 va = *reinterpret_cast<const float4*>(A + (long)(k0 + k) * HW + i0 + c4 * 4);
+            const float4 vb = *reinterpret_cast<const float4*>(Bm + (long)(k0 + k) * HW + j0 + c4 * 4);
+            *reinterpret_cast<float4*>(&sA[k][c4 * 4]) = va;
+            *reinterpret_cast<float4*>(&sB[k][c4 * 4]) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            float af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = sA[kk + fk][wm * 64 + a * 16 + fr];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bf[c] = sB[kk + fk][wn * 64 + c * 16 + fr];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[c], acc[a][c], 0, 0, 0);
+        }
+    }
+    float* o = out + (long)b * HW * HW;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + wm * 64 + a * 16 + fk * 4 + j, jj = j0 + wn * 64 + c * 16 + fr;
+                o[(long)i * HW + jj] = acc[a][c][j] * scale;
+            }
+}
+
+// [n][H][W] -> [n][H/2][W/2]
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * Ho * Wo) return;
+    const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+    const long m = i / ((long)Wo * Ho);
+    const float* p = in + (m * H + 2 * y) * W + 2 * x;
+    out[i] = (p[0] + p[1] + p[W] + p[W + 1]) * 0.25f;
+}
+
+// one thread per (pixel n = b*H1*W1 + h1*W1 + w1, window entry e = a*win + d) of one level
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ corr, const float* __restrict__ coords,
+                                                          float* __restrict__ out, int B, int H1, int W1, int Hl, int Wl,
+                                                          int r, int level, int nlevels) {
+    const int win = 2 * r + 1, ne = win * win;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long npix = (long)B * H1 * W1;
+    if (i >= npix * ne) return;
+    const long n = i % npix;                       // pixel fastest: coalesced output along w1
+    const int e = (int)(i / npix);
+    const int a = e / win, d = e % win;
+    const int w1 = (int)(n % W1), h1 = (int)((n / W1) % H1), b = (int)(n / ((long)W1 * H1));
+    const float inv = 1.0f / (float)(1 << level);
+    const float cx = coords[(((long)b * 2 + 0) * H1 + h1) * W1 + w1] * inv;
+    const float cy = coords[(((long)b * 2 + 1) * H1 + h1) * W1 + w1] * inv;
+    float x = cx + (float)(a - r);                 // x + dy[a]   (reference quirk)
+    float y = cy + (float)(d - r);                 // y + dx[d]
+    // round trip through the normalised grid as the reference does (utils.py:61-65, align_corners=True)
+    x = ((2.f * x / (float)(Wl - 1) - 1.f) + 1.f) * 0.5f * (float)(Wl - 1);
+    y = ((2.f * y / (float)(Hl - 1) - 1.f) + 1.f) * 0.5f * (float)(Hl - 1);
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float* img = corr + n * (long)Hl * Wl;
+    auto at = [&](int yy, int xx) -> float {
+        return (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? img[(long)yy * Wl + xx] : 0.f;
+    };
+    const float v = at(y0, x0) * wy0 * wx0 + at(y0, x0 + 1) * wy0 * wx1 + at(y0 + 1, x0) * wy1 * wx0 + at(y0 + 1, x0 + 1) * wy1 * wx1;
+    out[(((long)b * nlevels * ne + (long)level * ne + e) * H1 + h1) * W1 + w1] = v;
+}
+
+}  // namespace ppv
+
+extern "C" {
+
+// corr [B][HW][HW] f32 = f1^T f2 / sqrt(C); f1, f2 [B,C,H,W] f32.  HW % 128 == 0, C % 16 == 0.
+int ppv_corr_volume(const float* f1, const float* f2, float* corr, int B, int C, int HW, hipStream_t stream) {
+    if (!f1 || !f2 || !corr) return PPV_ERR_NULL;
+    if (HW % 128 || C % 16) return PPV_ERR_BAD_SIZE;
+    ppv::corr_volume_kernel<<<dim3(HW / 128, HW / 128, B), 256, 0, stream>>>(f1, f2, corr, C, HW, 1.0f / sqrtf((float)C));
+    return ppv_last_error();
+}
+
+int ppv_avgpool2(const float* in, float* out, long n, int H, int W, hipStream_t stream) {
+    if (!in || !out) return PPV_ERR_NULL;
+    if (H % 2 || W % 2) return PPV_ERR_BAD_SIZE;
+    const long tot = n * (H / 2) * (W / 2);
+    ppv::avgpool2_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(in, out, n, H, W);
+    return ppv_last_error();
+}
+
+// one pyramid level: corr_l [B*H1*W1][Hl][Wl], coords [B,2,H1,W1] (x, y), out [B, nlevels*(2r+1)^2, H1, W1]
+int ppv_corr_lookup(const float* corr_l, const float* coords, float* out, int B, int H1, int W1, int Hl, int Wl, int r,
+                    int level, int nlevels, hipStream_t stream) {
+    if (!corr_l || !coords || !out) return PPV_ERR_NULL;
+    const long tot = (long)B * H1 * W1 * (2 * r + 1) * (2 * r + 1);
+    ppv::corr_lookup_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(corr_l, coords, out, B, H1, W1, Hl, Wl, r, level, nlevels);
+    return ppv_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+"""RAFT CorrBlock: the CPU oracle against the golden captured from the reference (CPU), and the HIP drop-in against
+both (GPU)."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+
+def test_oracle_matches_reference_golden():
+    from oracle import corr as oc
+    g = load_golden("corr.npz")
+    f1, f2, coords = (torch.tensor(g[k]) for k in ("f1", "f2", "coords"))
+    pyr = oc.pyramid(oc.corr_volume(f1, f2))
+    assert rel_err(pyr[0], g["pyr0"]) < 1e-6 and rel_err(pyr[3], g["pyr3"]) < 1e-6
+    assert rel_err(oc.lookup(pyr, coords), g["out"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_corrblock_matches_reference_golden():
+    from ppv_amd.raft_corr import CorrBlock
+    g = load_golden("corr.npz")
+    f1, f2, coords = (torch.tensor(g[k]).cuda() for k in ("f1", "f2", "coords"))
+    blk = CorrBlock(f1, f2, num_levels=4, radius=4)
+    assert rel_err(blk.corr_pyramid[0], g["pyr0"]) < 1e-5 and rel_err(blk.corr_pyramid[3], g["pyr3"]) < 1e-5
+    out = blk(coords)
+    assert out.shape == (1, 324, 16, 16)
+    assert rel_err(out, g["out"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_corrblock_matches_oracle_at_config4_shape():
+    """fmaps [2,256,32,32] (256^2 input / 8), coords = grid + N(0, 2^2)  (reduced to 2 samples)."""
+    from oracle import corr as oc
+    from ppv_amd.raft_corr import CorrBlock
+    g0 = torch.Generator().manual_seed(0)
+    f1 = torch.randn(2, 256, 32, 32, generator=g0)
+    f2 = torch.randn(2, 256, 32, 32, generator=g0)
+    ys, xs = torch.meshgrid(torch.arange(32), torch.arange(32), indexing="ij")
+    coords = torch.stack([xs, ys], 0).float()[None].repeat(2, 1, 1, 1) + 2.0 * torch.randn(2, 2, 32, 32, generator=g0)
+    want = oc.lookup(oc.pyramid(oc.corr_volume(f1, f2)), coords)
+    blk = CorrBlock(f1.cuda(), f2.cuda())
+    assert rel_err(blk(coords.cuda()), want) < 1e-4

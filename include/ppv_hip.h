@@ -88,6 +88,7 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
                   int off, int div, int out_f32, int stat_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
+int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, ppv_stream_t stream);
 int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, ppv_stream_t stream);
 
 /* weight gradient (layer2..4 trainable, models.py:43-54): torch layout [N][Cs][R][S] f32 out; per-slice slabs in scratch */
@@ -107,7 +108,8 @@ int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* co
                int res_mode, int relu, ppv_stream_t stream);
 int ppv_bn_bwd_blocks(long rows, int C);
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
-               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, ppv_stream_t stream);
+               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
+               ppv_stream_t stream);
 /* stem BN + ReLU + MaxPool 3x3/2 (resnet.1-3) and AdaptiveAvgPool2d(36) (models.py:27,39-40) */
 int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, int B, int H, int W, int C,
                         ppv_stream_t stream);

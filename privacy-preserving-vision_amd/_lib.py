@@ -40,6 +40,7 @@ PROTOTYPES = {
     "ppv_fd_psf_workspace_bytes": (_Z, [_I]),
     "ppv_fd_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
     "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
+    "ppv_weight_layout_multi": (_I, [_P, _I, _I, _P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
     "ppv_conv_set_variant": (_I, [_I]),
@@ -52,7 +53,7 @@ PROTOTYPES = {
     "ppv_bn_finalize": (_I, [_P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_bwd_blocks": (_I, [_L, _I]),
-    "ppv_bn_bwd": (_I, [_P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "ppv_bn_bwd": (_I, [_P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_relu_maxpool": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_maxpool_relu_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_adaptive_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -12,12 +12,22 @@ BF16, F32 = torch.bfloat16, torch.float32
 def zero_page(device):
     key = (device.type, device.index)
     if key not in _zero_pages:
+        _apply_env_variants()
         _zero_pages[key] = torch.zeros(256, dtype=torch.uint8, device=device)
     return _zero_pages[key]
 
 
 def L():
     return _lib.lib()
+
+
+def _apply_env_variants():
+    """tuning hooks (A/B runs): PPV_CONV_VARIANT / PPV_WGRAD_VARIANT, see csrc/conv_gemm.hip, conv_wgrad_stem.hip"""
+    import os
+    if "PPV_CONV_VARIANT" in os.environ:
+        L().ppv_conv_set_variant(int(os.environ["PPV_CONV_VARIANT"], 0))
+    if "PPV_WGRAD_VARIANT" in os.environ:
+        L().ppv_wgrad_set_variant(int(os.environ["PPV_WGRAD_VARIANT"], 0))
 
 
 # bench.py sets PROFILE = [] to collect (kernel, algorithmic flops, start event, end event) per conv launch
@@ -43,6 +53,37 @@ def weight_layout(w, mode):
     out = torch.empty(shape, dtype=BF16, device=w.device)
     check(L().ppv_weight_layout(ptr(w.contiguous()), ptr(out), Cout, Cin, R, S, mode, stream_ptr()), "ppv_weight_layout")
     return out
+
+
+class WeightLayouts:
+    """bf16 kernel layouts (forward + data-gradient) of a list of conv weights, refreshed by ONE launch."""
+
+    def __init__(self, weights):
+        import struct
+        self.weights = list(weights)
+        dev = self.weights[0].device
+        self.fwd, self.dg = [], []
+        recs, blk = [], 0
+        for w in self.weights:
+            Cout, Cin, R, S = w.shape
+            f = torch.empty((Cout, R, S, Cin), dtype=BF16, device=dev)
+            d = torch.empty((Cin, R, S, Cout), dtype=BF16, device=dev)
+            self.fwd.append(f)
+            self.dg.append(d)
+            recs.append(struct.pack("<QQQiiiii", w.data_ptr(), f.data_ptr(), d.data_ptr(), Cout, Cin, R, S, blk))
+            recs[-1] += b"\0" * (48 - len(recs[-1]))
+            blk += (w.numel() + 255) // 256
+        self.total_blocks = blk
+        import numpy as np
+        self.desc = torch.from_numpy(np.frombuffer(b"".join(recs), dtype=np.uint8).copy()).to(dev)
+        self._ptrs = [w.data_ptr() for w in self.weights]
+
+    def valid(self):
+        return all(w.data_ptr() == p for w, p in zip(self.weights, self._ptrs))
+
+    def refresh(self):
+        check(L().ppv_weight_layout_multi(ptr(self.desc), len(self.weights), self.total_blocks, stream_ptr()),
+              "ppv_weight_layout_multi")
 
 
 def stat_tiles(M):
@@ -141,8 +182,8 @@ def bn_act(x, coef, res=None, coef_res=None, relu=True):
     return y
 
 
-def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True):
-    """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None)."""
+def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None):
+    """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None).  part: optional PRE-ZEROED f32 [64*C] scratch."""
     C = x.shape[-1]
     rows = x.numel() // C
     dev = x.device
@@ -150,10 +191,12 @@ def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True):
     gpre = torch.empty_like(x) if want_gpre else None
     dg = torch.empty(C, dtype=F32, device=dev) if want_affine else None
     db = torch.empty(C, dtype=F32, device=dev) if want_affine else None
-    part = torch.empty(64 * C, dtype=F32, device=dev)
+    prezeroed = part is not None
+    if part is None:
+        part = torch.empty(64 * C, dtype=F32, device=dev)
     kc = torch.empty(3 * C, dtype=F32, device=dev)
     check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
-                         ptr(kc), rows, C, int(relu), stream_ptr()), "ppv_bn_bwd")
+                         ptr(kc), rows, C, int(relu), int(prezeroed), stream_ptr()), "ppv_bn_bwd")
     return gx, gpre, dg, db
 
 

@@ -484,6 +484,26 @@ __global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const float* _
     o[i] = f2bf(w[(((long)n * Cin + c) * R + (R - 1 - r)) * S + (S - 1 - s)]);
 }
 
+// one launch for a whole list of convolutions: desc[i] = {w f32*, fwd bf16*, dgrad bf16*, Cout, Cin, R, S, first block}
+struct WLayoutDesc { const float* w; bf16_t* fwd; bf16_t* dg; int Cout, Cin, R, S, blk0; };
+__global__ __launch_bounds__(256) void weight_layout_multi_kernel(const WLayoutDesc* __restrict__ desc, int ndesc) {
+    // binary search of the descriptor that owns this block
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WLayoutDesc d = desc[lo];
+    const long i = (long)(blockIdx.x - d.blk0) * 256 + threadIdx.x;         // index in torch order [n][c][r][s]
+    const long tot = (long)d.Cout * d.Cin * d.R * d.S;
+    if (i >= tot) return;
+    const int s_ = (int)(i % d.S), r = (int)((i / d.S) % d.R), c = (int)((i / ((long)d.S * d.R)) % d.Cin);
+    const int n = (int)(i / ((long)d.S * d.R * d.Cin));
+    const bf16_t v = f2bf(d.w[i]);
+    d.fwd[(((long)n * d.R + r) * d.S + s_) * d.Cin + c] = v;
+    d.dg[(((long)c * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - s_)) * d.Cout + n] = v;
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -556,6 +576,14 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
 int ppv_conv_stat_tiles(long M) {
     const long t = (M + 127) / 128;
     return (int)(t < 32 ? t : 32);
+}
+
+// desc: device array of ndesc records {const float* w; void* fwd; void* dgrad; int Cout, Cin, R, S, blk0} (40 bytes each,
+// blk0 = prefix sum of ceil(numel/256)); total_blocks = sum.  Converts every listed weight to both bf16 layouts.
+int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, hipStream_t stream) {
+    if (!desc || ndesc < 1) return PPV_ERR_NULL;
+    weight_layout_multi_kernel<<<total_blocks, 256, 0, stream>>>((const WLayoutDesc*)desc, ndesc);
+    return ppv_last_error();
 }
 
 // mode 0: [Cout][Cin][R][S] f32 -> [Cout][R][S][Cin] bf16 (forward);  mode 1: -> [Cin][R][S][Cout] bf16 flipped (dgrad)

@@ -149,11 +149,16 @@ __global__ __launch_bounds__(256) void zernike_grad_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, float* __restrict__ out,
                                                            int nwg, int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    // one workgroup per coefficient: 256 threads stride over the per-workgroup partials
+    __shared__ double s_red[4];
+    const int k = blockIdx.x;
     double a = 0;
-    for (int w = 0; w < nwg; ++w) a += part[(long)w * K + k];
-    out[k] = (float)a;
+    for (int w = threadIdx.x; w < nwg; w += 256) a += part[(long)w * K + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k] = (float)(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
 // ----------------------------------------------------------------------------- field at the phase plate
@@ -549,7 +554,7 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
     ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
     const unsigned nwg = (unsigned)((npx4 + 255) / 256);
     zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, w.gh, w.part, K, npx4);
-    sum_partials_kernel<<<(K + 255) / 256, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg, K);
+    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg, K);
     return ppv_last_error();
 }
 

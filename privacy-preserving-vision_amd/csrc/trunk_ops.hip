@@ -359,7 +359,8 @@ int ppv_bn_bwd_blocks(long rows, int C) {
 // Train-mode BN backward (+ ReLU mask from y when relu != 0).  Writes g_x (bf16), optionally g_pre (bf16, may be
 // null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats (zeroed here); kc: scratch 3*C.
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
-               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, hipStream_t stream) {
+               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
+               hipStream_t stream) {
     if (!gy || !x || !coef || !gx || !part || !kc || (relu && !y)) return PPV_ERR_NULL;
     if (C % 64 || C > 2048) return PPV_ERR_BAD_SIZE;
     const int rpp = 256 / (C / 8);
@@ -367,7 +368,7 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
     long nb = (rows + rpb - 1) / rpb;
     while (nb > 2048) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
     const bf16_t *g = (const bf16_t*)gy, *yy = (const bf16_t*)y, *xx = (const bf16_t*)x;
-    (void)hipMemsetAsync(part, 0, sizeof(float) * 64 * C, stream);
+    if (!part_prezeroed) (void)hipMemsetAsync(part, 0, sizeof(float) * 64 * C, stream);
     if (relu) bn_bwd_reduce_kernel<true><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
     else bn_bwd_reduce_kernel<false><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
     bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, 32, count, coef, kc, dgamma, dbeta, C);

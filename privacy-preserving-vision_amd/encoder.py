@@ -58,7 +58,7 @@ def _make_trunk(layers):
 
 class _ConvRec:
     """one conv + its BatchNorm, with cached bf16 kernel layouts keyed on the parameter version."""
-    __slots__ = ("conv", "bn", "k", "stride", "pad", "_wt", "_wd", "_ver_t", "_ver_d", "stem")
+    __slots__ = ("conv", "bn", "k", "stride", "pad", "_wt", "_wd", "_ver_t", "_ver_d", "stem", "wl", "wl_idx")
 
     def __init__(self, conv, bn, stem=False):
         self.conv, self.bn = conv, bn
@@ -66,11 +66,14 @@ class _ConvRec:
         self._wt = self._wd = None
         self._ver_t = self._ver_d = -1
         self.stem = stem
+        self.wl, self.wl_idx = None, -1          # shared WeightLayouts of the trainable convs (one refresh launch per step)
 
     # Frozen weights are converted once; trainable ones every step (fused optimisers update ``.data`` without a
     # reliable version bump, so the cache key is (version, step token)).
     def wt(self, token=0):
         w = self.conv.weight
+        if self.wl is not None and w.requires_grad:
+            return self.wl.fwd[self.wl_idx]
         if w.requires_grad:
             if self._wt is None or self._ver_t != token:
                 self._wt = co.weight_layout(w.detach(), 0)
@@ -83,6 +86,8 @@ class _ConvRec:
 
     def wd(self, token=0):
         w = self.conv.weight
+        if self.wl is not None and w.requires_grad:
+            return self.wl.dg[self.wl_idx]
         if w.requires_grad:
             if self._wd is None or self._ver_d != token:
                 self._wd = co.weight_layout(w.detach(), 1)
@@ -117,6 +122,7 @@ class _TrunkFn(torch.autograd.Function):
 
         enc._step_token += 1
         tok = enc._step_token
+        enc._refresh_weight_layouts()
         # one zeroed f32 pool for every conv's BN partial sums of this step ([rows<=32][2][C] each)
         pool = torch.zeros(enc._stat_pool_elems(B, H, W), dtype=torch.float32, device=dev) if train else None
         pool_off = [0]
@@ -190,9 +196,20 @@ class _TrunkFn(torch.autograd.Function):
                     need = max(need, co.wgrad_scratch_bytes(gy_.numel() // gy_.shape[-1], w_.shape[0], rec_.k, rec_.k, w_.shape[1]))
         wscratch = torch.empty(max(need, 16), dtype=torch.uint8, device=g_out.device)
 
+        # one zeroed pool for every BN's [32][2][C] backward partial sums of this step
+        bn_ch = sum(r.conv.out_channels for blk_ in enc._blocks for r in blk_ if r is not None) + 64
+        bpool = torch.zeros(64 * bn_ch, dtype=torch.float32, device=g_out.device)
+        boff = [0]
+
+        def bn_part(C):
+            v = bpool[boff[0]:boff[0] + 64 * C]
+            boff[0] += 64 * C
+            return v
+
         def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False):
             trainable = rec.conv.weight.requires_grad
-            gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad)
+            gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad,
+                                         part=bn_part(xraw.shape[-1]))
             sync = enc.grad_sync
             if trainable:
                 grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch)
@@ -233,7 +250,7 @@ class _TrunkFn(torch.autograd.Function):
             st = enc._stem
             if st.conv.weight.requires_grad:
                 raise NotImplementedError("the stem convolution is frozen in the reference (models.py:43-54)")
-            gx0, _, dg, db = co.bn_bwd(gpre0, None, raw0, c0, False, want_affine=st.bn.weight.requires_grad)
+            gx0, _, dg, db = co.bn_bwd(gpre0, None, raw0, c0, False, want_affine=st.bn.weight.requires_grad, part=bn_part(64))
             if st.bn.weight.requires_grad:
                 grads[st.bn.weight], grads[st.bn.bias] = dg, db
             if needs_img:
@@ -276,6 +293,28 @@ class Encoder(nn.Module):
                 if r is not None:
                     tot += co.stat_tiles(B * h * w) * 2 * r.conv.out_channels
         return tot
+
+    def _refresh_weight_layouts(self):
+        """(Re)build the shared bf16 layouts of the trainable convs and refresh them with one launch."""
+        recs = [r for blk in self._blocks for r in blk if r is not None and r.conv.weight.requires_grad and r.conv.weight.is_cuda]
+        wl = getattr(self, "_wl", None)
+        if not recs:
+            for blk in self._blocks:
+                for r in blk:
+                    if r is not None:
+                        r.wl = None
+            object.__setattr__(self, "_wl", None)
+            return
+        if wl is None or len(wl.weights) != len(recs) or not wl.valid() or any(a is not r.conv.weight for a, r in zip(wl.weights, recs)):
+            for blk in self._blocks:
+                for r in blk:
+                    if r is not None:
+                        r.wl = None
+            wl = co.WeightLayouts([r.conv.weight for r in recs])
+            for i, r in enumerate(recs):
+                r.wl, r.wl_idx = wl, i
+            object.__setattr__(self, "_wl", wl)
+        wl.refresh()
 
     def _param_list(self):
         return list(self.resnet.parameters())

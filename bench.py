@@ -96,8 +96,20 @@ def roofline_of_dominant_kernel(step):
     fl, sec, n = agg[dom]
     achieved = fl / sec / 1e12
     detail = {k: {"launches": v[2], "tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3)} for k, v in agg.items()}
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md); PMC cannot be collected inside this process
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc) and dom == "conv_gemm<128>":
+        try:
+            pk = json.load(open(pmc))["per_kernel"]
+            for name, v in pk.items():
+                if "conv_gemm_pipe_kernel<256, 128, 3, false>" in name:
+                    traffic = round(v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"])
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+            "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
             "avg_launch_us": round(sec / n * 1e6, 2), "per_kernel": detail}
 
 
@@ -172,6 +184,7 @@ def main():
             dist.init_process_group(backend)
     rank = dist.get_rank() if world > 1 else 0
 
+    torch.manual_seed(1234)                      # identical height-map noise stream on every rank -> identical PSF
     camera, encoder = build(device, global_max_sync=world > 1)
     sync = None
     if world > 1:

@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
 // ----------------------------------------------------------------------------- BN backward
 // pass 1: per-channel partial sums of g_pre and g_pre * x, g_pre = g_y * (y > 0) [RELU] ; part [32][2][C] pre-zeroed,
 // block b adds into row b & 31
-template <bool RELU>
+// RELU: 0 none, 1 mask from the stored activation y, 2 mask recomputed as (x*scale + shift > 0) from coef (BN + ReLU
+// without residual: saves reading y; the expression is the forward kernel's, so the mask is bit-identical)
+template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
-                                                            const bf16_t* __restrict__ x, float* __restrict__ part,
-                                                            long rows, int C, int rows_per_blk) {
+                                                            const bf16_t* __restrict__ x, const float* __restrict__ coef,
+                                                            float* __restrict__ part, long rows, int C, int rows_per_blk) {
     __shared__ float s_red[256][17];
     const int tpr = C / 8;                         // threads per row
     const int rpp = 256 / tpr;                     // rows per pass
@@ -108,15 +110,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     float a[8], b[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = b[k] = 0.f;
+    float sc[8], sh[8];
+    if (RELU == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = coef[tc * 8 + k]; sh[k] = coef[C + tc * 8 + k]; }
+    }
     if (tr < rpp) {
         for (long row = r0 + tr; row < r1; row += rpp) {
             const long o = row * C + tc * 8;
             float g[8], xv[8], yv[8];
             load8(gy + o, g);
             load8(x + o, xv);
-            if (RELU) load8(y + o, yv);
+            if (RELU == 1) load8(y + o, yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
+                if (RELU == 2) yv[k] = xv[k] * sc[k] + sh[k];
                 const float gp = (RELU && !(yv[k] > 0.f)) ? 0.f : g[k];
                 a[k] += gp;
                 b[k] += gp * xv[k];
@@ -167,20 +175,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(const float* __restri
 }
 
 // pass 2: g_x = kc0*g_pre + kc1*x + kc2 ; optionally also store g_pre (the residual branch's gradient)
-template <bool RELU, bool WRITE_GPRE>
+template <int RELU, bool WRITE_GPRE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
                                                            const bf16_t* __restrict__ x, const float* __restrict__ kc,
-                                                           bf16_t* __restrict__ gx, bf16_t* __restrict__ gpre, long n8,
-                                                           int C) {
+                                                           const float* __restrict__ coef, bf16_t* __restrict__ gx,
+                                                           bf16_t* __restrict__ gpre, long n8, int C) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const int c0 = (int)((i * 8) % C);
     float g[8], xv[8], yv[8], o[8], gp[8];
     load8(gy + i * 8, g);
     load8(x + i * 8, xv);
-    if (RELU) load8(y + i * 8, yv);
+    if (RELU == 1) load8(y + i * 8, yv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        if (RELU == 2) yv[k] = xv[k] * coef[c0 + k] + coef[C + c0 + k];
         gp[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : g[k];
         o[k] = kc[c0 + k] * gp[k] + kc[C + c0 + k] * xv[k] + kc[2 * C + c0 + k];
     }
@@ -356,12 +365,13 @@ int ppv_bn_bwd_blocks(long rows, int C) {
     return (int)nb;
 }
 
-// Train-mode BN backward (+ ReLU mask from y when relu != 0).  Writes g_x (bf16), optionally g_pre (bf16, may be
+// Train-mode BN backward; relu: 0 none, 1 ReLU mask from the stored activation y, 2 mask recomputed from x and coef
+// (BN + ReLU without residual; y may be null).  Writes g_x (bf16), optionally g_pre (bf16, may be
 // null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats (zeroed here); kc: scratch 3*C.
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
                hipStream_t stream) {
-    if (!gy || !x || !coef || !gx || !part || !kc || (relu && !y)) return PPV_ERR_NULL;
+    if (!gy || !x || !coef || !gx || !part || !kc || (relu == 1 && !y)) return PPV_ERR_NULL;
     if (C % 64 || C > 2048) return PPV_ERR_BAD_SIZE;
     const int rpp = 256 / (C / 8);
     long rpb = (long)rpp * 16;
@@ -369,16 +379,19 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
     while (nb > 2048) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
     const bf16_t *g = (const bf16_t*)gy, *yy = (const bf16_t*)y, *xx = (const bf16_t*)x;
     if (!part_prezeroed) (void)hipMemsetAsync(part, 0, sizeof(float) * 64 * C, stream);
-    if (relu) bn_bwd_reduce_kernel<true><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
-    else bn_bwd_reduce_kernel<false><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, part, rows, C, (int)rpb);
+    if (relu == 2) bn_bwd_reduce_kernel<2><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb);
+    else if (relu) bn_bwd_reduce_kernel<1><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb);
+    else bn_bwd_reduce_kernel<0><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb);
     bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, 32, count, coef, kc, dgamma, dbeta, C);
     const long n8 = rows * C / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
     bf16_t *ox = (bf16_t*)gx, *op = (bf16_t*)gpre;
-    if (relu && gpre) bn_bwd_apply_kernel<true, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
-    else if (relu) bn_bwd_apply_kernel<true, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
-    else if (gpre) bn_bwd_apply_kernel<false, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
-    else bn_bwd_apply_kernel<false, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, ox, op, n8, C);
+    if (relu == 2 && gpre) bn_bwd_apply_kernel<2, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
+    else if (relu == 2) bn_bwd_apply_kernel<2, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
+    else if (relu && gpre) bn_bwd_apply_kernel<1, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
+    else if (relu) bn_bwd_apply_kernel<1, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
+    else if (gpre) bn_bwd_apply_kernel<0, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
+    else bn_bwd_apply_kernel<0, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
     return ppv_last_error();
 }
 

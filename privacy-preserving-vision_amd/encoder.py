@@ -231,9 +231,9 @@ class _TrunkFn(torch.autograd.Function):
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
             gx3, gpre = conv_bn_bwd(r3, g, yout, x3, c3, y2, True, want_gpre=True)
             gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
-            gx2, _ = conv_bn_bwd(r2, gy2, y2, x2, c2, y1, True)
+            gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)       # mask recomputed from x2 (no residual): y2 not read
             gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
-            gx1, _ = conv_bn_bwd(r1, gy1, y1, x1, c1, xin, True)
+            gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2)
             if rd is not None:
                 gxd, _ = conv_bn_bwd(rd, gpre, None, xd, cd, xin, False)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)

@@ -89,6 +89,9 @@ def test_batchnorm_train_forward_backward(C, res_mode):
     assert rel_err(dg, gamma.grad) < 5e-3 and rel_err(db, beta.grad) < 5e-3
     mask = (nhwc(y.detach()) > 0).float()
     assert rel_err(gpre.float() * mask.cuda(), nhwc(gy) * mask) < BF
+    if res_mode == 0:          # mask recomputed from x and the BN coefficients must give the same result
+        gx2, _, dg2, db2 = co.bn_bwd(nhwc(gy).cuda().bfloat16(), None, xd, coef, relu=2)
+        assert torch.equal(gx2, gx) and torch.equal(dg2, dg)
 
 
 def test_stem_bn_relu_maxpool_forward_backward():

@@ -12,7 +12,7 @@ class GradSync:
         self.world = dist.get_world_size(process_group)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.stream = None
-        self._bucket, self._size = [], 0
+        self._bucket, self._size, self._events = [], 0, []
         self.launched = 0
 
     # -- called by Encoder backward as each gradient tensor becomes final
@@ -20,21 +20,25 @@ class GradSync:
         if grad is None:
             return
         self._bucket.append(grad)
+        if grad.is_cuda:                         # the gradient is complete on whichever stream produced it
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events.append(ev)
         self._size += grad.numel() * grad.element_size()
         if self._size >= self.bucket_bytes:
             self._launch()
 
     def _launch(self):
         grads, self._bucket, self._size = self._bucket, [], 0
+        events, self._events = self._events, []
         if not grads:
             return
         self.launched += 1
         if grads[0].is_cuda:
             if self.stream is None:
                 self.stream = torch.cuda.Stream(device=grads[0].device)
-            ev = torch.cuda.Event()
-            ev.record()                              # gradients of this bucket are complete on the compute stream
-            self.stream.wait_event(ev)
+            for ev in events:                        # every gradient of this bucket, on its producing stream
+                self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 self._reduce(grads)
                 for g in grads:

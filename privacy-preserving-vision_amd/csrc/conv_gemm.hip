@@ -242,17 +242,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
 // WAR: stage t+NSTAGE-1 overwrites the buffer last read in compute(t-1), which every wave finished before barrier t.
 template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NSTAGE, bool OUT_F32>
-__global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32>
+__global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend,
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                                    int tiles_n, int stat_rows) {
-    constexpr int BK = 64, NT = BM * 2, NWAVE = NT / 64;
+    constexpr int NT = BM * 2, NWAVE = NT / 64;
+    constexpr int ROWB = BK * 2, CH = BK / 8;                             // bytes / 16-byte chunks per staged row
+    constexpr int RPI = 1024 / ROWB;                                       // rows per 1-KiB LDS-DMA wave-instruction
     constexpr int WN = BN / 64 > 0 ? BN / 64 : 1, WM = NWAVE / WN;        // wave grid; each wave owns 64 x (BN / WN)
     constexpr int WROWS = BM / WM, WCOLS = BN / WN, MI = WROWS / 16, NI = WCOLS / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int RPR = NT / 8;                                            // rows staged per round
+    constexpr int RPR = NWAVE * RPI;                                       // rows staged per round
     constexpr int ASLOTS = BM / RPR, BSLOTS = BN / RPR, L = ASLOTS + BSLOTS;
     static_assert(BN % RPR == 0 && WM * WN == NWAVE && MI * 16 == WROWS, "tile / wave grid mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,14 +270,17 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
     const long m0 = (long)tile_m * BM;
     const int n0 = tile_n * BN;
 
-    const int rl = lane >> 3, p = lane & 7, cch = p ^ rl;
+    // swizzle key of a row: 128-byte rows chunk ^= row & 7; 64-byte rows chunk ^= 3 * ((row >> 3) & 1) -- both make every
+    // ds_read_b128 fragment read conflict-free (worked out per 16-lane b128 group)
+    auto key = [](int row) { return BK == 64 ? (row & 7) : (((row >> 3) & 1) * 3); };
+    const int rl = lane / CH, p = lane % CH, cch = p ^ key(rl);
     int a_h0[ASLOTS], a_w0[ASLOTS], a_pix[ASLOTS];
     bool a_ok[ASLOTS];
     const long zdelta = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
     const int HoWo = g.Ho * g.Wo;
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i) {
-        const long m = m0 + i * RPR + wave * 8 + rl;
+        const long m = m0 + i * RPR + wave * RPI + rl;
         a_ok[i] = m < g.M;
         const long mm = a_ok[i] ? m : 0;
         const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
     const int dm = (1 << g.sh) - 1;
     const bf16_t* wbase[BSLOTS];
 #pragma unroll
-    for (int i = 0; i < BSLOTS; ++i) wbase[i] = Wt + (long)(n0 + i * RPR + wave * 8 + rl) * wrow + cch * 8;
+    for (int i = 0; i < BSLOTS; ++i) wbase[i] = Wt + (long)(n0 + i * RPR + wave * RPI + rl) * wrow + cch * 8;
 
     // staging cursor (advances one K-step per call).  The gather addresses are rebuilt only when the tap changes
     // (once per Cs/64 K-steps); inside a tap every valid row just walks 128 bytes along its channel run, so the
@@ -314,11 +319,11 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
         char* sa = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
-            GLDS16(reinterpret_cast<const char*>(X) + a_off[i], sa + (i * RPR + wave * 8) * 128);
+            GLDS16(reinterpret_cast<const char*>(X) + a_off[i], sa + (i * RPR + wave * RPI) * ROWB);
             a_off[i] += a_inc[i];
         }
 #pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) GLDS16(wbase[i] + skoff, sa + A_BYTES + (i * RPR + wave * 8) * 128);
+        for (int i = 0; i < BSLOTS; ++i) GLDS16(wbase[i] + skoff, sa + A_BYTES + (i * RPR + wave * RPI) * ROWB);
         skoff += BK;
         sc0 += BK;
         if (sc0 == g.Cs) {
@@ -339,13 +344,13 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
     auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[MI], bfr[NI];
-            const int chunk = ((kk * 4 + fq) ^ (fr & 7)) * 16;
+            const int chunk = ((kk * 4 + fq) ^ key(fr)) * 16;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sa + (wm * WROWS + mi * 16 + fr) * 128 + chunk);
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sa + (wm * WROWS + mi * 16 + fr) * ROWB + chunk);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (wn * WCOLS + ni * 16 + fr) * 128 + chunk);
+            for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (wn * WCOLS + ni * 16 + fr) * ROWB + chunk);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(BM * 2, 1) void conv_gemm_pipe_kernel(const bf16_t*
         // the addend tile comes in as whole 16-byte chunks (coalesced), is parked in LDS behind the output staging
         // area and added fragment-wise in f32: one rounding of (acc + addend), no 2-byte global gathers
         char* sAdd = smem + BM * LDO + 2048;
-        static_assert(2 * BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "addend staging does not fit the stage ring");
+        if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) return;      // host never launches this combination
 #pragma unroll
         for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
             const int idx = it * NT + tid;
@@ -539,12 +544,12 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
         if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows); \
         else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows);        \
     } while (0)
-#define PPV_LAUNCH_PIPE(BM_, BN_, NS_)                                                                                  \
+#define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_)                                                                                  \
     do {                                                                                                                \
-        constexpr int lds = NS_ * (BM_ + BN_) * 128;                                                                    \
+        constexpr int lds = NS_ * (BM_ + BN_) * BK_ * 2;                                                                    \
         const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;                                                      \
-        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, false>;                                                          \
-        auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, true>;                                                           \
+        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false>;                                                          \
+        auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, true>;                                                           \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
@@ -554,16 +559,21 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
         if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, z, g, tn, stat_rows);              \
         else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, z, g, tn, stat_rows);                      \
     } while (0)
-    // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages
+    // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages (BK 64),
+    // 4 = 256 x 128 x 3 stages of BK 32, two workgroups per CU
     const int CUS = 256;
     int v = g_conv_variant;
     if (N == 16 || N % 128) v = 1;
-    if (v == 0) {
+    if (v == 0) {                               // measured on the ResNet-101 shapes (tools/bench_conv.py, B = 128)
         const long t256 = ((g.M + 255) / 256) * (N / 128);
-        v = (t256 >= CUS) ? 3 : 2;              // the 256-row tile only when it still fills the chip
+        if (t256 >= 2 * CUS && !addend) v = 4;  // several rounds of tiles: two workgroups per CU hide tile pro/epilogues
+        else if (t256 >= CUS) v = 3;            // one round: deepest prefetch per workgroup
+        else v = 2;                             // the 256-row tile only when it still fills the chip
     }
-    if (v == 3) PPV_LAUNCH_PIPE(256, 128, 3);
-    else if (v == 2) PPV_LAUNCH_PIPE(128, 128, 4);
+    if (v == 4 && addend) v = 3;                // the 72 KB ring cannot park the addend tile
+    if (v == 4) PPV_LAUNCH_PIPE(256, 128, 3, 32, 2);      // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
+    else if (v == 3) PPV_LAUNCH_PIPE(256, 128, 3, 64, 1);
+    else if (v == 2) PPV_LAUNCH_PIPE(128, 128, 4, 64, 1);
     else if (N == 16) PPV_LAUNCH(16, 4, 1);
     else if (N % 128 == 0) PPV_LAUNCH(128, 2, N / 128);
     else PPV_LAUNCH(64, 2, N / 64);

@@ -1,0 +1,56 @@
+"""BASELINE.json config 2: camera alone, 64 x 3 x 256 x 256 fp32, forward + backward, one MI355X.
+Reports images/sec for the IC OpticsZernike (896/350, prueba '3', loss = sensor.mean() + loss_psf) and the FD Camera
+(N = 256, 300 terms, forward), and the achieved HBM rate of the FFT-convolution kernels against their algorithmic bytes
+(2.5 MB per 512^2 plane forward)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ppv_amd  # noqa: F401
+import ppv_amd.fftconv as fc
+from ppv_amd.camera_lens import OpticsZernike
+from ppv_amd.camera_optics import Camera
+
+dev = torch.device("cuda", 0)
+B = 64
+img = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(0)).to(dev)
+cam = OpticsZernike(input_shape=[None, 256, 256, 3], device=dev, zernike_terms=350, patch_size=256, height_tolerance=2e-8,
+                    sensor_distance=0.025, wave_resolution=[896, 896], sample_interval=3e-06, coeff_layout="B")
+
+
+def ic_step():
+    cam.zernike_coeffs_train.grad = None
+    sensor, psf, coeffs, loss = cam(img, None, "3")
+    (sensor.mean() + loss).backward()
+
+
+def timeit(fn, n=10, w=3):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+t_ic = timeit(ic_step)
+fd = Camera(device=dev, N=256, zernike_terms=300)
+imgn = img * 2 - 1
+t_fd = timeit(lambda: fd(imgn))
+# FFT convolution alone (forward): algorithmic bytes 2.5 MB per 512^2 plane
+psf = torch.rand(3, 256, 256, device=dev)
+otf = fc.otf_build(psf, 256, 512)
+ws = torch.empty(ppv_amd._lib.lib().ppv_fftconv_workspace_bytes(B, 3, 512), dtype=torch.uint8, device=dev)
+t_conv = timeit(lambda: fc.fftconv_fwd(img, otf, 0, workspace=ws), n=20)
+alg = B * 3 * 2.5e6
+print(json.dumps({
+    "config": "camera alone 64x3x256x256 fp32 (BASELINE.json configs[1])",
+    "ic_fwd_bwd_images_per_s": round(B / t_ic, 1), "ic_ms": round(t_ic * 1e3, 3),
+    "fd_fwd_images_per_s": round(B / t_fd, 1), "fd_ms": round(t_fd * 1e3, 3),
+    "fftconv_fwd_ms": round(t_conv * 1e3, 3), "fftconv_algorithmic_GBps": round(alg / t_conv / 1e9, 1),
+    "fftconv_frac_of_8TBps": round(alg / t_conv / 8e12, 3)}))

@@ -15,7 +15,7 @@ for cin, cout, k, st, h in SHAPES:
     part = torch.zeros(co.stat_tiles(B * ho * ho), 2, cout, device="cuda")
     fl = 2.0 * B * ho * ho * cout * cin * k * k
     line = f"cin {cin:5d} cout {cout:5d} k{k} s{st} h{h:3d}:"
-    for variant in (1, 2, 3):
+    for variant in (1, 3, 4):
         if cout % 128 and variant > 1:
             continue
         co.L().ppv_conv_set_variant(variant)

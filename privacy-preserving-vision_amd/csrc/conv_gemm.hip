@@ -401,7 +401,73 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         // the addend tile comes in as whole 16-byte chunks (coalesced), is parked in LDS behind the output staging
         // area and added fragment-wise in f32: one rounding of (acc + addend), no 2-byte global gathers
         char* sAdd = smem + BM * LDO + 2048;
-        if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) return;      // host never launches this combination
+        if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) {
+            // small ring (BK = 32): the output tile and the addend tile are processed in two 128-row halves
+            static_assert(BM == 256 && WM == 4 && BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "two-pass epilogue geometry");
+            constexpr int HR = BM / 2;                          // rows per pass
+            char* sOh = smem;
+            char* sAh = smem + HR * LDO;
+            float* sSt = reinterpret_cast<float*>(smem + 2 * HR * LDO);
+            bf16_t* outp = reinterpret_cast<bf16_t*>(Out);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int it = 0; it < (HR * CPR + NT - 1) / NT; ++it) {
+                    const int idx = it * NT + tid;
+                    const int row = idx / CPR, ch = idx % CPR;
+                    const long m = m0 + pass * HR + row;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (idx < HR * CPR && m < g.M) v = *reinterpret_cast<const uint4*>(addend + m * g.N + n0 + ch * 8);
+                    if (idx < HR * CPR) *reinterpret_cast<uint4*>(sAh + row * LDO + ch * 16) = v;
+                }
+                __syncthreads();
+                if ((wm >> 1) == pass) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        float s1 = 0.f, s2 = 0.f;
+                        const int col = wn * WCOLS + ni * 16 + fr;
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int rowl = (wm & 1) * WROWS + mi * 16 + fq * 4 + j;
+                                const float a = acc[mi][ni][j] + bf2f(*reinterpret_cast<const bf16_t*>(sAh + rowl * LDO + col * 2));
+                                const bf16_t h = f2bf(a);
+                                const float v = bf2f(h);
+                                s1 += v;
+                                s2 += v * v;
+                                *reinterpret_cast<bf16_t*>(sOh + rowl * LDO + col * 2) = h;
+                            }
+                        if (stat_part) {
+                            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                            if (fq == 0) {
+                                sSt[(wm * 2 + 0) * BN + col] = s1;
+                                sSt[(wm * 2 + 1) * BN + col] = s2;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < (HR * CPR + NT - 1) / NT; ++it) {
+                    const int idx = it * NT + tid;
+                    const int row = idx / CPR, ch = idx % CPR;
+                    const long m = m0 + pass * HR + row;
+                    if (idx < HR * CPR && m < g.M)
+                        *reinterpret_cast<uint4*>(outp + m * g.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(sOh + row * LDO + ch * 16);
+                }
+                __syncthreads();
+            }
+            if (stat_part && tid < 2 * BN) {
+                const int which = tid / BN, col = tid % BN;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) v += sSt[(w * 2 + which) * BN + col];
+                atomicAdd(&stat_part[((long)(tile_m % stat_rows) * 2 + which) * g.N + n0 + col], v);
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
             const int idx = it * NT + tid;
@@ -566,11 +632,10 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     if (N == 16 || N % 128) v = 1;
     if (v == 0) {                               // measured on the ResNet-101 shapes (tools/bench_conv.py, B = 128)
         const long t256 = ((g.M + 255) / 256) * (N / 128);
-        if (t256 >= 2 * CUS && !addend) v = 4;  // several rounds of tiles: two workgroups per CU hide tile pro/epilogues
+        if (t256 >= 2 * CUS) v = 4;             // several rounds of tiles: two workgroups per CU hide tile pro/epilogues
         else if (t256 >= CUS) v = 3;            // one round: deepest prefetch per workgroup
         else v = 2;                             // the 256-row tile only when it still fills the chip
     }
-    if (v == 4 && addend) v = 3;                // the 72 KB ring cannot park the addend tile
     if (v == 4) PPV_LAUNCH_PIPE(256, 128, 3, 32, 2);      // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
     else if (v == 3) PPV_LAUNCH_PIPE(256, 128, 3, 64, 1);
     else if (v == 2) PPV_LAUNCH_PIPE(128, 128, 4, 64, 1);

@@ -47,6 +47,21 @@ def build(device, global_max_sync):
     return camera, encoder
 
 
+class _MeanSquare(torch.autograd.Function):
+    """mean(x^2) with a one-pass forward (read) and a one-pass backward (read + write): the decoder stand-in must
+    consume encoder_out once and hand back a dense gradient once, nothing more."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.linalg.vector_norm(x) ** 2 / x.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return x * (g * (2.0 / x.numel()))
+
+
 def make_step(camera, encoder, batch, device, sync):
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
@@ -59,7 +74,7 @@ def make_step(camera, encoder, batch, device, sync):
         sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
         enc_out = encoder(sensor)
         # stand-in for CE + attention regulariser (the decoder is a next row): one read forward, one write backward
-        loss_head = torch.linalg.vector_norm(enc_out) ** 2 / enc_out.numel()
+        loss_head = _MeanSquare.apply(enc_out)
         loss_cam = 1 - torch.nn.functional.mse_loss(imgs, sensor)
         loss = 0.4 * loss_head + 6 * loss_cam + 30 * loss_psf
         opt_enc.zero_grad(set_to_none=True)

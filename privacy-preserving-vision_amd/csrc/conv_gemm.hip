@@ -403,7 +403,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         char* sAdd = smem + BM * LDO + 2048;
         if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) {
             // small ring (BK = 32): the output tile and the addend tile are processed in two 128-row halves
-            static_assert(BM == 256 && WM == 4 && BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "two-pass epilogue geometry");
+            static_assert(WM % 2 == 0 && BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "two-pass epilogue geometry");
             constexpr int HR = BM / 2;                          // rows per pass
             char* sOh = smem;
             char* sAh = smem + HR * LDO;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                     if (idx < HR * CPR) *reinterpret_cast<uint4*>(sAh + row * LDO + ch * 16) = v;
                 }
                 __syncthreads();
-                if ((wm >> 1) == pass) {
+                if (wm / (WM / 2) == pass) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         float s1 = 0.f, s2 = 0.f;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const int rowl = (wm & 1) * WROWS + mi * 16 + fq * 4 + j;
+                                const int rowl = (wm % (WM / 2)) * WROWS + mi * 16 + fq * 4 + j;
                                 const float a = acc[mi][ni][j] + bf2f(*reinterpret_cast<const bf16_t*>(sAh + rowl * LDO + col * 2));
                                 const bf16_t h = f2bf(a);
                                 const float v = bf2f(h);
@@ -629,6 +629,10 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     // 4 = 256 x 128 x 3 stages of BK 32, two workgroups per CU
     const int CUS = 256;
     int v = g_conv_variant;
+    if (N != 16 && N % 128 && (v == 0 || v >= 3) && g.M >= 128 * 1024) {
+        PPV_LAUNCH_PIPE(128, 64, 3, 32, 4);     // 64-column layers (layer1): HBM-bound, four small-ring workgroups per CU
+        return ppv_last_error();
+    }
     if (N == 16 || N % 128) v = 1;
     if (v == 0) {                               // measured on the ResNet-101 shapes (tools/bench_conv.py, B = 128)
         const long t256 = ((g.M + 255) / 256) * (N / 128);

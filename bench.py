@@ -118,9 +118,12 @@ def roofline_of_dominant_kernel(step):
     if os.path.exists(pmc) and dom == "conv_gemm<128>":
         try:
             pk = json.load(open(pmc))["per_kernel"]
-            for name, v in pk.items():
-                if "conv_gemm_pipe_kernel<256, 128, 3, false>" in name:
-                    traffic = round(v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"])
+            tot_b = tot_n = 0.0
+            for name, v in pk.items():          # every instantiation that serves the 128-column class
+                if "conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name:
+                    tot_b += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches_2steps"]
+                    tot_n += v["launches_2steps"]
+            traffic = round(tot_b / tot_n) if tot_n else None
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",

@@ -205,10 +205,61 @@ def gen_corr():
     print("corr", out.shape, stats(out))
 
 
+# --------------------------------------------------------------------------- FAN heat-map regressor
+def fill_by_name(module, scale_bn=True):
+    """Deterministic parameters / buffers keyed on state_dict names (no 27 MB weight fixture): every tensor is drawn
+    from a generator seeded with a CRC of its name.  Used identically by the oracle / product tests."""
+    import zlib
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+            if name.endswith("num_batches_tracked"):
+                continue
+            if name.endswith("running_var"):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            elif name.endswith("running_mean"):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+            elif t.dim() == 1 and ("bn" in name or "downsample.0" in name):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75 if name.endswith("weight") else torch.randn(t.shape, generator=g) * 0.1)
+            elif t.dim() == 1:
+                t.copy_(torch.randn(t.shape, generator=g) * 0.05)
+            else:
+                fan_in = t[0].numel()
+                t.copy_(torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5 * (0.004 if name.startswith("l0.") else 1.0))
+
+
+def gen_fan():
+    install_standins()
+    munch = types.ModuleType("munch")
+    munch.Munch = dict
+    sk = types.ModuleType("skimage")
+    sk.filters = types.ModuleType("skimage.filters")
+    sk.filters.gaussian = lambda *a, **k: None
+    for name, mod in [("munch", munch), ("skimage", sk), ("skimage.filters", sk.filters)]:
+        sys.modules[name] = mod
+    sys.path.insert(0, os.path.join(REF, "Face-DeId"))
+    from core.wing import FAN
+    fan = FAN().eval()
+    fill_by_name(fan)
+    out = {}
+    for tag, shape in (("b2_256", (2, 3, 256, 256)), ("b1_512", (1, 3, 512, 512))):
+        x = torch.rand(shape, generator=torch.Generator().manual_seed(0)) * 2 - 1
+        with torch.no_grad():
+            hm = fan.get_heatmap(x, Privacy=True)
+            xr = F.interpolate(x, size=256, mode="bilinear") * 0.5 + 0.5
+            raw = fan(xr)[0][-1]
+        out[f"{tag}_hm0"], out[f"{tag}_hm1"] = hm[0].numpy(), hm[1].numpy()
+        out[f"{tag}_raw_sub"] = raw[:, ::7, ::4, ::4].numpy()
+        out[f"{tag}_raw_stats"] = stats(raw)
+        print("fan", tag, "raw", stats(raw), "hm0", stats(hm[0]), "hm1", stats(hm[1]))
+    out["state_names"] = np.array(sorted(fan.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "fan.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        for w in ("ic", "fd", "corr"):
+        for w in ("ic", "fd", "corr", "fan"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr}[what]()
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan}[what]()

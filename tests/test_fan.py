@@ -1,0 +1,47 @@
+"""FAN heat-map regressor: CPU oracle pinned to the golden captured from the reference; HIP drop-in
+(bf16 storage, eval-mode BN) against the golden."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from fan_fill import fill_by_name
+
+
+def _inputs():
+    return {"b2_256": torch.rand((2, 3, 256, 256), generator=torch.Generator().manual_seed(0)) * 2 - 1,
+            "b1_512": torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(0)) * 2 - 1}
+
+
+def test_oracle_fan_matches_reference_golden():
+    from oracle.fan import FAN
+    g = load_golden("fan.npz")
+    fan = FAN().eval()
+    assert sorted(fan.state_dict().keys()) == list(g["state_names"])
+    fill_by_name(fan)
+    for tag, x in _inputs().items():
+        with torch.no_grad():
+            raw = fan(torch.nn.functional.interpolate(x, size=256, mode="bilinear") * 0.5 + 0.5)
+            hm = fan.get_heatmap_privacy(x)
+        assert rel_err(raw[:, ::7, ::4, ::4], g[f"{tag}_raw_sub"]) < 1e-4
+        assert rel_err(hm[0], g[f"{tag}_hm0"]) < 1e-4 and rel_err(hm[1], g[f"{tag}_hm1"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_fan_matches_reference_golden():
+    """bf16 activation storage through ~45 conv layers of eval-mode BN: tolerance 3e-2 of max on the raw 99-channel map
+    and on the clamped heat-maps (measured values printed)."""
+    from ppv_amd.fan import FAN
+    g = load_golden("fan.npz")
+    fan = FAN().eval()
+    assert sorted(fan.state_dict().keys()) == list(g["state_names"])
+    fill_by_name(fan)
+    fan = fan.cuda()
+    for tag, x in _inputs().items():
+        hm = fan.get_heatmap(x.cuda(), Privacy=True)
+        raw = fan.last_raw
+        e_raw = rel_err(raw[:, ::7, ::4, ::4], g[f"{tag}_raw_sub"])
+        e0, e1 = rel_err(hm[0], g[f"{tag}_hm0"]), rel_err(hm[1], g[f"{tag}_hm1"])
+        print(tag, f"raw {e_raw:.3e} hm0 {e0:.3e} hm1 {e1:.3e}")
+        assert hm[0].shape == g[f"{tag}_hm0"].shape and hm[0].dtype == torch.float32
+        assert e_raw < 3e-2 and e0 < 6e-2 and e1 < 6e-2

@@ -105,7 +105,7 @@ int ppv_stem_dgrad_scatter(const float* t, float* g, int B, int Ho, int Wo, ppv_
 int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, int C, ppv_stream_t stream);
 int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, long n, int C,
-               int res_mode, int relu, ppv_stream_t stream);
+               int res_mode, int relu, long res_mod, ppv_stream_t stream);
 int ppv_bn_bwd_blocks(long rows, int C);
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
@@ -132,6 +132,16 @@ int ppv_corr_volume(const float* f1, const float* f2, float* corr, int B, int C,
 int ppv_avgpool2(const float* in, float* out, long n, int H, int W, ppv_stream_t stream);
 int ppv_corr_lookup(const float* corr_l, const float* coords, float* out, int B, int H1, int W1, int Hl, int Wl, int r,
                     int level, int nlevels, ppv_stream_t stream);
+
+/* ---- FAN heat-map regressor forward, eval mode: Face-DeId/core/wing.py:178-260 (glue around ppv_conv_gemm) ------------- */
+int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, int W, ppv_stream_t stream);
+int ppv_fan_input(const float* x, const float* coords, float* out, int B, int Hin, int Win, int S, ppv_stream_t stream);
+int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, ppv_stream_t stream);
+int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, ppv_stream_t stream);
+int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* res, void* out, long M, int n1, int n2,
+                    int n3, int s1, int s2, int s3, ppv_stream_t stream);
+int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr,
+                 int nch, int split, int nsum, int up, ppv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,12 @@ PROTOTYPES = {
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
     "ppv_zernike_max_order": (_I, []),
+    "ppv_stem_conv6": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ppv_fan_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_avgpool2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ppv_upsample2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_concat3_add": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "ppv_fan_head": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_corr_volume": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_avgpool2": (_I, [_P, _P, _L, _I, _I, _P]),
     "ppv_corr_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -51,7 +57,7 @@ PROTOTYPES = {
     "ppv_stem_conv": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_stem_dgrad_scatter": (_I, [_P, _P, _I, _I, _I, _P]),
     "ppv_bn_finalize": (_I, [_P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
-    "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P]),
     "ppv_bn_bwd_blocks": (_I, [_L, _I]),
     "ppv_bn_bwd": (_I, [_P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_relu_maxpool": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -174,11 +174,12 @@ def bn_finalize(stat_part, count, gamma, beta, run_mean, run_var, momentum=0.1, 
     return coef
 
 
-def bn_act(x, coef, res=None, coef_res=None, relu=True):
+def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False):
+    """y = act(x*scale + shift + res); res_broadcast: res holds one image's worth of elements shared by the batch."""
     y = torch.empty_like(x)
     mode = 0 if res is None else (1 if coef_res is None else 2)
     check(L().ppv_bn_act(ptr(x), ptr(coef), ptr(res), ptr(coef_res), ptr(y), x.numel(), x.shape[-1], mode, int(relu),
-                         stream_ptr()), "ppv_bn_act")
+                         res.numel() if (res is not None and res_broadcast) else 0, stream_ptr()), "ppv_bn_act")
     return y
 
 

@@ -340,39 +340,42 @@ __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __rest
 }
 
 // ============================================================================= stem forward
-// torch [64][3][7][7] f32 -> [64][24 chunks][8] bf16, chunk = r*3 + c (21 used), element s (7 used)
+// torch [64][CIN][7][7] f32 -> [64][NCHP chunks][8] bf16, chunk = r*CIN + c (7*CIN used), element s (7 used)
+template <int CIN>
 __global__ __launch_bounds__(256) void stem_weight_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ o) {
+    constexpr int NCH = 7 * CIN, NCHP = (NCH + 7) / 8 * 8;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 64 * 192) return;
-    const int s = i & 7, ch = (i >> 3) % 24, n = i / 192;
+    if (i >= 64 * NCHP * 8) return;
+    const int s = i & 7, ch = (i >> 3) % NCHP, n = i / (NCHP * 8);
     float v = 0.f;
-    if (ch < 21 && s < 7) {
-        const int r = ch / 3, c = ch % 3;
-        v = w[((n * 3 + c) * 7 + r) * 7 + s];
+    if (ch < NCH && s < 7) {
+        const int r = ch / CIN, c = ch % CIN;
+        v = w[((n * CIN + c) * 7 + r) * 7 + s];
     }
     o[i] = f2bfw(v);
 }
 
-__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wst,
-                                                           bf16_t* __restrict__ out, float* __restrict__ stat_part, int B,
-                                                           int H, int W, int tiles, int stat_rows) {
-    constexpr int LDA = 384;                                   // bytes per A / W row (192 bf16)
-    __shared__ __attribute__((aligned(16))) char sA[128 * LDA];
-    __shared__ __attribute__((aligned(16))) char sW[64 * LDA];
-    __shared__ float sStat[2][2][64];
+template <int CIN>
+__global__ __launch_bounds__(256, CIN == 3 ? 2 : 1) void stem_conv_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wst,
+                                                                         bf16_t* __restrict__ out, float* __restrict__ stat_part,
+                                                                         int B, int H, int W, int tiles, int stat_rows) {
+    constexpr int NCH = 7 * CIN, NCHP = (NCH + 7) / 8 * 8, KS = NCHP / 4;
+    constexpr int LDA = NCHP * 16;                              // bytes per A / W row
+    extern __shared__ __attribute__((aligned(16))) char stem_smem[];
+    char* sA = stem_smem;
+    char* sW = stem_smem + 128 * LDA;
+    float (*sStat)[2][64] = reinterpret_cast<float (*)[2][64]>(stem_smem + 192 * LDA);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Ho = H / 2, Wo = W / 2;
     const long M = (long)B * Ho * Wo;
-    // weights: 64 rows x 24 chunks, swizzled chunk ^= row & 7
-    for (int idx = tid; idx < 64 * 24; idx += 256) {
-        const int n = idx / 24, ch = idx % 24;
-        *reinterpret_cast<uint4*>(sW + n * LDA + ((ch ^ (n & 7)) * 16)) = *reinterpret_cast<const uint4*>(wst + (n * 24 + ch) * 8);
+    for (int idx = tid; idx < 64 * NCHP; idx += 256) {
+        const int n = idx / NCHP, ch = idx % NCHP;
+        *reinterpret_cast<uint4*>(sW + n * LDA + ((ch ^ (n & 7)) * 16)) = *reinterpret_cast<const uint4*>(wst + (n * NCHP + ch) * 8);
     }
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const long m0 = (long)tile * 128;
         __syncthreads();
-        // ---- im2col: thread -> row (tid & 127), chunks (tid >> 7) + 2*j
         {
             const int row = tid & 127;
             const long m = m0 + row;
@@ -380,13 +383,13 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
             const long mm = okm ? m : 0;
             const int b = (int)(mm / ((long)Ho * Wo)), rem = (int)(mm % ((long)Ho * Wo));
             const int ho = rem / Wo, wo = rem % Wo;
-            for (int ch = (tid >> 7); ch < 24; ch += 2) {
+            for (int ch = (tid >> 7); ch < NCHP; ch += 2) {
                 unsigned wv[4] = {0, 0, 0, 0};
-                if (okm && ch < 21) {
-                    const int r = ch / 3, c = ch % 3;
+                if (okm && ch < NCH) {
+                    const int r = ch / CIN, c = ch % CIN;
                     const int hi = 2 * ho - 3 + r;
                     if (hi >= 0 && hi < H) {
-                        const float* src = img + (((long)b * 3 + c) * H + hi) * W;
+                        const float* src = img + (((long)b * CIN + c) * H + hi) * W;
                         float v[8];
 #pragma unroll
                         for (int s = 0; s < 8; ++s) {
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[mi][0] = acc[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 af[4], bfr[2];
             const int chunk = ((ks * 4 + fq) ^ (fr & 7)) * 16;
 #pragma unroll
@@ -419,7 +422,6 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
-        // ---- epilogue: bf16 rounding, BN partials, staged 16-byte stores (output row = 128 bytes)
         constexpr int LDO = 144;
         char* sO = sA;
 #pragma unroll
@@ -569,7 +571,8 @@ int ppv_wgrad_set_variant(int v) { g_wgrad_variant = v; return PPV_OK; }
 // mode 0: forward layout [64][24][8] bf16; mode 1: data-gradient layout [16][4][4][64] bf16
 int ppv_stem_weight_layout(const float* w, void* out, int mode, hipStream_t stream) {
     if (!w || !out) return PPV_ERR_NULL;
-    if (mode == 0) stem_weight_layout_kernel<<<(64 * 192 + 255) / 256, 256, 0, stream>>>(w, (bf16_t*)out);
+    if (mode == 0) stem_weight_layout_kernel<3><<<(64 * 192 + 255) / 256, 256, 0, stream>>>(w, (bf16_t*)out);
+    else if (mode == 2) stem_weight_layout_kernel<6><<<(64 * 384 + 255) / 256, 256, 0, stream>>>(w, (bf16_t*)out);   // [64][6][7][7] -> [64][48][8]
     else stem_dgrad_weight_kernel<<<(16 * 16 * 64 + 255) / 256, 256, 0, stream>>>(w, (bf16_t*)out);
     return ppv_last_error();
 }
@@ -582,7 +585,25 @@ int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part
     const long M = (long)B * (H / 2) * (W / 2);
     const int tiles = (int)((M + 127) / 128);
     const int grid = tiles < 1024 ? tiles : 1024;
-    stem_conv_kernel<<<grid, 256, 0, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles, stat_rows < 1 ? 1 : stat_rows);
+    constexpr int lds3 = 192 * 24 * 16 + 1024;
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3); attr3 = true; }
+    stem_conv_kernel<3><<<grid, 256, lds3, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles, stat_rows < 1 ? 1 : stat_rows);
+    return ppv_last_error();
+}
+
+// FAN CoordConv stem (Face-DeId/core/wing.py:184-186): img [B,6,H,W] f32 NCHW (3 image + 3 coordinate channels),
+// wst from ppv_stem_weight_layout(mode 2) -> raw [B,H/2,W/2,64] bf16 (bias is folded into the following BatchNorm)
+int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, int W, hipStream_t stream) {
+    if (!img || !wst || !out) return PPV_ERR_NULL;
+    if (H % 2 || W % 2) return PPV_ERR_BAD_SIZE;
+    const long M = (long)B * (H / 2) * (W / 2);
+    const int tiles = (int)((M + 127) / 128);
+    const int grid = tiles < 512 ? tiles : 512;
+    constexpr int lds6 = 192 * 48 * 16 + 1024;
+    static bool attr6 = false;
+    if (!attr6) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6); attr6 = true; }
+    stem_conv_kernel<6><<<grid, 256, lds6, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, nullptr, B, H, W, tiles, 1);
     return ppv_last_error();
 }
 

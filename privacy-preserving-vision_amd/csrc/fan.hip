@@ -1,0 +1,194 @@
+// Element-wise / resampling kernels of the FAN heat-map regressor forward (eval mode), NHWC bf16, gfx950.
+//
+// Replaces, around the MFMA convolutions of conv_gemm.hip / the 6-channel stem of conv_wgrad_stem.hip, the glue of
+// reference Face-DeId/core/wing.py:178-260: bilinear input resize + x*0.5+0.5 + CoordConv channels (:241-244,:78-118),
+// avg_pool2d 2x2 (:64,:213), nearest x2 up-sampling + add (:73-75), the channel concatenation + residual of ConvBlock
+// (:171-175), and the heat-map head: per-group channel sums, bilinear x4 (align_corners=True), clamp (:246-251).
+#include <hip/hip_runtime.h>
+#include "ppv_common.h"
+
+namespace ppv {
+
+typedef unsigned short bf16_t;
+__device__ __forceinline__ bf16_t f2bf_f(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ void load8f(const bf16_t* p, float (&f)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store8f(bf16_t* p, const float (&f)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf_f(f[2 * i]) | ((unsigned)f2bf_f(f[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// out [B,6,S,S] f32: channels 0..2 = bilinear(x [B,3,Hin,Win], align_corners=False) * 0.5 + 0.5, 3..5 = coords [3,S,S]
+__global__ __launch_bounds__(256) void fan_input_kernel(const float* __restrict__ x, const float* __restrict__ coords,
+                                                        float* __restrict__ out, int B, int Hin, int Win, int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)B * 6 * S * S;
+    if (i >= tot) return;
+    const int w = (int)(i % S), h = (int)((i / S) % S), c = (int)((i / ((long)S * S)) % 6), b = (int)(i / ((long)S * S * 6));
+    if (c >= 3) { out[i] = coords[((long)(c - 3) * S + h) * S + w]; return; }
+    const float sh = (float)Hin / (float)S, sw = (float)Win / (float)S;
+    const float fy = fmaxf(((float)h + 0.5f) * sh - 0.5f, 0.f), fx = fmaxf(((float)w + 0.5f) * sw - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = x + ((long)b * 3 + c) * Hin * Win;
+    const float v = (1.f - ly) * ((1.f - lx) * p[(long)y0 * Win + x0] + lx * p[(long)y0 * Win + x1]) +
+                    ly * ((1.f - lx) * p[(long)y1 * Win + x0] + lx * p[(long)y1 * Win + x1]);
+    out[i] = v * 0.5f + 0.5f;
+}
+
+// [B,H,W,C] bf16 -> [B,H/2,W/2,C] bf16
+__global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W,
+                                                            int C) {
+    const int Ho = H / 2, Wo = W / 2, c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * Ho * Wo * c8n) return;
+    const int c0 = (int)(i % c8n) * 8, wo = (int)((i / c8n) % Wo), ho = (int)((i / ((long)c8n * Wo)) % Ho);
+    const int b = (int)(i / ((long)c8n * Wo * Ho));
+    float a[8], acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            load8f(x + (((long)b * H + 2 * ho + dy) * W + 2 * wo + dx) * C + c0, a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += a[k];
+        }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= 0.25f;
+    store8f(y + i * 8, acc);
+}
+
+// out [B,H,W,C] = up1 + nearest_x2(low [B,H/2,W/2,C])
+__global__ __launch_bounds__(256) void upsample2_add_kernel(const bf16_t* __restrict__ up1, const bf16_t* __restrict__ low,
+                                                            bf16_t* __restrict__ out, int B, int H, int W, int C) {
+    const int c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H * W * c8n) return;
+    const int c0 = (int)(i % c8n) * 8, w = (int)((i / c8n) % W), h = (int)((i / ((long)c8n * W)) % H);
+    const int b = (int)(i / ((long)c8n * W * H));
+    float a[8], l[8];
+    load8f(up1 + i * 8, a);
+    load8f(low + (((long)b * (H / 2) + h / 2) * (W / 2) + w / 2) * C + c0, l);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += l[k];
+    store8f(out + i * 8, a);
+}
+
+// out [M][n1+n2+n3] = cat(o1[M][:n1] (stride s1), o2[M][:n2] (stride s2), o3[M][:n3] (stride s3)) + res [M][n1+n2+n3]
+__global__ __launch_bounds__(256) void concat3_add_kernel(const bf16_t* __restrict__ o1, const bf16_t* __restrict__ o2,
+                                                          const bf16_t* __restrict__ o3, const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ out, long M, int n1, int n2, int n3, int s1,
+                                                          int s2, int s3) {
+    const int C = n1 + n2 + n3, c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * c8n) return;
+    const int c0 = (int)(i % c8n) * 8;
+    const long m = i / c8n;
+    const bf16_t* src = (c0 < n1) ? o1 + m * s1 + c0 : (c0 < n1 + n2) ? o2 + m * s2 + (c0 - n1) : o3 + m * s3 + (c0 - n1 - n2);
+    float a[8], r[8];
+    load8f(src, a);
+    load8f(res + i * 8, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += r[k];
+    store8f(out + i * 8, a);
+}
+
+// l0 raw [M][ldr] f32 accumulators (+ bias [nch]) -> raw_out [B][nch][HW] f32 (optional) and sums [B][2][HW] f32 over channels
+// [0, split) and [split, nsum)
+__global__ __launch_bounds__(256) void fan_head_sum_kernel(const float* __restrict__ raw, const float* __restrict__ bias,
+                                                           float* __restrict__ raw_out, float* __restrict__ sums, long M, int HW,
+                                                           int ldr, int nch, int split, int nsum) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const long b = m / HW, px = m % HW;
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < nch; ++c) {
+        const float v = raw[m * ldr + c] + bias[c];
+        if (raw_out) raw_out[(b * nch + c) * HW + px] = v;
+        if (c < split) s0 += v;
+        else if (c < nsum) s1 += v;
+    }
+    sums[(b * 2 + 0) * HW + px] = s0;
+    sums[(b * 2 + 1) * HW + px] = s1;
+}
+
+// in [n][S][S] f32 -> out [n][S*f][S*f] f32, bilinear align_corners=True, clamp [0,1]
+__global__ __launch_bounds__(256) void bilinear_up_clamp_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int S,
+                                                                int f) {
+    const int So = S * f;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * So * So) return;
+    const int w = (int)(i % So), h = (int)((i / So) % So);
+    const long m = i / ((long)So * So);
+    const float sc = (float)(S - 1) / (float)(So - 1);
+    const float fy = (float)h * sc, fx = (float)w * sc;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, S - 1), x1 = min(x0 + 1, S - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = in + m * S * S;
+    const float v = (1.f - ly) * ((1.f - lx) * p[y0 * S + x0] + lx * p[y0 * S + x1]) + ly * ((1.f - lx) * p[y1 * S + x0] + lx * p[y1 * S + x1]);
+    out[i] = fminf(fmaxf(v, 0.f), 1.f);
+}
+
+}  // namespace ppv
+
+using namespace ppv;
+
+extern "C" {
+
+int ppv_fan_input(const float* x, const float* coords, float* out, int B, int Hin, int Win, int S, hipStream_t stream) {
+    if (!x || !coords || !out) return PPV_ERR_NULL;
+    const long tot = (long)B * 6 * S * S;
+    fan_input_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, coords, out, B, Hin, Win, S);
+    return ppv_last_error();
+}
+
+int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, hipStream_t stream) {
+    if (!x || !y) return PPV_ERR_NULL;
+    if (H % 2 || W % 2 || C % 8) return PPV_ERR_BAD_SIZE;
+    const long tot = (long)B * (H / 2) * (W / 2) * (C / 8);
+    avgpool2_nhwc_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    return ppv_last_error();
+}
+
+int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, hipStream_t stream) {
+    if (!up1 || !low || !out) return PPV_ERR_NULL;
+    if (H % 2 || W % 2 || C % 8) return PPV_ERR_BAD_SIZE;
+    const long tot = (long)B * H * W * (C / 8);
+    upsample2_add_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)up1, (const bf16_t*)low, (bf16_t*)out, B, H, W, C);
+    return ppv_last_error();
+}
+
+int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* res, void* out, long M, int n1, int n2, int n3,
+                    int s1, int s2, int s3, hipStream_t stream) {
+    if (!o1 || !o2 || !o3 || !res || !out) return PPV_ERR_NULL;
+    if (n1 % 8 || n2 % 8 || n3 % 8) return PPV_ERR_BAD_SIZE;
+    const long tot = M * ((n1 + n2 + n3) / 8);
+    concat3_add_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)o1, (const bf16_t*)o2, (const bf16_t*)o3,
+                                                                         (const bf16_t*)res, (bf16_t*)out, M, n1, n2, n3, s1, s2, s3);
+    return ppv_last_error();
+}
+
+int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr, int nch,
+                 int split, int nsum, int up, hipStream_t stream) {
+    if (!raw || !bias || !sums || !heat) return PPV_ERR_NULL;
+    const long M = (long)B * S * S;
+    fan_head_sum_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>((const float*)raw, bias, raw_out, sums, M, S * S, ldr, nch, split, nsum);
+    const long tot = (long)B * 2 * S * up * S * up;
+    bilinear_up_clamp_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(sums, heat, (long)B * 2, S, up);
+    return ppv_last_error();
+}
+
+}  // extern "C"

@@ -71,13 +71,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 template <int RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ x, const float* __restrict__ coef1,
                                                      const bf16_t* __restrict__ r, const float* __restrict__ coef2,
-                                                     bf16_t* __restrict__ y, long n8, int C) {
+                                                     bf16_t* __restrict__ y, long n8, int C, long res_mod8) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const int c0 = (int)((i * 8) % C);
     float xv[8], rv[8], o[8];
     load8(x + i * 8, xv);
-    if (RES) load8(r + i * 8, rv);
+    if (RES) load8(r + (res_mod8 ? i % res_mod8 : i) * 8, rv);      // res_mod8 > 0: residual broadcast over the batch
     const float4 sa = *reinterpret_cast<const float4*>(coef1 + c0), sb = *reinterpret_cast<const float4*>(coef1 + c0 + 4);
     const float4 ta = *reinterpret_cast<const float4*>(coef1 + C + c0), tb = *reinterpret_cast<const float4*>(coef1 + C + c0 + 4);
     const float s1[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
@@ -339,21 +339,22 @@ int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, 
     return ppv_last_error();
 }
 
-// y = act(x*s1+t1 + res);  res_mode 0 none, 1 identity r, 2 r*s2+t2 (coef2)
+// y = act(x*s1+t1 + res);  res_mode 0 none, 1 identity r, 2 r*s2+t2 (coef2); res_mod > 0: r holds res_mod elements and
+// is broadcast (index modulo), e.g. a per-pixel constant map shared by the batch
 int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, long n, int C, int res_mode,
-               int relu, hipStream_t stream) {
+               int relu, long res_mod, hipStream_t stream) {
     if (!x || !coef1 || !y || (res_mode && !r) || (res_mode == 2 && !coef2)) return PPV_ERR_NULL;
     if (C % 8 || n % 8) return PPV_ERR_BAD_SIZE;
     const long n8 = n / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
     const bf16_t *xx = (const bf16_t*)x, *rr = (const bf16_t*)r;
     bf16_t* yy = (bf16_t*)y;
-    if (res_mode == 0 && relu) bn_act_kernel<0, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
-    else if (res_mode == 0) bn_act_kernel<0, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
-    else if (res_mode == 1 && relu) bn_act_kernel<1, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
-    else if (res_mode == 1) bn_act_kernel<1, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
-    else if (relu) bn_act_kernel<2, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
-    else bn_act_kernel<2, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C);
+    if (res_mode == 0 && relu) bn_act_kernel<0, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
+    else if (res_mode == 0) bn_act_kernel<0, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
+    else if (res_mode == 1 && relu) bn_act_kernel<1, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
+    else if (res_mode == 1) bn_act_kernel<1, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
+    else if (relu) bn_act_kernel<2, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
+    else bn_act_kernel<2, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
     return ppv_last_error();
 }
 

@@ -1,0 +1,265 @@
+"""Drop-in for reference ``Face-DeId/core/wing.py:178 FAN`` (forward / ``get_heatmap``, eval mode) on MI355X.
+
+Same module tree and ``state_dict`` names (``conv1.conv.weight``, ``conv2.bn1.*``, ``m0.b1_4.conv1.weight``,
+``top_m_0.*``, ``conv_last0.*``, ``bn_end0.*``, ``l0.*``) so the reference's pretrained ``wing.ckpt`` loads unchanged
+(``load_pretrained_weights``).  The ``torch.nn`` sub-modules are PARAMETER HOLDERS; ``forward`` runs the whole network
+through libppv_hip.so on NHWC bfloat16 activations (fp32 accumulation): the 6-channel CoordConv stem, every 3x3 / 1x1
+convolution on MFMA, eval-mode BatchNorm + ReLU as a pre-activation pass, pooling / up-sampling / concatenation and the
+heat-map head as fused element-wise kernels.  The reference only ever calls it under ``no_grad`` at 256 x 256
+(``get_heatmap`` is decorated, wing.py:240); no autograd graph is attached.
+"""
+from functools import partial
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from . import convops as co
+from ._lib import check, ptr, stream_ptr
+
+
+def _coord_channels(h, w):
+    xx = (torch.arange(h).unsqueeze(1).expand(h, w).float() / (h - 1)) * 2 - 1          # wing.py:86-90
+    yy = (torch.arange(w).unsqueeze(0).expand(h, w).float() / (w - 1)) * 2 - 1
+    rr = torch.sqrt(xx ** 2 + yy ** 2)
+    return torch.stack([xx, yy, rr / rr.max()], 0)                                      # [3,h,w]
+
+
+class AddCoordsTh(nn.Module):
+    def __init__(self, height=64, width=64, with_r=False, with_boundary=False):
+        super().__init__()
+        self.with_r, self.with_boundary = with_r, with_boundary
+
+
+class CoordConvTh(nn.Module):
+    def __init__(self, height, width, with_r, with_boundary, in_channels, first_one=False, *args, **kwargs):
+        super().__init__()
+        self.addcoords = AddCoordsTh(height, width, with_r, with_boundary)
+        in_channels += 2 + (1 if with_r else 0) + (2 if (with_boundary and not first_one) else 0)
+        self.conv = nn.Conv2d(in_channels=in_channels, *args, **kwargs)
+        self.hw = (height, width)
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_planes, out_planes):
+        super().__init__()
+        conv3x3 = partial(nn.Conv2d, kernel_size=3, stride=1, padding=1, bias=False, dilation=1)
+        self.bn1 = nn.BatchNorm2d(in_planes)
+        self.conv1 = conv3x3(in_planes, out_planes // 2)
+        self.bn2 = nn.BatchNorm2d(out_planes // 2)
+        self.conv2 = conv3x3(out_planes // 2, out_planes // 4)
+        self.bn3 = nn.BatchNorm2d(out_planes // 4)
+        self.conv3 = conv3x3(out_planes // 4, out_planes // 4)
+        self.downsample = None
+        if in_planes != out_planes:
+            self.downsample = nn.Sequential(nn.BatchNorm2d(in_planes), nn.ReLU(True), nn.Conv2d(in_planes, out_planes, 1, 1, bias=False))
+
+
+class HourGlass(nn.Module):
+    def __init__(self, num_modules, depth, num_features, first_one=False):
+        super().__init__()
+        self.num_modules, self.depth, self.features = num_modules, depth, num_features
+        self.coordconv = CoordConvTh(64, 64, True, True, 256, first_one, out_channels=256, kernel_size=1, stride=1, padding=0)
+        self._generate_network(depth)
+
+    def _generate_network(self, level):
+        self.add_module('b1_' + str(level), ConvBlock(256, 256))
+        self.add_module('b2_' + str(level), ConvBlock(256, 256))
+        if level > 1:
+            self._generate_network(level - 1)
+        else:
+            self.add_module('b2_plus_' + str(level), ConvBlock(256, 256))
+        self.add_module('b3_' + str(level), ConvBlock(256, 256))
+
+
+def _pad_to(t, shape):
+    out = torch.zeros(shape, dtype=t.dtype, device=t.device)
+    out[tuple(slice(0, s) for s in t.shape)] = t
+    return out
+
+
+def _bn_coef(bn, pad_to=None, extra_shift=None):
+    """eval-mode BatchNorm as (scale, shift) [4,C] (rows 2,3 unused); optional conv bias folded in, optional zero padding."""
+    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    if extra_shift is not None:
+        shift = shift + extra_shift * scale
+    c = torch.stack([scale, shift, scale, scale]).float()
+    if pad_to is not None and pad_to > c.shape[1]:
+        c = _pad_to(c, (4, pad_to))
+    return c.contiguous()
+
+
+class FAN(nn.Module):
+    def __init__(self, num_modules=1, end_relu=False, num_landmarks=98, fname_pretrained=None):
+        super().__init__()
+        self.num_modules, self.end_relu = num_modules, end_relu
+        self.conv1 = CoordConvTh(256, 256, True, False, in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv2 = ConvBlock(64, 128)
+        self.conv3 = ConvBlock(128, 128)
+        self.conv4 = ConvBlock(128, 256)
+        self.add_module('m0', HourGlass(1, 4, 256, first_one=True))
+        self.add_module('top_m_0', ConvBlock(256, 256))
+        self.add_module('conv_last0', nn.Conv2d(256, 256, 1, 1, 0))
+        self.add_module('bn_end0', nn.BatchNorm2d(256))
+        self.add_module('l0', nn.Conv2d(256, num_landmarks + 1, 1, 1, 0))
+        self._cache = None
+        self.last_raw = None
+        if fname_pretrained is not None:
+            self.load_pretrained_weights(fname_pretrained)
+
+    def load_pretrained_weights(self, fname):
+        checkpoint = torch.load(fname, map_location="cpu")
+        model_weights = self.state_dict()
+        model_weights.update({k: v for k, v in checkpoint['state_dict'].items() if k in model_weights})
+        self.load_state_dict(model_weights)
+        self._cache = None
+
+    # ------------------------------------------------------------------ cached kernel-side constants (frozen, eval)
+    def _block_consts(self, blk):
+        n1, n2, n3 = blk.conv1.out_channels, blk.conv2.out_channels, blk.conv3.out_channels
+        p2, p3 = max(n2, 64), max(n3, 64)
+        c = {"n": (n1, n2, n3), "p": (p2, p3),
+             "bn1": _bn_coef(blk.bn1), "bn2": _bn_coef(blk.bn2), "bn3": _bn_coef(blk.bn3, pad_to=p2),
+             "w1": co.weight_layout(blk.conv1.weight.detach().float(), 0),
+             "w2": co.weight_layout(_pad_to(blk.conv2.weight.detach().float(), (p2, n1, 3, 3)), 0),
+             "w3": co.weight_layout(_pad_to(blk.conv3.weight.detach().float(), (p3, p2, 3, 3)), 0)}
+        if blk.downsample is not None:
+            c["bnd"] = _bn_coef(blk.downsample[0])
+            c["wd"] = co.weight_layout(blk.downsample[2].weight.detach().float(), 0)
+        return c
+
+    def _build_cache(self, dev):
+        L = _lib.lib()
+        cache = {"dev": dev}
+        w1 = self.conv1.conv.weight.detach().float().contiguous()                     # [64,6,7,7]
+        wst = torch.empty((64, 48, 8), dtype=torch.bfloat16, device=dev)
+        check(L.ppv_stem_weight_layout(ptr(w1), ptr(wst), 2, stream_ptr()), "ppv_stem_weight_layout")
+        cache["stem_w"] = wst
+        cache["stem_bn"] = _bn_coef(self.bn1, extra_shift=self.conv1.conv.bias.detach())
+        cache["coords256"] = _coord_channels(256, 256).to(dev).contiguous()
+        for name in ("conv2", "conv3", "conv4", "top_m_0"):
+            cache[name] = self._block_consts(getattr(self, name))
+        for name, m in self.m0.named_children():
+            if isinstance(m, ConvBlock):
+                cache["m0." + name] = self._block_consts(m)
+        # hourglass CoordConv 1x1 (259 -> 256): conv over the 256 feature channels on MFMA + a per-pixel constant map
+        # (the three coordinate channels are input independent) + bias, added by one broadcast element-wise pass
+        wc = self.m0.coordconv.conv.weight.detach().float()                            # [256,259,1,1]
+        cache["cc_w"] = co.weight_layout(wc[:, :256].contiguous(), 0)
+        cmap = torch.einsum("oc,chw->hwo", wc[:, 256:, 0, 0], _coord_channels(64, 64).to(dev))
+        cache["cc_map"] = cmap.to(torch.bfloat16).contiguous()                        # [64,64,256]
+        one = torch.ones(256, device=dev)
+        cache["coords64_tail"] = _coord_channels(64, 64)[1:].to(dev).contiguous()
+        cache["cc_coef"] = torch.stack([one, self.m0.coordconv.conv.bias.detach().float(), one, one]).contiguous()
+        cache["last_w"] = co.weight_layout(self.conv_last0.weight.detach().float(), 0)
+        cache["end_bn"] = _bn_coef(self.bn_end0, extra_shift=self.conv_last0.bias.detach())
+        nl = self.l0.out_channels
+        cache["l0_w"] = co.weight_layout(_pad_to(self.l0.weight.detach().float(), (128, 256, 1, 1)), 0)
+        cache["l0_b"] = self.l0.bias.detach().float().contiguous()
+        cache["nl"] = nl
+        return cache
+
+    def refresh(self):
+        """Call after changing parameters in place (the kernel-side constants are cached)."""
+        self._cache = None
+
+    # ------------------------------------------------------------------ forward pieces
+    def _convblock(self, x, c):
+        n1, n2, n3 = c["n"]
+        p2, p3 = c["p"]
+        o1 = co.conv_fwd(co.bn_act(x, c["bn1"]), c["w1"], 1, 1)
+        o2 = co.conv_fwd(co.bn_act(o1, c["bn2"]), c["w2"], 1, 1)
+        o3 = co.conv_fwd(co.bn_act(o2, c["bn3"]), c["w3"], 1, 1)
+        res = x if "wd" not in c else co.conv_fwd(co.bn_act(x, c["bnd"]), c["wd"], 1, 0)
+        B, H, W, _ = x.shape
+        out = torch.empty((B, H, W, n1 + n2 + n3), dtype=torch.bfloat16, device=x.device)
+        check(_lib.lib().ppv_concat3_add(ptr(o1), ptr(o2), ptr(o3), ptr(res), ptr(out), B * H * W, n1, n2, n3, n1, p2, p3,
+                                         stream_ptr()), "ppv_concat3_add")
+        return out
+
+    def _avgpool(self, x):
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // 2, W // 2, C), dtype=torch.bfloat16, device=x.device)
+        check(_lib.lib().ppv_avgpool2_nhwc(ptr(x), ptr(y), B, H, W, C, stream_ptr()), "ppv_avgpool2_nhwc")
+        return y
+
+    def _hourglass(self, level, x, cache):
+        up1 = self._convblock(x, cache[f"m0.b1_{level}"])
+        low = self._convblock(self._avgpool(x), cache[f"m0.b2_{level}"])
+        low = self._hourglass(level - 1, low, cache) if level > 1 else self._convblock(low, cache["m0.b2_plus_1"])
+        low = self._convblock(low, cache[f"m0.b3_{level}"])
+        B, H, W, C = up1.shape
+        out = torch.empty_like(up1)
+        check(_lib.lib().ppv_upsample2_add(ptr(up1), ptr(low), ptr(out), B, H, W, C, stream_ptr()), "ppv_upsample2_add")
+        return out
+
+    def _trunk(self, x6):
+        """x6 [B,6,256,256] f32 NCHW (image*0.5+0.5 and the three coordinate channels) -> l0 raw [B,64,64,128] f32."""
+        cache = self._cache
+        L = _lib.lib()
+        B = x6.shape[0]
+        raw0 = torch.empty((B, 128, 128, 64), dtype=torch.bfloat16, device=x6.device)
+        check(L.ppv_stem_conv6(ptr(x6), ptr(cache["stem_w"]), ptr(raw0), B, 256, 256, stream_ptr()), "ppv_stem_conv6")
+        x = co.bn_act(raw0, cache["stem_bn"])
+        x = self._avgpool(self._convblock(x, cache["conv2"]))
+        x = self._convblock(self._convblock(x, cache["conv3"]), cache["conv4"])
+        h = co.conv_fwd(x, cache["cc_w"], 1, 0)
+        h = co.bn_act(h, cache["cc_coef"], res=cache["cc_map"], relu=False, res_broadcast=True)
+        ll = self._convblock(self._hourglass(4, h, cache), cache["top_m_0"])
+        ll = co.bn_act(co.conv_fwd(ll, cache["last_w"], 1, 0), cache["end_bn"])
+        return co.conv_fwd(ll, cache["l0_w"], 1, 0, out_f32=True)       # head logits stay in fp32 (49-channel sums follow)
+
+    def _prepare(self, x):
+        if self.training:
+            raise NotImplementedError("ppv_amd FAN implements the eval-mode forward the reference uses (model.py:298-306)")
+        if not x.is_cuda:
+            raise RuntimeError("ppv_amd FAN runs on an MI355X (input must be a cuda tensor); no CPU path")
+        if self._cache is None or self._cache["dev"] != x.device:
+            self._cache = self._build_cache(x.device)
+
+    @torch.no_grad()
+    def get_heatmap(self, x, b_preprocess=True, Privacy=False, delimiter=False):
+        """wing.py:240-260.  Only the ``Privacy=True`` branch (solver.py:147) runs on the device; the other branches
+        post-process landmarks on the host with OpenCV (``preprocess``, wing.py:440-578: out of scope)."""
+        if not (b_preprocess and Privacy):
+            raise NotImplementedError("host-side landmark post-processing (wing.py preprocess) is out of scope")
+        self._prepare(x)
+        L = _lib.lib()
+        x = x.detach().float().contiguous()
+        B, _, Hin, Win = x.shape
+        x6 = torch.empty((B, 6, 256, 256), dtype=torch.float32, device=x.device)
+        check(L.ppv_fan_input(ptr(x), ptr(self._cache["coords256"]), ptr(x6), B, Hin, Win, 256, stream_ptr()), "ppv_fan_input")
+        raw = self._trunk(x6)
+        nl = self._cache["nl"]
+        self.last_raw = torch.empty((B, nl, 64, 64), dtype=torch.float32, device=x.device)
+        sums = torch.empty((B, 2, 64, 64), dtype=torch.float32, device=x.device)
+        heat = torch.empty((B, 2, 256, 256), dtype=torch.float32, device=x.device)
+        check(L.ppv_fan_head(ptr(raw), ptr(self._cache["l0_b"]), ptr(self.last_raw), ptr(sums), ptr(heat), B, 64, 128, nl, 49,
+                             nl - 1, 4, stream_ptr()), "ppv_fan_head")
+        return [heat[:, 0:1].clamp_(0, 1), heat[:, 1:2].clamp_(0, 1)]
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x [B,3,256,256] in [0,1] -> ([heat-map logits [B,99,64,64] f32], [boundary channel])  (wing.py:212-238)."""
+        self._prepare(x)
+        L = _lib.lib()
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        if x.shape[-1] != 256 or x.shape[-2] != 256:
+            raise RuntimeError("FAN's CoordConv is built for 256 x 256 inputs (wing.py:184)")
+        coords = self._cache["coords256"].unsqueeze(0).expand(B, -1, -1, -1)
+        x6 = torch.cat([x, coords], 1).contiguous()
+        raw = self._trunk(x6)
+        nl = self._cache["nl"]
+        out = torch.empty((B, nl, 64, 64), dtype=torch.float32, device=x.device)
+        sums = torch.empty((B, 2, 64, 64), dtype=torch.float32, device=x.device)
+        heat = torch.empty((B, 2, 256, 256), dtype=torch.float32, device=x.device)
+        check(L.ppv_fan_head(ptr(raw), ptr(self._cache["l0_b"]), ptr(out), ptr(sums), ptr(heat), B, 64, 128, nl, 49, nl - 1, 4,
+                             stream_ptr()), "ppv_fan_head")
+        if self.end_relu:
+            out = F.relu(out)
+        boundary = self._cache["coords64_tail"].unsqueeze(0).expand(B, -1, -1, -1)      # last two CoordConv input channels
+        return [out], [boundary]

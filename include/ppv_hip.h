@@ -143,6 +143,19 @@ int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* 
 int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr,
                  int nch, int split, int nsum, int up, ppv_stream_t stream);
 
+/* backward of the FD camera: sensor image -> PSF (Optics.py:126-128), PSF + losses -> height map (Optics.py:92-120),
+ * height map -> Zernike coefficients (Optics.py:79-83) */
+size_t ppv_fftconv_fd_bwd_workspace_bytes(int B, int C, int N);
+int ppv_fftconv_fd_bwd(const float* img, const float* g_sensor, const float* sensor, const float* maxv, float* g_psf,
+                       void* workspace, int B, int C, int N, ppv_stream_t stream);
+size_t ppv_fd_psf_bwd_workspace_bytes(int N);
+int ppv_fd_psf_bwd(const float* g_psf, const double* g_lr, const double* g_cl, const float* psf, const void* base,
+                   const void* chirp1, const void* chirp2T, const void* chirp3, const float* rho, const float* kf,
+                   float lratio, float amp, const float* h, const double* acc, float* gh, void* workspace,
+                   void* workspace2, int N, ppv_stream_t stream);
+size_t ppv_zernike_grad_scratch_bytes(int K, long npx);
+int ppv_zernike_grad(const float* Z, const float* gh, float* g_coeffs, void* part, int K, long npx, ppv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

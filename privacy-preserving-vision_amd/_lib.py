@@ -33,6 +33,12 @@ PROTOTYPES = {
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
     "ppv_zernike_max_order": (_I, []),
+    "ppv_fftconv_fd_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
+    "ppv_fftconv_fd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ppv_fd_psf_bwd_workspace_bytes": (_Z, [_I]),
+    "ppv_fd_psf_bwd": (_I, [_P] * 10 + [_F, _F, _P, _P, _P, _P, _P, _I, _P]),
+    "ppv_zernike_grad_scratch_bytes": (_Z, [_I, _L]),
+    "ppv_zernike_grad": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "ppv_stem_conv6": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_fan_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_avgpool2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -6,8 +6,9 @@ input-independent chirps / apertures of ``get_psf`` are built once on the host w
 formulas (Optics.py:13-55,94-107) and kept resident; per call the height map, the 3-D FFT Fresnel step, the PSF,
 both losses, the circular FFT convolution and the per-image amax normalisation run in libppv_hip.so.
 
-Gap this round: no autograd graph is attached (the reference's only caller, ``solver.py:144``, detaches the result;
-``self.camera.eval()`` at ``solver.py:114``); the gradient w.r.t. ``Zer_train`` is a later row.
+Autograd: ``img_sensor``, ``loss_rad`` and ``centering_loss`` carry a graph to ``Zer_train`` (hand-written adjoint
+kernels: sensor -> PSF correlation, PSF/losses -> height map through the adjoint 3-D FFT chain, height map -> Zernike
+coefficients).  The gradient w.r.t. the input image is not provided (the reference's caller detaches, ``solver.py:144``).
 """
 import numpy as np
 import torch
@@ -31,8 +32,80 @@ def _cexp(ph):
     return torch.complex(torch.cos(ph), torch.sin(ph))
 
 
+class _FdPsfFn(torch.autograd.Function):
+    """coeffs [K,1,1] -> (psf [1,3,N,N] f32, loss_rad f32 0-d, centering_loss f32 0-d)   (Optics.py:92-120,124-125)"""
+
+    @staticmethod
+    def forward(ctx, coeffs, cam):
+        L = _lib.lib()
+        N = cam.N
+        c = coeffs.detach().reshape(-1).contiguous()
+        h = torch.empty((N, N), dtype=torch.float32, device=cam.device)
+        check(L.ppv_zernike_contract(ptr(cam.zernike_volume), ptr(c), ptr(h), c.numel(), h.numel(), stream_ptr()), "ppv_zernike_contract")
+        psf = torch.empty((1, 3, N, N), dtype=torch.float32, device=cam.device)
+        acc = torch.empty(4, dtype=torch.float64, device=cam.device)
+        cam._state_token += 1
+        check(L.ppv_fd_psf_fwd(ptr(h), ptr(cam._base), ptr(cam._chirp1), ptr(cam._chirp2T), ptr(cam._chirp3), ptr(cam._rho),
+                               cam._kf_p, cam._lratio, cam._amp, ptr(psf), ptr(acc), ptr(cam._ws), N, stream_ptr()), "ppv_fd_psf_fwd")
+        ctx.cam, ctx.token = cam, cam._state_token
+        ctx.save_for_backward(psf, h, acc)
+        ctx.set_materialize_grads(False)
+        return psf, torch.sqrt(acc[0]).to(torch.float32), ((acc[1] + acc[2]) / (3.0 * N * N)).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g_psf, g_lr, g_cl):
+        cam = ctx.cam
+        if ctx.token != cam._state_token:
+            raise RuntimeError("Camera: forward() ran again before backward(); the saved optical state was overwritten")
+        psf, h, acc = ctx.saved_tensors
+        L = _lib.lib()
+        N, K = cam.N, cam.zernike_volume.shape[0]
+        dev = cam.device
+        gp = g_psf.contiguous().float() if g_psf is not None else None
+        glr = g_lr.to(torch.float64).contiguous() if g_lr is not None else None
+        gcl = g_cl.to(torch.float64).contiguous() if g_cl is not None else None
+        gh = torch.empty(N * N, dtype=torch.float32, device=dev)
+        ws2 = torch.empty(L.ppv_fd_psf_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
+        check(L.ppv_fd_psf_bwd(ptr(gp), ptr(glr), ptr(gcl), ptr(psf), ptr(cam._base), ptr(cam._chirp1), ptr(cam._chirp2T),
+                               ptr(cam._chirp3), ptr(cam._rho), cam._kf_p, cam._lratio, cam._amp, ptr(h), ptr(acc), ptr(gh),
+                               ptr(cam._ws), ptr(ws2), N, stream_ptr()), "ppv_fd_psf_bwd")
+        gc = torch.empty(K, dtype=torch.float32, device=dev)
+        part = torch.empty(L.ppv_zernike_grad_scratch_bytes(K, N * N), dtype=torch.uint8, device=dev)
+        check(L.ppv_zernike_grad(ptr(cam.zernike_volume), ptr(gh), ptr(gc), ptr(part), K, N * N, stream_ptr()), "ppv_zernike_grad")
+        return gc.reshape(K, 1, 1), None
+
+
+class _FdSensorFn(torch.autograd.Function):
+    """(img [B,3,N,N], psf [1,3,N,N]) -> img (*) roll(psf) / per-image amax   (Optics.py:126-128)"""
+
+    @staticmethod
+    def forward(ctx, img, psf, cam):
+        N = cam.N
+        img = img.contiguous()
+        otf = fc.otf_build(psf.detach()[0], N, N)
+        out, _, partial = fc.fftconv_fwd(img, otf, mode=1)
+        m = fc.group_max(partial, img.shape[0])
+        fc.div_by_group_(out, m)
+        ctx.save_for_backward(img, out, m)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input image of the FD camera (the reference detaches, solver.py:144)")
+        img, sensor, m = ctx.saved_tensors
+        L = _lib.lib()
+        B, C, N, _ = img.shape
+        g_psf = torch.empty((1, C, N, N), dtype=torch.float32, device=img.device)
+        ws = torch.empty(L.ppv_fftconv_fd_bwd_workspace_bytes(B, C, N), dtype=torch.uint8, device=img.device)
+        check(L.ppv_fftconv_fd_bwd(ptr(img), ptr(g.contiguous()), ptr(sensor), ptr(m), ptr(g_psf), ptr(ws), B, C, N, stream_ptr()),
+              "ppv_fftconv_fd_bwd")
+        return None, g_psf, None
+
+
 class Camera(nn.Module):
-    supports_backward = False
+    supports_backward = True
 
     def __init__(self, device="cpu", N=256, lamdas=3, zernike_terms=50, height_tolerance=2e-8):
         super().__init__()
@@ -104,6 +177,7 @@ class Camera(nn.Module):
         with torch.cuda.device(device):
             check(L.ppv_init(), "ppv_init")
         self._ws = torch.empty(L.ppv_fd_psf_workspace_bytes(N), dtype=torch.uint8, device=device)
+        self._state_token = 0
 
     def get_Heith_Map(self):
         c = torch.cat((self.Zer_no_train, self.Zer_train), 0).detach().reshape(-1).contiguous()
@@ -120,16 +194,8 @@ class Camera(nn.Module):
         self.load_state_dict(ckpt['camera'])
 
     def get_psf(self):
-        N = self.N
-        h = self.get_Heith_Map()
-        psf = torch.empty((1, 3, N, N), dtype=torch.float32, device=self.device)
-        acc = torch.empty(4, dtype=torch.float64, device=self.device)
-        check(_lib.lib().ppv_fd_psf_fwd(ptr(h), ptr(self._base), ptr(self._chirp1), ptr(self._chirp2T), ptr(self._chirp3),
-                                        ptr(self._rho), self._kf_p, self._lratio, self._amp, ptr(psf), ptr(acc), ptr(self._ws),
-                                        N, stream_ptr()), "ppv_fd_psf_fwd")
-        self.loss_rad = torch.sqrt(acc[0]).to(torch.float32)                           # Optics.py:113
-        self._centering = ((acc[1] + acc[2]) / (3.0 * N * N)).to(torch.float32)
-        self.psfs = psf
+        coeffs = torch.cat((self.Zer_no_train, self.Zer_train), 0)
+        self.psfs, self.loss_rad, self._centering = _FdPsfFn.apply(coeffs, self)
         return self.psfs
 
     def forward(self, img):
@@ -139,8 +205,4 @@ class Camera(nn.Module):
             raise RuntimeError("image size must equal the camera's N (Optics.py:124-126 rolls by img.size // 2)")
         psf = self.get_psf()
         self.centering_loss = self._centering                                          # Optics.py:124-125
-        otf = fc.otf_build(psf[0], self.N, self.N)                                     # roll by -N/2 == PSF centre -> origin
-        out, _, partial = fc.fftconv_fwd(img.detach().to(torch.float32), otf, mode=1)
-        m = fc.group_max(partial, img.shape[0])                                        # Optics.py:128
-        fc.div_by_group_(out, m)
-        return out
+        return _FdSensorFn.apply(img.to(torch.float32), psf, self)                     # Optics.py:126-128

@@ -477,6 +477,97 @@ __global__ __launch_bounds__(256) void ic_out_bwd_kernel(const float* __restrict
     gr[idx] = out;
 }
 
+// ----------------------------------------------------------------------------- backward of the FD sensor image
+// (Optics.py:126-128: circular conv + per-image amax).  dotcnt[b][0] += sum g*sensor, dotcnt[b][1] += #(sensor == 1)
+__global__ __launch_bounds__(256) void dot_count_group_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
+                                                              double* __restrict__ dotcnt, long per_group4) {
+    __shared__ double s_red[4][2];
+    const long base = (long)blockIdx.y * per_group4;
+    double d = 0, c = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_group4; i += (long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(g)[base + i], b = reinterpret_cast<const float4*>(sensor)[base + i];
+        d += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+        c += (b.x == 1.f) + (b.y == 1.f) + (b.z == 1.f) + (b.w == 1.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d += __shfl_xor(d, off, 64); c += __shfl_xor(c, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = d; s_red[threadIdx.x >> 6][1] = c; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        atomicAdd(&dotcnt[blockIdx.y * 2 + threadIdx.x], s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// gr = (g - [sensor == 1] dot_b / cnt_b) / M_b
+__global__ __launch_bounds__(256) void fd_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
+                                                         const float* __restrict__ maxv, const double* __restrict__ dotcnt,
+                                                         float* __restrict__ gr, long per_group, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / per_group;
+    const float share = (float)(dotcnt[2 * b] / dotcnt[2 * b + 1]);
+    gr[i] = (g[i] - ((sensor[i] == 1.f) ? share : 0.f)) / maxv[b];
+}
+
+// as cols_corr_acc_kernel for operands with N rows (circular FD convolution): 8-column tiles, one column per wave
+template <int R>
+__global__ __launch_bounds__(512) void cols_corr_acc_full_kernel(const float2* __restrict__ SX, const float2* __restrict__ SG,
+                                                                 float2* __restrict__ part,
+                                                                 const float2* __restrict__ twg, int B, int C, int bchunk) {
+    constexpr int N = 64 * R, NH = N / 2, LD = 9;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[8][fft_scratch_elems<R>()];
+    __shared__ float2 s_x[N * LD];
+    __shared__ float2 s_g[N * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x, ch = blockIdx.y, chunk = blockIdx.z;
+    for (int i = tid; i < N; i += 512) s_tw[i] = twg[i];
+    float2 acc[R], accn[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] = accn[q] = make_float2(0.f, 0.f);
+    const int kx = tile * 8 + wave;
+    const int b0 = chunk * bchunk, b1 = min(B, b0 + bchunk);
+    for (int b = b0; b < b1; ++b) {
+        const long plane = (long)b * C + ch;
+        __syncthreads();
+        for (int idx = tid; idx < N * 4; idx += 512) {
+            const int row = idx >> 2, c4 = idx & 3;
+            const float4 vx = *reinterpret_cast<const float4*>(&SX[(plane * N + row) * NH + tile * 8 + c4 * 2]);
+            const float4 vg = *reinterpret_cast<const float4*>(&SG[(plane * N + row) * NH + tile * 8 + c4 * 2]);
+            s_x[row * LD + c4 * 2] = make_float2(vx.x, vx.y); s_x[row * LD + c4 * 2 + 1] = make_float2(vx.z, vx.w);
+            s_g[row * LD + c4 * 2] = make_float2(vg.x, vg.y); s_g[row * LD + c4 * 2 + 1] = make_float2(vg.z, vg.w);
+        }
+        __syncthreads();
+        float2 x[R], g[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { x[r] = s_x[(lane + 64 * r) * LD + wave]; g[r] = s_g[(lane + 64 * r) * LD + wave]; }
+        fft_wave<R>(x, s_scr[wave], s_tw, lane);
+        fft_wave<R>(g, s_scr[wave], s_tw, lane);
+        if (kx == 0) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                float2 mx = shfl2(x[R - 1 - q], (64 - lane) & 63), mg = shfl2(g[R - 1 - q], (64 - lane) & 63);
+                if (lane == 0) { mx = x[(R - q) % R]; mg = g[(R - q) % R]; }
+                const float2 xa = make_float2(0.5f * (x[q].x + mx.x), 0.5f * (x[q].y - mx.y));
+                const float2 xb = make_float2(0.5f * (x[q].y + mx.y), -0.5f * (x[q].x - mx.x));
+                const float2 ga = make_float2(0.5f * (g[q].x + mg.x), 0.5f * (g[q].y - mg.y));
+                const float2 gb = make_float2(0.5f * (g[q].y + mg.y), -0.5f * (g[q].x - mg.x));
+                acc[q] = cadd(acc[q], cmul_conj(ga, xa));
+                accn[q] = cadd(accn[q], cmul_conj(gb, xb));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = cadd(acc[q], cmul_conj(g[q], x[q]));
+        }
+    }
+    float2* pbase = part + ((long)chunk * C + ch) * (NH + 1) * N;
+#pragma unroll
+    for (int q = 0; q < R; ++q) pbase[(long)kx * N + lane + 64 * q] = acc[q];
+    if (kx == 0) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) pbase[(long)NH * N + lane + 64 * q] = accn[q];
+    }
+}
+
 // ----------------------------------------------------------------------------- normalisation helpers
 __global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                         int per_group) {
@@ -603,6 +694,42 @@ int fftconv_bwd_t(const float* img, const float* g_sensor, const float* sensor, 
     return ppv_last_error();
 }
 
+template <int R>
+int fftconv_fd_bwd_t(const float* img, const float* g_sensor, const float* sensor, const float* maxv, float* g_psf,
+                     void* workspace, int B, int C, hipStream_t stream) {
+    constexpr int N = 64 * R, NH = N / 2;
+    const float2* tw = (const float2*)ppv_twiddles_f32(N);
+    if (!tw) return PPV_ERR_INIT;
+    const int planes = B * C;
+    const long per_group = (long)C * N * N, total = per_group * B;
+    char* wp = (char*)workspace;
+    double* dotcnt = (double*)wp;           wp += ((size_t)B * 2 * sizeof(double) + 255) & ~(size_t)255;
+    float* gr = (float*)wp;                 wp += (size_t)total * sizeof(float);
+    float2* SX = (float2*)wp;               wp += (size_t)planes * N * NH * sizeof(float2);
+    float2* SG = (float2*)wp;               wp += (size_t)planes * N * NH * sizeof(float2);
+    const int nchunk = B < 16 ? B : 16;
+    const int bchunk = (B + nchunk - 1) / nchunk;
+    float2* part = (float2*)wp;             wp += (size_t)nchunk * C * (NH + 1) * N * sizeof(float2);
+    float2* S2 = (float2*)wp;               wp += (size_t)C * N * NH * sizeof(float2);
+    float* gemb = (float*)wp;
+    (void)hipMemsetAsync(dotcnt, 0, (size_t)B * 2 * sizeof(double), stream);
+    dot_count_group_kernel<<<dim3(64, B), 256, 0, stream>>>(g_sensor, sensor, dotcnt, per_group / 4);
+    fd_out_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(g_sensor, sensor, maxv, dotcnt, gr, per_group, total);
+    const int ppw = 4;
+    const long pairs = (long)planes * (N / 2);
+    const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
+    rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(gr, SG, tw, planes, N, N, ppw);
+    rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(img, SX, tw, planes, N, N, ppw);
+    const int nch = (B + bchunk - 1) / bchunk;
+    cols_corr_acc_full_kernel<R><<<dim3(NH / 8, C, nch), 512, 0, stream>>>(SX, SG, part, tw, B, C, bchunk);
+    cols_inv_from_T_kernel<R><<<(unsigned)((C * NH + 3) / 4), 256, 0, stream>>>(part, S2, tw, C, nch, 1.0f / ((float)N * (float)N));
+    const long cp = (long)C * (N / 2);
+    rows_c2r_kernel<R, 1><<<(unsigned)((cp + 4 * ppw - 1) / (4 * ppw)), 256, 0, stream>>>(S2, gemb, nullptr, nullptr, tw, C, N, ppw, 1.f);
+    const long tp = (long)C * N * N;
+    psf_gather_kernel<float><<<(unsigned)((tp + 255) / 256), 256, 0, stream>>>(gemb, g_psf, C, N, N, (long)N * N, N, 1);
+    return ppv_last_error();
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -683,6 +810,23 @@ int ppv_fftconv_ic_bwd(const float* img, const float* g_sensor, const float* sen
     if (g_img && !otfT) return PPV_ERR_NULL;
     if (N == 512) return fftconv_bwd_t<8>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, g_img, workspace, B, C, stream);
     if (N == 256) return fftconv_bwd_t<4>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, g_img, workspace, B, C, stream);
+    return PPV_ERR_BAD_SIZE;
+}
+
+size_t ppv_fftconv_fd_bwd_workspace_bytes(int B, int C, int N) {
+    const size_t planes = (size_t)B * C, NH = N / 2;
+    const size_t nchunk = B < 16 ? B : 16;
+    return 4096 + (size_t)B * 16 + planes * N * N * sizeof(float) + 2 * planes * N * NH * sizeof(float2) +
+           nchunk * C * (NH + 1) * N * sizeof(float2) + (size_t)C * N * NH * sizeof(float2) + (size_t)C * N * N * sizeof(float);
+}
+
+// Backward of the FD sensor image (Optics.py:126-128) w.r.t. the PSF: img, g_sensor, sensor [B,C,N,N] f32, maxv [B] (the
+// per-image maxima of the forward pass) -> g_psf [C][N][N] f32 (centre at N/2, i.e. w.r.t. the un-rolled PSF).
+int ppv_fftconv_fd_bwd(const float* img, const float* g_sensor, const float* sensor, const float* maxv, float* g_psf,
+                       void* workspace, int B, int C, int N, hipStream_t stream) {
+    if (!img || !g_sensor || !sensor || !maxv || !g_psf || !workspace) return PPV_ERR_NULL;
+    if (N == 512) return fftconv_fd_bwd_t<8>(img, g_sensor, sensor, maxv, g_psf, workspace, B, C, stream);
+    if (N == 256) return fftconv_fd_bwd_t<4>(img, g_sensor, sensor, maxv, g_psf, workspace, B, C, stream);
     return PPV_ERR_BAD_SIZE;
 }
 

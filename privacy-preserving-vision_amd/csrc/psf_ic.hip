@@ -567,6 +567,19 @@ int ppv_zernike_contract(const float* Z, const float* coeffs, float* h, int K, l
     return ppv_last_error();
 }
 
+// g_coeffs[k] = sum_px Z[k][px] * gh[px]  (adjoint of ppv_zernike_contract); part: scratch of
+// ppv_zernike_grad_scratch_bytes(K, npx)
+size_t ppv_zernike_grad_scratch_bytes(int K, long npx) { return ((size_t)((npx / 4 + 255) / 256)) * K * sizeof(double); }
+int ppv_zernike_grad(const float* Z, const float* gh, float* g_coeffs, void* part, int K, long npx, hipStream_t stream) {
+    if (!Z || !gh || !g_coeffs || !part) return PPV_ERR_NULL;
+    if (npx % 4) return PPV_ERR_BAD_SIZE;
+    const long npx4 = npx / 4;
+    const unsigned nwg = (unsigned)((npx4 + 255) / 256);
+    zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, gh, (double*)part, K, npx4);
+    sum_partials_kernel<<<K, 256, 0, stream>>>((const double*)part, g_coeffs, (int)nwg, K);
+    return ppv_last_error();
+}
+
 // debug / parity taps into the saved state
 int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0, size_t* off_U, size_t* off_I32,
                              size_t* off_raw) {

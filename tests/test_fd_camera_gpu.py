@@ -1,5 +1,5 @@
-"""GPU parity of the Face-DeId Camera drop-in (forward) against the goldens captured from the reference and the
-CPU oracle on the same parameters."""
+"""GPU parity of the Face-DeId Camera drop-in (forward AND the gradient w.r.t. Zer_train) against the goldens captured
+from the reference."""
 import pytest
 import torch
 
@@ -19,6 +19,7 @@ def test_fd_camera_forward_against_reference_golden(n):
         cam.Zer_train.copy_(torch.tensor(g[f"{t}_zer_train"]))
     assert sorted(cam.state_dict()) == ["Zer_no_train", "Zer_train", "ca"]
     img = torch.rand(2, 3, n, n, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    w = torch.rand(2, 3, n, n, generator=torch.Generator().manual_seed(5))
     sensor = cam(img.cuda())
     assert sensor.shape == (2, 3, n, n) and cam.psfs.shape == (1, 3, n, n)
     assert rel_err(cam.psfs, g[f"{t}_psfs"]) < TOL
@@ -29,3 +30,7 @@ def test_fd_camera_forward_against_reference_golden(n):
     st = g[f"{t}_sensor_stats"]
     assert abs(sensor.double().sum().item() - st[0]) < 2e-3 * abs(st[1]) ** 0.5 * 10
     assert sensor.amax((1, 2, 3)).cpu().tolist() == [1.0, 1.0]
+    # same scalar as tests/golden/make_golden.py::gen_fd: (sensor*w).sum() + 1e3*loss_rad + 1e6*centering_loss
+    loss = (sensor * w.cuda()).sum() + 1e3 * cam.loss_rad + 1e6 * cam.centering_loss
+    grad, = torch.autograd.grad(loss, [cam.Zer_train])
+    assert rel_err(grad.reshape(-1), g[f"{t}_grad"]) < 5 * TOL

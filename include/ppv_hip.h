@@ -130,6 +130,11 @@ int ppv_fd_psf_fwd(const float* h, const void* base, const void* chirp1, const v
 /* ---- RAFT correlation block: Face-DeId/RAFT/core/corr.py:12-60 (fp32) -------------------------------------------------- */
 int ppv_corr_volume(const float* f1, const float* f2, float* corr, int B, int C, int HW, ppv_stream_t stream);
 int ppv_avgpool2(const float* in, float* out, long n, int H, int W, ppv_stream_t stream);
+int ppv_corr_lookup_bwd(const float* gout, const float* coords, float* gcorr_l, int B, int H1, int W1, int Hl, int Wl,
+                        int r, int level, int nlevels, ppv_stream_t stream);
+int ppv_avgpool2_bwd_acc(const float* g_coarse, float* g_fine, long n, int H, int W, ppv_stream_t stream);
+int ppv_corr_volume_bwd(const float* gcorr, const float* f1, const float* f2, float* g_f1, float* g_f2, int B, int C,
+                        int HW, ppv_stream_t stream);
 int ppv_corr_lookup(const float* corr_l, const float* coords, float* out, int B, int H1, int W1, int Hl, int Wl, int r,
                     int level, int nlevels, ppv_stream_t stream);
 

@@ -107,6 +107,94 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     out[(((long)b * nlevels * ne + (long)level * ne + e) * H1 + h1) * W1 + w1] = v;
 }
 
+// ----------------------------------------------------------------------------- backward
+// adjoint of corr_lookup for one level: gcorr_l[n][y][x] += bilinear weights * gout[b][level*ne + e][h1][w1]
+__global__ __launch_bounds__(256) void corr_lookup_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ coords,
+                                                              float* __restrict__ gcorr, int B, int H1, int W1, int Hl, int Wl,
+                                                              int r, int level, int nlevels) {
+    const int win = 2 * r + 1, ne = win * win;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long npix = (long)B * H1 * W1;
+    if (i >= npix * ne) return;
+    const long n = i % npix;
+    const int e = (int)(i / npix);
+    const int a = e / win, d = e % win;
+    const int w1 = (int)(n % W1), h1 = (int)((n / W1) % H1), b = (int)(n / ((long)W1 * H1));
+    const float inv = 1.0f / (float)(1 << level);
+    float x = coords[(((long)b * 2 + 0) * H1 + h1) * W1 + w1] * inv + (float)(a - r);
+    float y = coords[(((long)b * 2 + 1) * H1 + h1) * W1 + w1] * inv + (float)(d - r);
+    x = ((2.f * x / (float)(Wl - 1) - 1.f) + 1.f) * 0.5f * (float)(Wl - 1);
+    y = ((2.f * y / (float)(Hl - 1) - 1.f) + 1.f) * 0.5f * (float)(Hl - 1);
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float g = gout[(((long)b * nlevels * ne + (long)level * ne + e) * H1 + h1) * W1 + w1];
+    float* img = gcorr + n * (long)Hl * Wl;
+    auto add = [&](int yy, int xx, float wgt) {
+        if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) atomicAdd(&img[(long)yy * Wl + xx], g * wgt);
+    };
+    add(y0, x0, wy0 * wx0); add(y0, x0 + 1, wy0 * wx1); add(y0 + 1, x0, wy1 * wx0); add(y0 + 1, x0 + 1, wy1 * wx1);
+}
+
+// g_fine[n][y][x] += 0.25 * g_coarse[n][y/2][x/2]   (adjoint of avgpool2)
+__global__ __launch_bounds__(256) void avgpool2_bwd_acc_kernel(const float* __restrict__ gc, float* __restrict__ gf, long n, int H, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long m = i / ((long)W * H);
+    gf[i] += 0.25f * gc[(m * (H / 2) + y / 2) * (W / 2) + x / 2];
+}
+
+// D[m][n] = scale * sum_k A(m,k) * B(k,n); A stored [M][K] (lda); B stored [K][N] (transB = 0) or [N][K] (transB = 1).
+// 64 x 64 tile, K chunk 16, fp32 MFMA 16x16x4.  M, N % 64 == 0, K % 16 == 0.
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
+                                                         int K, long lda, long ldb, long ldd, int transB, float scale, long sa,
+                                                         long sb, long sd) {
+    __shared__ float sA[16][64 + 4], sB[16][64 + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    A += (long)blockIdx.z * sa; Bm += (long)blockIdx.z * sb; D += (long)blockIdx.z * sd;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fk = lane >> 4;
+    f32x4c acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();
+        for (int idx = tid; idx < 16 * 64; idx += 256) {
+            const int k = idx & 15, m = idx >> 4;                 // A is K-contiguous: consecutive threads walk k
+            sA[k][m] = A[(long)(m0 + m) * lda + k0 + k];
+            if (transB) sB[k][m] = Bm[(long)(n0 + m) * ldb + k0 + k];
+        }
+        if (!transB)
+            for (int idx = tid; idx < 16 * 64; idx += 256) {
+                const int n = idx & 63, k = idx >> 6;             // B is N-contiguous
+                sB[k][n] = Bm[(long)(k0 + k) * ldb + n0 + n];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = sA[kk + fk][wm * 32 + a * 16 + fr];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bf[c] = sB[kk + fk][wn * 32 + c * 16 + fr];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[c], acc[a][c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                D[(long)(m0 + wm * 32 + a * 16 + fk * 4 + j) * ldd + n0 + wn * 32 + c * 16 + fr] = acc[a][c][j] * scale;
+}
+
 }  // namespace ppv
 
 extern "C" {
@@ -133,6 +221,37 @@ int ppv_corr_lookup(const float* corr_l, const float* coords, float* out, int B,
     if (!corr_l || !coords || !out) return PPV_ERR_NULL;
     const long tot = (long)B * H1 * W1 * (2 * r + 1) * (2 * r + 1);
     ppv::corr_lookup_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(corr_l, coords, out, B, H1, W1, Hl, Wl, r, level, nlevels);
+    return ppv_last_error();
+}
+
+// adjoint of ppv_corr_lookup for one level; gcorr_l [B*H1*W1][Hl][Wl] is ACCUMULATED into (f32 atomics)
+int ppv_corr_lookup_bwd(const float* gout, const float* coords, float* gcorr_l, int B, int H1, int W1, int Hl, int Wl, int r,
+                        int level, int nlevels, hipStream_t stream) {
+    if (!gout || !coords || !gcorr_l) return PPV_ERR_NULL;
+    const long tot = (long)B * H1 * W1 * (2 * r + 1) * (2 * r + 1);
+    ppv::corr_lookup_bwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(gout, coords, gcorr_l, B, H1, W1, Hl, Wl, r, level, nlevels);
+    return ppv_last_error();
+}
+
+// g_fine [n][H][W] += adjoint of avgpool2 applied to g_coarse [n][H/2][W/2]
+int ppv_avgpool2_bwd_acc(const float* g_coarse, float* g_fine, long n, int H, int W, hipStream_t stream) {
+    if (!g_coarse || !g_fine) return PPV_ERR_NULL;
+    const long tot = n * H * W;
+    ppv::avgpool2_bwd_acc_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(g_coarse, g_fine, n, H, W);
+    return ppv_last_error();
+}
+
+// adjoint of ppv_corr_volume: gcorr [B][HW][HW] -> g_f1, g_f2 [B,C,H,W] f32 (either may be null).  HW % 64 == 0, C % 64 == 0.
+int ppv_corr_volume_bwd(const float* gcorr, const float* f1, const float* f2, float* g_f1, float* g_f2, int B, int C, int HW,
+                        hipStream_t stream) {
+    if (!gcorr || !f1 || !f2) return PPV_ERR_NULL;
+    if (HW % 64 || C % 64) return PPV_ERR_BAD_SIZE;
+    const float scale = 1.0f / sqrtf((float)C);
+    const dim3 grid(HW / 64, C / 64, B);
+    // g_f1[c][i] = scale * sum_j f2[c][j] * G[i][j]   (B operand stored [N = i][K = j])
+    if (g_f1) ppv::sgemm_mfma_kernel<<<grid, 256, 0, stream>>>(f2, gcorr, g_f1, HW, HW, HW, HW, 1, scale, (long)C * HW, (long)HW * HW, (long)C * HW);
+    // g_f2[c][j] = scale * sum_i f1[c][i] * G[i][j]   (B operand stored [K = i][N = j])
+    if (g_f2) ppv::sgemm_mfma_kernel<<<grid, 256, 0, stream>>>(f1, gcorr, g_f2, HW, HW, HW, HW, 0, scale, (long)C * HW, (long)HW * HW, (long)C * HW);
     return ppv_last_error();
 }
 

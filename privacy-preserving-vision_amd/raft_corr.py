@@ -1,39 +1,95 @@
-"""Drop-in for reference ``Face-DeId/RAFT/core/corr.py:12 CorrBlock`` (forward) on MI355X: all-pairs correlation
-volume (fp32 MFMA), 4-level average-pool pyramid and the 9x9 bilinear window lookup, through libppv_hip.so.
-Same constructor and ``__call__(coords)`` contract; no autograd graph is attached this round (gap: RAFT's flow loss
-back-propagates through the lookup in ``core/utils.py:437-462``)."""
+"""Drop-in for reference ``Face-DeId/RAFT/core/corr.py:12 CorrBlock`` on MI355X: all-pairs correlation volume (fp32
+MFMA), 4-level average-pool pyramid and the 9x9 bilinear window lookup, through libppv_hip.so.  Same constructor and
+``__call__(coords)`` contract.  Autograd: gradients flow to ``fmap1`` / ``fmap2`` through the lookup, the pyramid and the
+volume (RAFT detaches ``coords`` every iteration, raft.py:123, and the reference's own CUDA extension leaves
+``coords_grad`` zero), which is what ``loss_RAFT`` (core/utils.py:437-462) back-propagates."""
 import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 
+class _VolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, num_levels):
+        L = _lib.lib()
+        f1 = f1.float().contiguous()
+        f2 = f2.float().contiguous()
+        B, C, H, W = f1.shape
+        corr = torch.empty((B * H * W, 1, H, W), dtype=torch.float32, device=f1.device)
+        check(L.ppv_corr_volume(ptr(f1), ptr(f2), ptr(corr), B, C, H * W, stream_ptr()), "ppv_corr_volume")
+        pyr = [corr]
+        h, w = H, W
+        for _ in range(num_levels - 1):
+            nxt = torch.empty((B * H * W, 1, h // 2, w // 2), dtype=torch.float32, device=f1.device)
+            check(L.ppv_avgpool2(ptr(pyr[-1]), ptr(nxt), B * H * W, h, w, stream_ptr()), "ppv_avgpool2")
+            pyr.append(nxt)
+            h, w = h // 2, w // 2
+        ctx.save_for_backward(f1, f2)
+        ctx.set_materialize_grads(False)
+        return tuple(pyr)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        f1, f2 = ctx.saved_tensors
+        L = _lib.lib()
+        B, C, H, W = f1.shape
+        n = B * H * W
+        # fold the pyramid gradients down to level 0 (adjoint of the avg-pool chain)
+        g = [x.contiguous().clone() if x is not None else None for x in gs]
+        for lvl in range(len(g) - 1, 0, -1):
+            if g[lvl] is None:
+                continue
+            h, w = H >> (lvl - 1), W >> (lvl - 1)
+            if g[lvl - 1] is None:
+                g[lvl - 1] = torch.zeros((n, 1, h, w), dtype=torch.float32, device=f1.device)
+            check(L.ppv_avgpool2_bwd_acc(ptr(g[lvl]), ptr(g[lvl - 1]), n, h, w, stream_ptr()), "ppv_avgpool2_bwd_acc")
+        if g[0] is None:
+            return None, None, None
+        g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        check(L.ppv_corr_volume_bwd(ptr(g[0]), ptr(f1), ptr(f2), ptr(g1), ptr(g2), B, C, H * W, stream_ptr()), "ppv_corr_volume_bwd")
+        return g1, g2, None
+
+
+class _LookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coords, radius, shape, *pyr):
+        L = _lib.lib()
+        B, H, W = shape
+        r = radius
+        coords = coords.detach().float().contiguous()
+        nl = len(pyr)
+        out = torch.empty((B, nl * (2 * r + 1) ** 2, H, W), dtype=torch.float32, device=coords.device)
+        for i, c in enumerate(pyr):
+            check(L.ppv_corr_lookup(ptr(c), ptr(coords), ptr(out), B, H, W, c.shape[-2], c.shape[-1], r, i, nl, stream_ptr()),
+                  "ppv_corr_lookup")
+        ctx.save_for_backward(coords)
+        ctx.meta = (r, shape, [tuple(c.shape) for c in pyr])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        coords, = ctx.saved_tensors
+        r, (B, H, W), shapes = ctx.meta
+        L = _lib.lib()
+        gout = gout.contiguous().float()
+        grads = []
+        for i, shp in enumerate(shapes):
+            gc = torch.zeros(shp, dtype=torch.float32, device=gout.device)
+            check(L.ppv_corr_lookup_bwd(ptr(gout), ptr(coords), ptr(gc), B, H, W, shp[-2], shp[-1], r, i, len(shapes), stream_ptr()),
+                  "ppv_corr_lookup_bwd")
+            grads.append(gc)
+        return (None, None, None) + tuple(grads)
+
+
 class CorrBlock:
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         _lib.require_cuda(fmap1, fmap2)
         self.num_levels, self.radius = num_levels, radius
-        f1 = fmap1.detach().float().contiguous()
-        f2 = fmap2.detach().float().contiguous()
-        B, C, H, W = f1.shape
+        B, C, H, W = fmap1.shape
         self.shape = (B, H, W)
-        L = _lib.lib()
-        corr = torch.empty((B * H * W, 1, H, W), dtype=torch.float32, device=f1.device)
-        check(L.ppv_corr_volume(ptr(f1), ptr(f2), ptr(corr), B, C, H * W, stream_ptr()), "ppv_corr_volume")
-        self.corr_pyramid = [corr]
-        h, w = H, W
-        for _ in range(num_levels - 1):
-            nxt = torch.empty((B * H * W, 1, h // 2, w // 2), dtype=torch.float32, device=f1.device)
-            check(L.ppv_avgpool2(ptr(self.corr_pyramid[-1]), ptr(nxt), B * H * W, h, w, stream_ptr()), "ppv_avgpool2")
-            self.corr_pyramid.append(nxt)
-            h, w = h // 2, w // 2
+        self.corr_pyramid = list(_VolumeFn.apply(fmap1, fmap2, num_levels))
 
     def __call__(self, coords):
-        B, H, W = self.shape
-        r = self.radius
-        coords = coords.detach().float().contiguous()
-        out = torch.empty((B, self.num_levels * (2 * r + 1) ** 2, H, W), dtype=torch.float32, device=coords.device)
-        L = _lib.lib()
-        for i, c in enumerate(self.corr_pyramid):
-            check(L.ppv_corr_lookup(ptr(c), ptr(coords), ptr(out), B, H, W, c.shape[-2], c.shape[-1], r, i, self.num_levels,
-                                    stream_ptr()), "ppv_corr_lookup")
-        return out
+        return _LookupFn.apply(coords, self.radius, self.shape, *self.corr_pyramid)

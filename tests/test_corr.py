@@ -40,3 +40,26 @@ def test_hip_corrblock_matches_oracle_at_config4_shape():
     want = oc.lookup(oc.pyramid(oc.corr_volume(f1, f2)), coords)
     blk = CorrBlock(f1.cuda(), f2.cuda())
     assert rel_err(blk(coords.cuda()), want) < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_corrblock_backward_matches_oracle():
+    """d/d fmap1, d/d fmap2 through two lookups sharing one pyramid (the structure loss_RAFT back-propagates)."""
+    from oracle import corr as oc
+    from ppv_amd.raft_corr import CorrBlock
+    g0 = torch.Generator().manual_seed(0)
+    f1 = torch.randn(2, 64, 16, 16, generator=g0)
+    f2 = torch.randn(2, 64, 16, 16, generator=g0)
+    ys, xs = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
+    base = torch.stack([xs, ys], 0).float()[None].repeat(2, 1, 1, 1)
+    c1 = base + 2.0 * torch.randn(2, 2, 16, 16, generator=g0)
+    c2 = base + 2.0 * torch.randn(2, 2, 16, 16, generator=g0)
+    w1 = torch.randn(2, 324, 16, 16, generator=g0)
+    w2 = torch.randn(2, 324, 16, 16, generator=g0)
+    a1, a2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    pyr = oc.pyramid(oc.corr_volume(a1, a2))
+    ((oc.lookup(pyr, c1) * w1).sum() + (oc.lookup(pyr, c2) * w2).sum()).backward()
+    b1, b2 = f1.cuda().requires_grad_(True), f2.cuda().requires_grad_(True)
+    blk = CorrBlock(b1, b2)
+    ((blk(c1.cuda()) * w1.cuda()).sum() + (blk(c2.cuda()) * w2.cuda()).sum()).backward()
+    assert rel_err(b1.grad, a1.grad) < 1e-4 and rel_err(b2.grad, a2.grad) < 1e-4

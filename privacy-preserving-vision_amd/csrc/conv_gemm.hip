@@ -401,9 +401,11 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         // the addend tile comes in as whole 16-byte chunks (coalesced), is parked in LDS behind the output staging
         // area and added fragment-wise in f32: one rounding of (acc + addend), no 2-byte global gathers
         char* sAdd = smem + BM * LDO + 2048;
-        if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) {
+        if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES && WM % 2 != 0) {
+            return;                                             // host never pairs this tile shape with an addend
+        } else if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) {
             // small ring (BK = 32): the output tile and the addend tile are processed in two 128-row halves
-            static_assert(WM % 2 == 0 && BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "two-pass epilogue geometry");
+            static_assert(BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "two-pass epilogue geometry");
             constexpr int HR = BM / 2;                          // rows per pass
             char* sOh = smem;
             char* sAh = smem + HR * LDO;
@@ -640,7 +642,8 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
         else if (t256 >= CUS) v = 3;            // one round: deepest prefetch per workgroup
         else v = 2;                             // the 256-row tile only when it still fills the chip
     }
-    if (v == 4) PPV_LAUNCH_PIPE(256, 128, 3, 32, 2);      // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
+    if (v == 5) PPV_LAUNCH_PIPE(128, 128, 3, 32, 3);      // 16 KB stages, three 4-wave workgroups per CU
+    else if (v == 4) PPV_LAUNCH_PIPE(256, 128, 3, 32, 2); // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
     else if (v == 3) PPV_LAUNCH_PIPE(256, 128, 3, 64, 1);
     else if (v == 2) PPV_LAUNCH_PIPE(128, 128, 4, 64, 1);
     else if (N == 16) PPV_LAUNCH(16, 4, 1);

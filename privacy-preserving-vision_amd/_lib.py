@@ -7,7 +7,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libppv_hip.so")
+LIB_PATH = os.environ.get("PPV_LIB_PATH") or os.path.join(_HERE, "lib", "libppv_hip.so")   # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 
 _c = ctypes

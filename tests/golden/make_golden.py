@@ -256,10 +256,41 @@ def gen_fan():
     np.savez_compressed(os.path.join(HERE, "fan.npz"), **out)
 
 
+# --------------------------------------------------------------------------- attention decoder (Image_Caption/models.py)
+def gen_decoder():
+    install_standins()
+    sys.path.insert(0, os.path.join(REF, "Image_Caption"))
+    import models as ref_models
+    from torch.nn.utils.rnn import pack_padded_sequence
+    ref_models.device = torch.device("cpu")                   # models.py:5 hard-wires cuda:0
+    g = torch.Generator().manual_seed(0)
+    B, S, E, A, M, D, V, L = 5, 6, 64, 32, 24, 40, 50, 11
+    dec = ref_models.DecoderWithAttention(attention_dim=A, embed_dim=M, decoder_dim=D, vocab_size=V, encoder_dim=E, dropout=0.3).eval()
+    fill_by_name(dec)
+    with torch.no_grad():
+        dec.embedding.weight.copy_(torch.rand(V, M, generator=g) * 0.2 - 0.1)
+    enc = torch.randn(B, S, S, E, generator=g).requires_grad_(True)
+    caps = torch.randint(0, V, (B, L), generator=g)
+    caplens = torch.tensor([[7], [11], [4], [9], [7]])
+    preds, caps_sorted, dec_len, alphas, order = dec(enc, caps, caplens)
+    targets = caps_sorted[:, 1:]
+    sc = pack_padded_sequence(preds, dec_len, batch_first=True)
+    tg = pack_padded_sequence(targets, dec_len, batch_first=True)
+    loss = torch.nn.functional.cross_entropy(sc.data, tg.data) + 1.0 * ((1.0 - alphas.sum(dim=1)) ** 2).mean()   # train.py:276-282
+    loss.backward()
+    out = {"enc": enc.detach().numpy(), "caps": caps.numpy(), "caplens": caplens.numpy(), "preds": preds.detach().numpy(),
+           "alphas": alphas.detach().numpy(), "order": order.numpy(), "dec_len": np.array(dec_len), "loss": loss.item(),
+           "g_enc": enc.grad.numpy(), "emb_weight": dec.embedding.weight.detach().numpy(), "dims": np.array([B, S, E, A, M, D, V, L])}
+    for n, p_ in dec.named_parameters():
+        out["g_" + n] = p_.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "decoder.npz"), **out)
+    print("decoder loss", loss.item(), "preds", stats(preds), "alphas", stats(alphas), "g_enc", stats(enc.grad))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        for w in ("ic", "fd", "corr", "fan"):
+        for w in ("ic", "fd", "corr", "fan", "decoder"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan}[what]()
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder}[what]()

@@ -148,6 +148,23 @@ int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* 
 int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr,
                  int nch, int split, int nsum, int up, ppv_stream_t stream);
 
+/* ---- soft-attention LSTM caption decoder, Image_Caption/models.py:57-218.  encoder_att is hoisted out
+ * of the time loop (models.py:83 recomputes it every step) and runs through ppv_conv_gemm; these are the per-step kernels.
+ * "sorted" = the batch order after the caption-length sort of models.py:181-183; order[b] = original image index. */
+int ppv_dec_prepare(const float* enc, const long* order, void* encs, float* mean, int B, int P, int E, ppv_stream_t stream);
+int ppv_dec_attend_fwd(const void* att1, const void* encs, const float* hproj, int ldh, const float* wfull, float* ebuf,
+                       float* alpha_out, float* awe_save, float* xh, int ldx, int x_off, int bt, int P, int A, int E,
+                       ppv_stream_t stream);
+int ppv_dec_attend_bwd(const void* att1, const void* encs, const float* hproj, int ldh, const float* wfull, const float* alpha,
+                       const float* awe_save, const float* dxh, int ldx, int x_off, const float* dalpha_in, float* dhproj,
+                       float* dawe_out, float* dalpha, float* datt1, float* dwfull, int bt, int P, int A, int E,
+                       ppv_stream_t stream);
+int ppv_lstm_cell_fwd(const float* z, const float* c_prev, float* gates, float* c_new, float* h_a, int ld_a, float* h_b, int ld_b,
+                      int bt, int D, ppv_stream_t stream);
+int ppv_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh, const float* dc_in, float* dz,
+                      float* dc_prev, int bt, int D, ppv_stream_t stream);
+int ppv_dec_combine(const float* acc, const float* dmean, const long* order, float* out, int B, int P, int E, ppv_stream_t stream);
+
 /* backward of the FD camera: sensor image -> PSF (Optics.py:126-128), PSF + losses -> height map (Optics.py:92-120),
  * height map -> Zernike coefficients (Optics.py:79-83) */
 size_t ppv_fftconv_fd_bwd_workspace_bytes(int B, int C, int N);

@@ -1,0 +1,410 @@
+// Soft-attention LSTM caption decoder (Image_Caption/models.py:57-218): the per-time-step kernels.
+//
+// What is hoisted out of the time loop (result-identical, see decoder.py): att1 = encoder_att(encoder_out) is computed
+// ONCE with the bf16 MFMA GEMM (ppv_conv_gemm as a 1x1 convolution) instead of once per step (models.py:83 via :207).
+// Inside the loop every step is HBM-bound streaming over two per-image tables,
+//     att1 [B][P][A] bf16   (scores)   and   encs [B][P][E] bf16   (context),
+// so the kernels below are organised around whole-row 16-byte loads, one wave per pixel row, wave-shuffle reductions,
+// and a grid of (images x pixel slabs) or (images x channel slabs) that fills 256 CUs at B = 128:
+//
+//   dec_prepare      f32 encoder_out --gather by sort order--> bf16 encs, + per-image mean (init_h / init_c input)
+//   dec_score_fwd    e[b,p] = w_full . relu(att1[b,p,:] + att2[b,:])                      (models.py:85)
+//   dec_ctx_fwd      alpha = softmax_p(e); awe = sum_p alpha_p encs[b,p,:]; x = sigmoid(f_beta(h)) * awe  (:86-87, :205-206)
+//   lstm_fwd/bwd     the LSTMCell pointwise part (gate order i, f, g, o)                    (:207-210)
+//   dec_ctx_bwd      d awe, d gate, d alpha_p = d awe . encs[b,p,:]
+//   dec_score_bwd    softmax backward, relu mask recomputed from att1 + att2, f32 accumulation into d att1
+//   dec_combine      d encoder_out[order[b]] = (context + score paths) + d mean / P
+//
+// The dense GEMMs of a step (h projections, LSTM gates, vocabulary scores) are plain library GEMMs on the host side.
+#include <hip/hip_runtime.h>
+#include "ppv_common.h"
+
+namespace ppv {
+
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bflo(unsigned x) { return __builtin_bit_cast(float, x << 16); }
+__device__ __forceinline__ float bfhi(unsigned x) { return __builtin_bit_cast(float, x & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide (256 threads) reductions through 4 LDS words
+__device__ __forceinline__ float block_sum(float v, float* s4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+__device__ __forceinline__ float block_max(float v, float* s4) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+}
+
+// ----------------------------------------------------------------------------- prepare
+// grid (B, ceil(P / PT)); encs[b][p][:] = bf16(enc[order[b]][p][:]); mean[b][:] += sum_p / P  (mean pre-zeroed)
+__global__ __launch_bounds__(256) void dec_prepare_kernel(const float* __restrict__ enc, const long* __restrict__ order,
+                                                          bf16_t* __restrict__ encs, float* __restrict__ mean, int P, int E,
+                                                          int PT) {
+    const int b = blockIdx.x, p0 = blockIdx.y * PT, p1 = min(p0 + PT, P);
+    const float* src = enc + order[b] * (long)P * E;
+    bf16_t* dst = encs + (long)b * P * E;
+    const float invP = 1.f / (float)P;
+    for (int c = threadIdx.x * 8; c < E; c += 2048) {
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = p0; p < p1; ++p) {
+            const float4 u = *reinterpret_cast<const float4*>(src + (long)p * E + c);
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)p * E + c + 4);
+            s[0] += u.x; s[1] += u.y; s[2] += u.z; s[3] += u.w; s[4] += v.x; s[5] += v.y; s[6] += v.z; s[7] += v.w;
+            uint4 o;
+            o.x = pack_bf2(u.x, u.y); o.y = pack_bf2(u.z, u.w); o.z = pack_bf2(v.x, v.y); o.w = pack_bf2(v.z, v.w);
+            *reinterpret_cast<uint4*>(dst + (long)p * E + c) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&mean[(long)b * E + c + k], s[k] * invP);
+    }
+}
+
+// ----------------------------------------------------------------------------- attention scores
+// grid (bt, ceil(P / PS)), 4 waves, one wave per pixel row.  hproj row b: [att2 (A) | gate_pre (E)], stride ldh.
+__global__ __launch_bounds__(256) void dec_score_fwd_kernel(const bf16_t* __restrict__ att1, const float* __restrict__ hproj,
+                                                            int ldh, const float* __restrict__ wfull,
+                                                            float* __restrict__ ebuf, int P, int A, int PS) {
+    extern __shared__ float sm[];
+    float* sA2 = sm;
+    float* sW = sm + A;
+    const int b = blockIdx.x, p0 = blockIdx.y * PS, p1 = min(p0 + PS, P);
+    for (int a = threadIdx.x; a < A; a += 256) {
+        sA2[a] = hproj[(long)b * ldh + a];
+        sW[a] = wfull[a];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int p = p0 + wave; p < p1; p += 4) {
+        const bf16_t* row = att1 + ((long)b * P + p) * A;
+        float acc = 0.f;
+        for (int a0 = lane * 8; a0 < A; a0 += 512) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + a0);
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc += fmaxf(bflo(w4[k]) + sA2[a0 + 2 * k], 0.f) * sW[a0 + 2 * k];
+                acc += fmaxf(bfhi(w4[k]) + sA2[a0 + 2 * k + 1], 0.f) * sW[a0 + 2 * k + 1];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) ebuf[(long)b * P + p] = acc;
+    }
+}
+
+// ----------------------------------------------------------------------------- softmax + context + gate
+// grid (bt, ceil(E / 256)): every workgroup redoes the (cheap) softmax of its image, then owns 256 context channels.
+// alpha_out [bt][P] (written by channel slab 0), awe_save [bt][E] (ungated), xh[b*ldx + x_off + e] = gate * awe.
+__global__ __launch_bounds__(256) void dec_ctx_fwd_kernel(const bf16_t* __restrict__ encs, const float* __restrict__ ebuf,
+                                                          const float* __restrict__ hproj, int ldh, int gate_off,
+                                                          float* __restrict__ alpha_out, float* __restrict__ awe_save,
+                                                          float* __restrict__ xh, int ldx, int x_off, int P, int E) {
+    extern __shared__ float sm[];
+    float* sAl = sm;                 // [P]
+    float* sRed = sm + P;            // [8][256]
+    __shared__ float s4[4];
+    const int b = blockIdx.x, c0 = blockIdx.y * 256, tid = threadIdx.x;
+    float m = -3.4e38f;
+    for (int p = tid; p < P; p += 256) m = fmaxf(m, ebuf[(long)b * P + p]);
+    m = block_max(m, s4);
+    float s = 0.f;
+    for (int p = tid; p < P; p += 256) {
+        const float v = __expf(ebuf[(long)b * P + p] - m);
+        sAl[p] = v;
+        s += v;
+    }
+    s = block_sum(s, s4);
+    const float inv = 1.f / s;
+    for (int p = tid; p < P; p += 256) {
+        const float a = sAl[p] * inv;
+        sAl[p] = a;
+        if (blockIdx.y == 0) alpha_out[(long)b * P + p] = a;
+    }
+    __syncthreads();
+    const int cg = tid & 31, pg = tid >> 5, c = c0 + cg * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < E) {
+        const bf16_t* base = encs + (long)b * P * E + c;
+        for (int p = pg; p < P; p += 8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base + (long)p * E);
+            const float a = sAl[p];
+            acc[0] += a * bflo(v.x); acc[1] += a * bfhi(v.x); acc[2] += a * bflo(v.y); acc[3] += a * bfhi(v.y);
+            acc[4] += a * bflo(v.z); acc[5] += a * bfhi(v.z); acc[6] += a * bflo(v.w); acc[7] += a * bfhi(v.w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sRed[pg * 256 + cg * 8 + k] = acc[k];
+    __syncthreads();
+    const int e = c0 + tid;
+    if (e < E) {
+        float awe = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) awe += sRed[g * 256 + tid];
+        awe_save[(long)b * E + e] = awe;
+        xh[(long)b * ldx + x_off + e] = sigmoidf(hproj[(long)b * ldh + gate_off + e]) * awe;
+    }
+}
+
+// ----------------------------------------------------------------------------- LSTM cell, pointwise part
+// z [bt][4D] = W_ih x + b_ih + W_hh h + b_hh (i, f, g, o).  gates [bt][4D] keeps the ACTIVATED values for backward.
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+                                                       float* __restrict__ gates, float* __restrict__ c_new,
+                                                       float* __restrict__ h_a, int ld_a, float* __restrict__ h_b, int ld_b,
+                                                       int bt, int D) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)bt * D) return;
+    const int b = (int)(i / D), d = (int)(i % D);
+    const float* zr = z + (long)b * 4 * D;
+    const float gi = sigmoidf(zr[d]), gf = sigmoidf(zr[D + d]), gg = tanhf(zr[2 * D + d]), go = sigmoidf(zr[3 * D + d]);
+    const float c = gf * c_prev[i] + gi * gg;
+    const float h = go * tanhf(c);
+    float* gr = gates + (long)b * 4 * D;
+    gr[d] = gi; gr[D + d] = gf; gr[2 * D + d] = gg; gr[3 * D + d] = go;
+    c_new[i] = c;
+    h_a[(long)b * ld_a + d] = h;
+    if (h_b) h_b[(long)b * ld_b + d] = h;
+}
+
+// dh [bt][D] (from the vocabulary scores + the next step), dc_in [bt][D] (from the next step) -> dz [bt][4D], dc_prev.
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                       const float* __restrict__ c_new, const float* __restrict__ dh,
+                                                       const float* __restrict__ dc_in, float* __restrict__ dz,
+                                                       float* __restrict__ dc_prev, int bt, int D) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)bt * D) return;
+    const int b = (int)(i / D), d = (int)(i % D);
+    const float* gr = gates + (long)b * 4 * D;
+    const float gi = gr[d], gf = gr[D + d], gg = gr[2 * D + d], go = gr[3 * D + d];
+    const float tc = tanhf(c_new[i]);
+    const float dhv = dh[i];
+    const float dc = dc_in[i] + dhv * go * (1.f - tc * tc);
+    float* dr = dz + (long)b * 4 * D;
+    dr[d] = dc * gg * gi * (1.f - gi);
+    dr[D + d] = dc * c_prev[i] * gf * (1.f - gf);
+    dr[2 * D + d] = dc * gi * (1.f - gg * gg);
+    dr[3 * D + d] = dhv * tc * go * (1.f - go);
+    dc_prev[i] = dc * gf;
+}
+
+// ----------------------------------------------------------------------------- context backward
+// grid (bt, ceil(P / PS)).  dxh row b holds d(gated awe) at x_off.  Slab 0 also writes d gate_pre into dhproj and the
+// ungated d awe (kept for the batched alpha^T . d awe GEMM after the time loop).
+// dalpha[b][p] = d awe . encs[b][p][:] (+ the caller's gradient on the returned alphas)
+__global__ __launch_bounds__(256) void dec_ctx_bwd_kernel(const bf16_t* __restrict__ encs, const float* __restrict__ dxh, int ldx,
+                                                          int x_off, const float* __restrict__ hproj, int ldh, int gate_off,
+                                                          const float* __restrict__ awe_save, const float* __restrict__ dalpha_in,
+                                                          float* __restrict__ dhproj, float* __restrict__ dawe_out,
+                                                          float* __restrict__ dalpha, int P, int E, int PS) {
+    extern __shared__ float sD[];    // [E] d awe
+    const int b = blockIdx.x, p0 = blockIdx.y * PS, p1 = min(p0 + PS, P);
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const float g = sigmoidf(hproj[(long)b * ldh + gate_off + e]);
+        const float dx = dxh[(long)b * ldx + x_off + e];
+        const float da = dx * g;
+        sD[e] = da;
+        if (blockIdx.y == 0) {
+            dhproj[(long)b * ldh + gate_off + e] = dx * awe_save[(long)b * E + e] * g * (1.f - g);
+            dawe_out[(long)b * E + e] = da;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int p = p0 + wave; p < p1; p += 4) {
+        const bf16_t* row = encs + ((long)b * P + p) * E;
+        float acc = 0.f;
+        for (int e0 = lane * 8; e0 < E; e0 += 512) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + e0);
+            const float* d = sD + e0;
+            acc += bflo(v.x) * d[0] + bfhi(v.x) * d[1] + bflo(v.y) * d[2] + bfhi(v.y) * d[3] + bflo(v.z) * d[4] +
+                   bfhi(v.z) * d[5] + bflo(v.w) * d[6] + bfhi(v.w) * d[7];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dalpha[(long)b * P + p] = acc + (dalpha_in ? dalpha_in[(long)b * P + p] : 0.f);
+    }
+}
+
+// ----------------------------------------------------------------------------- score backward
+// grid (bt, ceil(P / PS)).  d e_p = alpha_p (d alpha_p - sum_q alpha_q d alpha_q);  pre = att1 + att2;
+// d att1[b][p][a] += [pre > 0] d e_p w_a  (f32 read-modify-write);  d att2[b][a] += same summed over p (atomics into
+// dhproj[:, 0:A], pre-zeroed);  d w_full[a] += d e_p relu(pre)  (atomics).  A <= 2048.
+__global__ __launch_bounds__(256) void dec_score_bwd_kernel(const bf16_t* __restrict__ att1, const float* __restrict__ hproj, int ldh,
+                                                            const float* __restrict__ wfull, const float* __restrict__ alpha,
+                                                            const float* __restrict__ dalpha, float* __restrict__ datt1,
+                                                            float* __restrict__ dhproj, float* __restrict__ dwfull, int P, int A,
+                                                            int PS) {
+    extern __shared__ float sm[];
+    float* sA2 = sm;                 // [A]
+    float* sW = sm + A;              // [A]
+    float* sAcc = sm + 2 * A;        // [2][A] cross-wave accumulators (d att2, d w)
+    __shared__ float s4[4];
+    const int b = blockIdx.x, p0 = blockIdx.y * PS, p1 = min(p0 + PS, P), tid = threadIdx.x;
+    for (int a = tid; a < A; a += 256) {
+        sA2[a] = hproj[(long)b * ldh + a];
+        sW[a] = wfull[a];
+        sAcc[a] = 0.f;
+        sAcc[A + a] = 0.f;
+    }
+    float dot = 0.f;
+    for (int p = tid; p < P; p += 256) dot += alpha[(long)b * P + p] * dalpha[(long)b * P + p];
+    dot = block_sum(dot, s4);        // (its barriers also publish sA2 / sW / sAcc)
+    const int wave = tid >> 6, lane = tid & 63;
+    float da2[4][8], dw[4][8];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) da2[ch][k] = dw[ch][k] = 0.f;
+    for (int p = p0 + wave; p < p1; p += 4) {
+        const float de = alpha[(long)b * P + p] * (dalpha[(long)b * P + p] - dot);
+        const bf16_t* row = att1 + ((long)b * P + p) * A;
+        float* drow = datt1 + ((long)b * P + p) * A;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int a0 = ch * 512 + lane * 8;
+            if (a0 < A) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + a0);
+                const float x[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+                float4 g0 = *reinterpret_cast<const float4*>(drow + a0), g1 = *reinterpret_cast<const float4*>(drow + a0 + 4);
+                float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float pre = x[k] + sA2[a0 + k];
+                    const float dp = pre > 0.f ? de * sW[a0 + k] : 0.f;
+                    dw[ch][k] += de * fmaxf(pre, 0.f);
+                    da2[ch][k] += dp;
+                    g[k] += dp;
+                }
+                *reinterpret_cast<float4*>(drow + a0) = make_float4(g[0], g[1], g[2], g[3]);
+                *reinterpret_cast<float4*>(drow + a0 + 4) = make_float4(g[4], g[5], g[6], g[7]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int a0 = ch * 512 + lane * 8;
+        if (a0 < A) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                atomicAdd(&sAcc[a0 + k], da2[ch][k]);
+                atomicAdd(&sAcc[A + a0 + k], dw[ch][k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 256) {
+        atomicAdd(&dhproj[(long)b * ldh + a], sAcc[a]);
+        atomicAdd(&dwfull[a], sAcc[A + a]);
+    }
+}
+
+// ----------------------------------------------------------------------------- encoder gradient assembly
+// out[order[b]][p][:] = acc[b][p][:] + dmean[b][:] / P     (un-sorts the batch; float4 granules)
+__global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restrict__ acc, const float* __restrict__ dmean,
+                                                          const long* __restrict__ order, float* __restrict__ out, int P, int E) {
+    const int b = blockIdx.y;
+    const long per = (long)P * E / 4, i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const int e4 = (int)(i % (E / 4));
+    const float invP = 1.f / (float)P;
+    const float4 a = reinterpret_cast<const float4*>(acc + (long)b * P * E)[i];
+    const float4 m = reinterpret_cast<const float4*>(dmean + (long)b * E)[e4];
+    reinterpret_cast<float4*>(out + order[b] * (long)P * E)[i] =
+        make_float4(a.x + m.x * invP, a.y + m.y * invP, a.z + m.z * invP, a.w + m.w * invP);
+}
+
+}  // namespace ppv
+
+using namespace ppv;
+
+extern "C" {
+
+static inline int dec_slab(int P) { return 48 < P ? 48 : P; }
+
+// models.py:181-183,151 : gather by the length sort, bf16 copy and per-image mean.  mean [B][E] PRE-ZEROED.  E % 8 == 0.
+int ppv_dec_prepare(const float* enc, const long* order, void* encs, float* mean, int B, int P, int E, hipStream_t stream) {
+    if (!enc || !order || !encs || !mean) return PPV_ERR_NULL;
+    if (B < 1 || P < 1 || E < 8 || E % 8) return PPV_ERR_BAD_SIZE;
+    const int PT = 16;
+    dec_prepare_kernel<<<dim3(B, (P + PT - 1) / PT), 256, 0, stream>>>(enc, order, (bf16_t*)encs, mean, P, E, PT);
+    return ppv_last_error();
+}
+
+// models.py:83-90,205-206 for the first bt (sorted) images of one time step.
+//   att1 [B][P][A] bf16 (encoder_att WITHOUT bias), hproj [bt][ldh] f32 = [att2 + both biases (A) | f_beta(h) (E)],
+//   wfull [A]; ebuf [bt][P] scratch; alpha_out [bt][P]; awe_save [bt][E]; xh row stride ldx, gated context at x_off.
+int ppv_dec_attend_fwd(const void* att1, const void* encs, const float* hproj, int ldh, const float* wfull, float* ebuf,
+                       float* alpha_out, float* awe_save, float* xh, int ldx, int x_off, int bt, int P, int A, int E,
+                       hipStream_t stream) {
+    if (!att1 || !encs || !hproj || !wfull || !ebuf || !alpha_out || !awe_save || !xh) return PPV_ERR_NULL;
+    if (bt < 1 || A % 8 || E % 8 || A > 2048 || P > 8192 || ldh < A + E) return PPV_ERR_BAD_SIZE;
+    const int PS = dec_slab(P);
+    dec_score_fwd_kernel<<<dim3(bt, (P + PS - 1) / PS), 256, 2 * A * sizeof(float), stream>>>((const bf16_t*)att1, hproj, ldh, wfull,
+                                                                                             ebuf, P, A, PS);
+    dec_ctx_fwd_kernel<<<dim3(bt, (E + 255) / 256), 256, (P + 8 * 256) * sizeof(float), stream>>>(
+        (const bf16_t*)encs, ebuf, hproj, ldh, A, alpha_out, awe_save, xh, ldx, x_off, P, E);
+    return ppv_last_error();
+}
+
+// Adjoint of ppv_dec_attend_fwd for one step.  dxh: gradient of the LSTM input rows (gated context at x_off);
+// dalpha_in [bt][P] or null; dhproj [bt][ldh] with its first A columns PRE-ZEROED (att2 part is accumulated, gate part
+// written); dawe_out [bt][E]; dalpha [bt][P] scratch; datt1 [B][P][A] f32 ACCUMULATED; dwfull [A] ACCUMULATED.
+int ppv_dec_attend_bwd(const void* att1, const void* encs, const float* hproj, int ldh, const float* wfull, const float* alpha,
+                       const float* awe_save, const float* dxh, int ldx, int x_off, const float* dalpha_in, float* dhproj,
+                       float* dawe_out, float* dalpha, float* datt1, float* dwfull, int bt, int P, int A, int E,
+                       hipStream_t stream) {
+    if (!att1 || !encs || !hproj || !wfull || !alpha || !awe_save || !dxh || !dhproj || !dawe_out || !dalpha || !datt1 || !dwfull)
+        return PPV_ERR_NULL;
+    if (bt < 1 || A % 8 || E % 8 || A > 2048 || P > 8192 || ldh < A + E) return PPV_ERR_BAD_SIZE;
+    const int PS = dec_slab(P);
+    dec_ctx_bwd_kernel<<<dim3(bt, (P + PS - 1) / PS), 256, E * sizeof(float), stream>>>(
+        (const bf16_t*)encs, dxh, ldx, x_off, hproj, ldh, A, awe_save, dalpha_in, dhproj, dawe_out, dalpha, P, E, PS);
+    dec_score_bwd_kernel<<<dim3(bt, (P + PS - 1) / PS), 256, 4 * A * sizeof(float), stream>>>(
+        (const bf16_t*)att1, hproj, ldh, wfull, alpha, dalpha, datt1, dhproj, dwfull, P, A, PS);
+    return ppv_last_error();
+}
+
+// torch.nn.LSTMCell pointwise part (models.py:207-210).  h is written to h_a (row stride ld_a) and, if non-null, h_b.
+int ppv_lstm_cell_fwd(const float* z, const float* c_prev, float* gates, float* c_new, float* h_a, int ld_a, float* h_b, int ld_b,
+                      int bt, int D, hipStream_t stream) {
+    if (!z || !c_prev || !gates || !c_new || !h_a) return PPV_ERR_NULL;
+    if (bt < 1 || D < 1) return PPV_ERR_BAD_SIZE;
+    lstm_fwd_kernel<<<(unsigned)(((long)bt * D + 255) / 256), 256, 0, stream>>>(z, c_prev, gates, c_new, h_a, ld_a, h_b, ld_b, bt, D);
+    return ppv_last_error();
+}
+
+int ppv_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh, const float* dc_in, float* dz,
+                      float* dc_prev, int bt, int D, hipStream_t stream) {
+    if (!gates || !c_prev || !c_new || !dh || !dc_in || !dz || !dc_prev) return PPV_ERR_NULL;
+    if (bt < 1 || D < 1) return PPV_ERR_BAD_SIZE;
+    lstm_bwd_kernel<<<(unsigned)(((long)bt * D + 255) / 256), 256, 0, stream>>>(gates, c_prev, c_new, dh, dc_in, dz, dc_prev, bt, D);
+    return ppv_last_error();
+}
+
+// d encoder_out [B][P][E] f32 in the caller's (unsorted) batch order.  E % 4 == 0.
+int ppv_dec_combine(const float* acc, const float* dmean, const long* order, float* out, int B, int P, int E, hipStream_t stream) {
+    if (!acc || !dmean || !order || !out) return PPV_ERR_NULL;
+    if (B < 1 || E % 4) return PPV_ERR_BAD_SIZE;
+    const long per = (long)P * E / 4;
+    dec_combine_kernel<<<dim3((unsigned)((per + 255) / 256), B), 256, 0, stream>>>(acc, dmean, order, out, P, E);
+    return ppv_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+"""Soft-attention LSTM captioner on the MI355X — drop-in for ``DecoderWithAttention`` (Image_Caption/models.py:93-218)
+and its ``Attention`` sub-module (models.py:57-90).  SURVEY.md §8(f)-1.
+
+Same constructor, parameter names (``attention.encoder_att.weight`` …, so reference checkpoints load), ``forward``
+signature and return tuple ``(predictions, sorted captions, decode_lengths, alphas, sort_ind)``.
+
+How the step is organised (result-identical restructuring, not an approximation):
+
+* ``encoder_att(encoder_out)`` does not depend on the time step but the reference evaluates it inside the loop
+  (models.py:83 via :207; 1.36 GMAC per image per step).  Here it runs ONCE, as a bf16 MFMA GEMM (``ppv_conv_gemm``
+  used as a 1x1 convolution over the B*P pixel rows), and its bias moves onto the ``decoder_att`` side.
+* the caption-length sort gathers ``encoder_out`` once, fused with the f32->bf16 copy and the per-image mean
+  (``ppv_dec_prepare``); every step then streams the two per-image tables att1 [B,P,A] and encs [B,P,E] (bf16) through
+  the fused score / softmax / context / gate kernels (``ppv_dec_attend_fwd``).
+* the vocabulary projection (models.py:211) and every weight gradient are batched over all time steps after the loop;
+  the context path's encoder gradient is one batched GEMM alpha^T . d awe, the score path's is accumulated in f32 per
+  step and finished with the bf16 MFMA data-/weight-gradient kernels (``ppv_conv_gemm`` / ``ppv_conv_wgrad``).
+
+Precision: BASELINE.json config 3 (bf16 storage, f32 accumulate) — att1 / encs are bf16; the LSTM state, softmax, all
+reductions and all small per-step GEMMs are f32.  The per-step dense GEMMs (h projections, LSTM gates, vocabulary
+scores) are plain library GEMMs (``torch.addmm`` -> rocBLAS); everything else is libppv_hip.  No CPU path.
+"""
+import torch
+from torch import nn
+
+from . import convops as co
+from ._lib import check, ptr, stream_ptr
+from .convops import L
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+class Attention(nn.Module):
+    """Parameter container with the reference's names (models.py:57-73); the math runs inside _DecoderFn."""
+
+    def __init__(self, encoder_dim, decoder_dim, attention_dim):
+        super().__init__()
+        self.encoder_att = nn.Linear(encoder_dim, attention_dim)
+        self.decoder_att = nn.Linear(decoder_dim, attention_dim)
+        self.full_att = nn.Linear(attention_dim, 1)
+
+
+def _attend_fwd(att1, encs, hproj, wfull, ebuf, alpha, awe, xh, x_off, bt, P, A, E):
+    check(L().ppv_dec_attend_fwd(ptr(att1), ptr(encs), ptr(hproj), hproj.shape[-1], ptr(wfull), ptr(ebuf), ptr(alpha), ptr(awe),
+                                 ptr(xh), xh.shape[-1], x_off, bt, P, A, E, stream_ptr()), "ppv_dec_attend_fwd")
+
+
+class _DecoderFn(torch.autograd.Function):
+    """Whole decoder forward / hand-written BPTT.  Inputs after (module, static info): encoder_out f32 [B,...,E], then
+    the 18 parameters in ``DecoderWithAttention._plist`` order."""
+
+    @staticmethod
+    def forward(ctx, mod, caps, order, dec_len, drop_mask_seed, enc, *params):
+        (w_enc, b_enc, w_dec, b_dec, w_full, b_full, w_emb, w_ih, w_hh, b_ih, b_hh, w_h0, b_h0, w_c0, b_c0, w_fb, b_fb,
+         w_fc, b_fc) = params
+        dev = enc.device
+        B, E = enc.shape[0], enc.shape[-1]
+        P = enc.numel() // (B * E)
+        A, D, M, V = w_enc.shape[0], w_hh.shape[1], w_emb.shape[1], w_fc.shape[0]
+        if E % 128 or A % 128:
+            raise ValueError("ppv_amd decoder: encoder_dim and attention_dim must be multiples of 128 (MFMA GEMM tiles)")
+        T = max(dec_len)
+        bts = [sum(1 for l in dec_len if l > t) for t in range(T)]
+        X = M + E + D                                            # LSTM GEMM input row: [embedding | gated context | h]
+
+        # ---- once per forward
+        enc_c = enc.contiguous().float()
+        encs = torch.empty((B, P, 1, E), dtype=BF16, device=dev)
+        mean = torch.zeros((B, E), dtype=F32, device=dev)
+        check(L().ppv_dec_prepare(ptr(enc_c), ptr(order), ptr(encs), ptr(mean), B, P, E, stream_ptr()), "ppv_dec_prepare")
+        wl_enc = co.weight_layout(w_enc.detach().view(A, E, 1, 1), 0)
+        att1 = co.conv_fwd(encs, wl_enc, 1, 0)                   # [B,P,1,A] bf16, no bias (folded below)
+        w1 = torch.cat([w_dec, w_fb], 0).detach()                # [A+E, D]: decoder_att | f_beta
+        b1 = torch.cat([b_dec + b_enc, b_fb], 0).detach()
+        w2 = torch.cat([w_ih, w_hh], 1).detach()                 # [4D, X]
+        b2 = (b_ih + b_hh).detach()
+        w0 = torch.cat([w_h0, w_c0], 0).detach()                 # [2D, E]
+        b0 = torch.cat([b_h0, b_c0], 0).detach()
+        wfull = w_full.detach().reshape(-1).contiguous()
+        hc0 = torch.addmm(b0, mean, w0.t())                      # models.py:150-155
+
+        XH = torch.zeros((T + 1, B, X), dtype=F32, device=dev)
+        XH[:T, :, :M] = w_emb.detach()[caps[:, :T]].transpose(0, 1)
+        XH[0, :, M + E:] = hc0[:, :D]
+        C = torch.empty((T + 1, B, D), dtype=F32, device=dev)
+        C[0] = hc0[:, D:]
+        HP = torch.zeros((T, B, A + E), dtype=F32, device=dev)
+        AW = torch.zeros((T, B, E), dtype=F32, device=dev)
+        AL = torch.zeros((T, B, P), dtype=F32, device=dev)
+        G = torch.zeros((T, B, 4 * D), dtype=F32, device=dev)
+        HS = torch.zeros((T, B, D), dtype=F32, device=dev)
+        ebuf = torch.empty((B, P), dtype=F32, device=dev)
+        z = torch.empty((B, 4 * D), dtype=F32, device=dev)
+        w1t, w2t = w1.t(), w2.t()
+        for t in range(T):
+            bt = bts[t]
+            torch.addmm(b1, XH[t, :bt, M + E:], w1t, out=HP[t, :bt])
+            _attend_fwd(att1, encs, HP[t], wfull, ebuf, AL[t], AW[t], XH[t], M, bt, P, A, E)
+            torch.addmm(b2, XH[t, :bt], w2t, out=z[:bt])
+            check(L().ppv_lstm_cell_fwd(ptr(z), ptr(C[t]), ptr(G[t]), ptr(C[t + 1]), ptr(HS[t]), D, ptr(XH[t + 1, :, M + E:]), X,
+                                        bt, D, stream_ptr()), "ppv_lstm_cell_fwd")
+        valid = torch.zeros((T, B, 1), dtype=F32, device=dev)
+        for t in range(T):
+            valid[t, :bts[t]] = 1.0
+        if mod.training and mod.p_drop > 0:                      # models.py:211 nn.Dropout
+            keep = 1.0 - mod.p_drop
+            dmask = (torch.rand((T, B, D), device=dev) < keep).to(F32) / keep
+            HD = HS * dmask
+        else:
+            dmask, HD = None, HS
+        preds = torch.addmm(b_fc.detach(), HD.view(T * B, D), w_fc.detach().t()).view(T, B, V)
+        preds.mul_(valid)                                        # positions past a caption's end stay exactly 0 (models.py:194)
+
+        ctx.mod, ctx.dims = mod, (B, P, E, A, D, M, V, T, X)
+        ctx.bts, ctx.caps, ctx.order = bts, caps, order
+        ctx.saved = (encs, att1, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, G, HD, dmask, valid, w_fc.detach(), w_enc.detach())
+        ctx.enc_shape = enc.shape
+        return preds.transpose(0, 1), AL.transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, g_preds, g_alphas):
+        B, P, E, A, D, M, V, T, X = ctx.dims
+        encs, att1, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, G, HD, dmask, valid, w_fc, w_enc = ctx.saved
+        bts, caps, order = ctx.bts, ctx.caps, ctx.order
+        dev = encs.device
+        if g_preds is None:
+            gp = torch.zeros((T, B, V), dtype=F32, device=dev)
+        else:
+            gp = (g_preds.transpose(0, 1).float() * valid).contiguous()   # [T,B,V]; dead positions carry no gradient
+        gp2 = gp.view(T * B, V)
+        d_wfc = gp2.t() @ HD.view(T * B, D)
+        d_bfc = gp2.sum(0)
+        dHS = (gp2 @ w_fc).view(T, B, D)
+        if dmask is not None:
+            dHS = dHS * dmask
+        ga = None if g_alphas is None else (g_alphas.transpose(0, 1).float() * valid).contiguous()
+
+        DZ = torch.zeros((T, B, 4 * D), dtype=F32, device=dev)
+        DHP = torch.zeros((T, B, A + E), dtype=F32, device=dev)
+        DX = torch.zeros((T, B, X), dtype=F32, device=dev)
+        DAW = torch.zeros((T, B, E), dtype=F32, device=dev)
+        datt1 = torch.zeros((B, P, 1, A), dtype=F32, device=dev)
+        dwfull = torch.zeros(A, dtype=F32, device=dev)
+        dalpha = torch.empty((B, P), dtype=F32, device=dev)
+        dh_next = torch.zeros((B, D), dtype=F32, device=dev)
+        dc_a = torch.zeros((B, D), dtype=F32, device=dev)
+        dc_b = torch.zeros((B, D), dtype=F32, device=dev)
+        dh = torch.empty((B, D), dtype=F32, device=dev)
+        for t in range(T - 1, -1, -1):
+            bt = bts[t]
+            torch.add(dHS[t, :bt], dh_next[:bt], out=dh[:bt])
+            check(L().ppv_lstm_cell_bwd(ptr(G[t]), ptr(C[t]), ptr(C[t + 1]), ptr(dh), ptr(dc_a), ptr(DZ[t]), ptr(dc_b), bt, D,
+                                        stream_ptr()), "ppv_lstm_cell_bwd")
+            dc_a, dc_b = dc_b, dc_a                               # rows >= bt of the new dc_a are still zero from earlier steps
+            torch.mm(DZ[t, :bt], w2, out=DX[t, :bt])
+            check(L().ppv_dec_attend_bwd(ptr(att1), ptr(encs), ptr(HP[t]), A + E, ptr(wfull), ptr(AL[t]), ptr(AW[t]), ptr(DX[t]), X, M,
+                                         ptr(ga[t]) if ga is not None else None, ptr(DHP[t]), ptr(DAW[t]), ptr(dalpha),
+                                         ptr(datt1), ptr(dwfull), bt, P, A, E, stream_ptr()), "ppv_dec_attend_bwd")
+            torch.addmm(DX[t, :bt, M + E:], DHP[t, :bt], w1, out=dh_next[:bt])
+
+        # ---- batched over all steps
+        d_w2 = DZ.view(T * B, 4 * D).t() @ XH[:T].view(T * B, X)
+        d_b2 = DZ.sum((0, 1))
+        d_w1 = DHP.view(T * B, A + E).t() @ XH[:T, :, M + E:].reshape(T * B, D)
+        d_b1 = DHP.sum((0, 1))
+        d_emb = torch.zeros((V, M), dtype=F32, device=dev).index_add_(0, caps[:, :T].t().reshape(-1), DX[:, :, :M].reshape(T * B, M))
+        dhc0 = torch.cat([dh_next, dc_a], 1)                      # [B, 2D]
+        d_w0 = dhc0.t() @ mean
+        d_b0 = dhc0.sum(0)
+        dmean = dhc0 @ w0                                         # [B, E]
+
+        # ---- encoder side: score path through the bf16 MFMA kernels, context path as one batched GEMM
+        datt1_bf = datt1.to(BF16)
+        d_wenc = co.conv_wgrad(datt1_bf, encs, 1, 1, 1, 0).view(A, E)
+        g_enc = None
+        if ctx.needs_input_grad[5]:
+            wl_d = co.weight_layout(w_enc.view(A, E, 1, 1), 1)
+            acc = co.conv_dgrad(datt1_bf, wl_d, 1, 0, (P, 1), out_f32=True).view(B, P, E)
+            acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
+            g_enc = torch.empty((B, P, E), dtype=F32, device=dev)
+            check(L().ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_enc), B, P, E, stream_ptr()), "ppv_dec_combine")
+            g_enc = g_enc.view(ctx.enc_shape)
+        d_batt = d_b1[:A]
+        grads = (d_wenc, d_batt, d_w1[:A], d_batt.clone(), dwfull.view(1, A), torch.zeros(1, dtype=F32, device=dev), d_emb,
+                 d_w2[:, :M + E], d_w2[:, M + E:], d_b2, d_b2.clone(), d_w0[:D], d_b0[:D], d_w0[D:], d_b0[D:], d_w1[A:], d_b1[A:],
+                 d_wfc, d_bfc)
+        return (None, None, None, None, None, g_enc) + grads
+
+
+class DecoderWithAttention(nn.Module):
+    """models.py:93-218."""
+
+    def __init__(self, attention_dim, embed_dim, decoder_dim, vocab_size, encoder_dim=2048, dropout=0.5):
+        super().__init__()
+        self.encoder_dim, self.attention_dim, self.embed_dim = encoder_dim, attention_dim, embed_dim
+        self.decoder_dim, self.vocab_size, self.p_drop = decoder_dim, vocab_size, dropout
+        self.attention = Attention(encoder_dim, decoder_dim, attention_dim)
+        self.embedding = nn.Embedding(vocab_size, embed_dim)
+        self.dropout = nn.Dropout(p=dropout)                     # kept for attribute parity; the mask is drawn in _DecoderFn
+        self.decode_step = nn.LSTMCell(embed_dim + encoder_dim, decoder_dim, bias=True)
+        self.init_h = nn.Linear(encoder_dim, decoder_dim)
+        self.init_c = nn.Linear(encoder_dim, decoder_dim)
+        self.f_beta = nn.Linear(decoder_dim, encoder_dim)
+        self.sigmoid = nn.Sigmoid()
+        self.fc = nn.Linear(decoder_dim, vocab_size)
+        self.init_weights()
+
+    def init_weights(self):
+        """models.py:121-127."""
+        self.embedding.weight.data.uniform_(-0.1, 0.1)
+        self.fc.bias.data.fill_(0)
+        self.fc.weight.data.uniform_(-0.1, 0.1)
+
+    def load_pretrained_embeddings(self, embeddings):
+        self.embedding.weight = nn.Parameter(embeddings)
+
+    def fine_tune_embeddings(self, fine_tune=True):
+        for p in self.embedding.parameters():
+            p.requires_grad = fine_tune
+
+    def _plist(self):
+        a, ds = self.attention, self.decode_step
+        return [a.encoder_att.weight, a.encoder_att.bias, a.decoder_att.weight, a.decoder_att.bias, a.full_att.weight,
+                a.full_att.bias, self.embedding.weight, ds.weight_ih, ds.weight_hh, ds.bias_ih, ds.bias_hh, self.init_h.weight,
+                self.init_h.bias, self.init_c.weight, self.init_c.bias, self.f_beta.weight, self.f_beta.bias, self.fc.weight,
+                self.fc.bias]
+
+    def forward(self, encoder_out, encoded_captions, caption_lengths):
+        if not encoder_out.is_cuda:
+            raise RuntimeError("ppv_amd DecoderWithAttention runs on an MI355X (encoder_out must be a cuda tensor); no CPU path")
+        # models.py:181; stable, so equal lengths keep their batch order exactly as the reference's CPU sort leaves them
+        lens, order = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
+        caps = encoded_captions[order]
+        dec_len = (lens - 1).tolist()                                               # models.py:193
+        preds, alphas = _DecoderFn.apply(self, caps, order.contiguous(), dec_len, None, encoder_out, *self._plist())
+        return preds, caps, dec_len, alphas, order

@@ -264,7 +264,7 @@ def gen_decoder():
     from torch.nn.utils.rnn import pack_padded_sequence
     ref_models.device = torch.device("cpu")                   # models.py:5 hard-wires cuda:0
     g = torch.Generator().manual_seed(0)
-    B, S, E, A, M, D, V, L = 5, 6, 64, 32, 24, 40, 50, 11
+    B, S, E, A, M, D, V, L = 5, 6, 128, 128, 24, 40, 50, 11   # E, A: multiples of 128 (the HIP path's MFMA tiles)
     dec = ref_models.DecoderWithAttention(attention_dim=A, embed_dim=M, decoder_dim=D, vocab_size=V, encoder_dim=E, dropout=0.3).eval()
     fill_by_name(dec)
     with torch.no_grad():

@@ -163,6 +163,8 @@ int ppv_lstm_cell_fwd(const float* z, const float* c_prev, float* gates, float* 
                       int bt, int D, ppv_stream_t stream);
 int ppv_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh, const float* dc_in, float* dz,
                       float* dc_prev, int bt, int D, ppv_stream_t stream);
+int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
+                     int B, int P, int E, int T, ppv_stream_t stream);
 int ppv_dec_combine(const float* acc, const float* dmean, const long* order, float* out, int B, int P, int E, ppv_stream_t stream);
 
 /* backward of the FD camera: sensor image -> PSF (Optics.py:126-128), PSF + losses -> height map (Optics.py:92-120),

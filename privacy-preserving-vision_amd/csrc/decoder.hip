@@ -94,20 +94,34 @@ __global__ __launch_bounds__(256) void dec_score_fwd_kernel(const bf16_t* __rest
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int p = p0 + wave; p < p1; p += 4) {
-        const bf16_t* row = att1 + ((long)b * P + p) * A;
-        float acc = 0.f;
+    // four pixel rows per wave per trip: their loads are issued together (4 x 1 KB in flight per wave)
+    for (int pb = p0 + wave * 4; pb < p1; pb += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int a0 = lane * 8; a0 < A; a0 += 512) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row + a0);
-            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+            uint4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc += fmaxf(bflo(w4[k]) + sA2[a0 + 2 * k], 0.f) * sW[a0 + 2 * k];
-                acc += fmaxf(bfhi(w4[k]) + sA2[a0 + 2 * k + 1], 0.f) * sW[a0 + 2 * k + 1];
+            for (int j = 0; j < 4; ++j) {
+                const int p = min(pb + j, p1 - 1);
+                v[j] = *reinterpret_cast<const uint4*>(att1 + ((long)b * P + p) * A + a0);
+            }
+            float a2[8], w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a2[k] = sA2[a0 + k]; w[k] = sW[a0 + k]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[j] += fmaxf(bflo(w4[k]) + a2[2 * k], 0.f) * w[2 * k];
+                    acc[j] += fmaxf(bfhi(w4[k]) + a2[2 * k + 1], 0.f) * w[2 * k + 1];
+                }
             }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) ebuf[(long)b * P + p] = acc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = wave_sum(acc[j]);
+            if (lane == 0 && pb + j < p1) ebuf[(long)b * P + pb + j] = r;
+        }
     }
 }
 
@@ -330,6 +344,40 @@ __global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restric
         make_float4(a.x + m.x * invP, a.y + m.y * invP, a.z + m.z * invP, a.w + m.w * invP);
 }
 
+// out[order[b]][p][e] = part[b][p][e] + dmean[b][e] / P + sum_t alpha[t][b][p] * dawe[t][b][e]
+// (score path + init_h/init_c path + context path in ONE pass over the 4 * B * P * E bytes; un-sorts the batch).
+// grid (B, ceil(P / 48), E / 256); alpha [T][B][P], dawe [T][B][E]; LDS: [T][256] d awe + [T][48] alpha.
+__global__ __launch_bounds__(256) void dec_enc_grad_kernel(const float* __restrict__ part, const float* __restrict__ dmean,
+                                                           const float* __restrict__ alpha, const float* __restrict__ dawe,
+                                                           const long* __restrict__ order, float* __restrict__ out, int B, int P,
+                                                           int E, int T) {
+    extern __shared__ float sm[];
+    float* sD = sm;                  // [T][256]
+    float* sA = sm + T * 256;        // [T][48]
+    const int b = blockIdx.x, p0 = blockIdx.y * 48, np = min(48, P - p0), c0 = blockIdx.z * 256, tid = threadIdx.x;
+    for (int i = tid; i < T * 256; i += 256) sD[i] = dawe[((long)(i >> 8) * B + b) * E + c0 + (i & 255)];
+    for (int i = tid; i < T * 48; i += 256) {
+        const int t = i / 48, j = i % 48;
+        sA[i] = j < np ? alpha[((long)t * B + b) * P + p0 + j] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = (tid & 63) * 4, pw = tid >> 6;
+    const float invP = 1.f / (float)P;
+    const float4 m = *reinterpret_cast<const float4*>(dmean + (long)b * E + c0 + c4);
+    float* dst = out + order[b] * (long)P * E;
+    for (int j = pw; j < np; j += 4) {
+        const long off = (long)(p0 + j) * E + c0 + c4;
+        float4 a = *reinterpret_cast<const float4*>(part + (long)b * P * E + off);
+        a.x += m.x * invP; a.y += m.y * invP; a.z += m.z * invP; a.w += m.w * invP;
+        for (int t = 0; t < T; ++t) {
+            const float w = sA[t * 48 + j];
+            const float4 d = *reinterpret_cast<const float4*>(sD + t * 256 + c4);
+            a.x += w * d.x; a.y += w * d.y; a.z += w * d.z; a.w += w * d.w;
+        }
+        *reinterpret_cast<float4*>(dst + off) = a;
+    }
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -404,6 +452,22 @@ int ppv_dec_combine(const float* acc, const float* dmean, const long* order, flo
     if (B < 1 || E % 4) return PPV_ERR_BAD_SIZE;
     const long per = (long)P * E / 4;
     dec_combine_kernel<<<dim3((unsigned)((per + 255) / 256), B), 256, 0, stream>>>(acc, dmean, order, out, P, E);
+    return ppv_last_error();
+}
+
+// d encoder_out in one pass (see dec_enc_grad_kernel).  part [B][P][E] f32 = score-path gradient (sorted order),
+// alpha [T][B][P], dawe [T][B][E] (rows of finished captions zero).  E % 256 == 0, T <= 128.
+int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
+                     int B, int P, int E, int T, hipStream_t stream) {
+    if (!part || !dmean || !alpha || !dawe || !order || !out) return PPV_ERR_NULL;
+    if (B < 1 || P < 1 || E % 256 || T < 1 || T > 128) return PPV_ERR_BAD_SIZE;
+    const size_t lds = (size_t)T * (256 + 48) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dec_enc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4);
+        attr_set = true;
+    }
+    dec_enc_grad_kernel<<<dim3(B, (P + 47) / 48, E / 256), 256, lds, stream>>>(part, dmean, alpha, dawe, order, out, B, P, E, T);
     return ppv_last_error();
 }
 

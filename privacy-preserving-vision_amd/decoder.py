@@ -176,9 +176,13 @@ class _DecoderFn(torch.autograd.Function):
         if ctx.needs_input_grad[5]:
             wl_d = co.weight_layout(w_enc.view(A, E, 1, 1), 1)
             acc = co.conv_dgrad(datt1_bf, wl_d, 1, 0, (P, 1), out_f32=True).view(B, P, E)
-            acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
             g_enc = torch.empty((B, P, E), dtype=F32, device=dev)
-            check(L().ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_enc), B, P, E, stream_ptr()), "ppv_dec_combine")
+            if E % 256 == 0 and T <= 128:                         # one pass: + alpha^T . d awe + d mean / P, un-sorted
+                check(L().ppv_dec_enc_grad(ptr(acc), ptr(dmean), ptr(AL), ptr(DAW), ptr(order), ptr(g_enc), B, P, E, T,
+                                           stream_ptr()), "ppv_dec_enc_grad")
+            else:
+                acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
+                check(L().ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_enc), B, P, E, stream_ptr()), "ppv_dec_combine")
             g_enc = g_enc.view(ctx.enc_shape)
         d_batt = d_b1[:A]
         grads = (d_wenc, d_batt, d_w1[:A], d_batt.clone(), dwfull.view(1, A), torch.zeros(1, dtype=F32, device=dev), d_emb,

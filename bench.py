@@ -62,19 +62,33 @@ class _MeanSquare(torch.autograd.Function):
         return x * (g * (2.0 / x.numel()))
 
 
-def make_step(camera, encoder, batch, device, sync):
+def make_step(camera, encoder, batch, device, sync, decoder=None):
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
     opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True)
     opt_cam = torch.optim.Adam(cam_params, lr=5e-7)
     rank = dist.get_rank() if dist.is_initialized() else 0
     imgs = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(device)
+    if decoder is not None:                                                       # BASELINE.json config 3 / 5
+        from torch.nn.utils.rnn import pack_padded_sequence
+        dec_params = [p for p in decoder.parameters() if p.requires_grad]
+        opt_dec = torch.optim.Adam(dec_params, lr=4e-4, fused=True)                # train.py:33,100-101
+        gen = torch.Generator().manual_seed(100 + rank)
+        caps = torch.randint(0, decoder.vocab_size, (batch, 52), generator=gen).to(device)
+        caplens = torch.randint(9, 19, (batch, 1), generator=gen).to(device)      # COCO-like lengths incl. <start>/<end>
 
     def step():
         sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
         enc_out = encoder(sensor)
-        # stand-in for CE + attention regulariser (the decoder is a next row): one read forward, one write backward
-        loss_head = _MeanSquare.apply(enc_out)
+        if decoder is not None:                                                   # train.py:274-282
+            scores, caps_sorted, dec_len, alphas, _ = decoder(enc_out, caps, caplens)
+            sc = pack_padded_sequence(scores, dec_len, batch_first=True).data
+            tg = pack_padded_sequence(caps_sorted[:, 1:], dec_len, batch_first=True).data
+            loss_head = torch.nn.functional.cross_entropy(sc, tg) + 1.0 * ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+            opt_dec.zero_grad(set_to_none=True)
+        else:
+            # stand-in for CE + attention regulariser: one read of encoder_out forward, one dense gradient backward
+            loss_head = _MeanSquare.apply(enc_out)
         loss_cam = 1 - torch.nn.functional.mse_loss(imgs, sensor)
         loss = 0.4 * loss_head + 6 * loss_cam + 30 * loss_psf
         opt_enc.zero_grad(set_to_none=True)
@@ -87,6 +101,13 @@ def make_step(camera, encoder, batch, device, sync):
         torch._foreach_clamp_min_(grads, -5.0)
         torch._foreach_clamp_max_(grads, 5.0)
         opt_enc.step()
+        if decoder is not None:
+            dgr = [p.grad for p in dec_params]
+            if sync is not None:
+                sync.reduce_now(dgr)
+            torch._foreach_clamp_min_(dgr, -5.0)
+            torch._foreach_clamp_max_(dgr, 5.0)
+            opt_dec.step()
         camera.zernike_coeffs_train[1:].data.clamp_(-1, 1)                        # train.py:322-323
         return loss
 
@@ -185,6 +206,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--decoder", action="store_true",
+                    help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
+                         "default is the headline Camera+ResNet-101 metric")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,7 +233,13 @@ def main():
         from ppv_amd.dist_sync import GradSync
         sync = GradSync(bucket_mb=32)
         encoder.grad_sync = sync
-    step, params = make_step(camera, encoder, args.batch, device, sync)
+    decoder = None
+    if args.decoder:
+        from ppv_amd.decoder import DecoderWithAttention
+        torch.manual_seed(3)
+        decoder = DecoderWithAttention(attention_dim=512, embed_dim=512, decoder_dim=512, vocab_size=9490, dropout=0.3).to(device)
+        decoder.train()
+    step, params = make_step(camera, encoder, args.batch, device, sync, decoder)
 
     for _ in range(args.warmup):
         step()
@@ -232,12 +262,14 @@ def main():
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
         line = {
-            "metric": "images/sec fwd+bwd, Camera+ResNet-101 @256^2", "value": round(value, 1), "unit": "images/sec",
+            "metric": "images/sec fwd+bwd, Camera+ResNet-101" + ("+attention decoder" if args.decoder else "") + " @256^2",
+            "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "IC OpticsZernike camera (896^2 wave grid, 350 Zernike terms, prueba '3') + ResNet-101 "
                                    "Encoder, fwd+bwd+Adam, 256x256; camera fp32/fp64, trunk bf16 storage + fp32 accumulate; "
-                                   "caption decoder not included (next row)",
+                                   + ("soft-attention LSTM decoder (512-d, 9490 words, captions of 9-18 tokens, CE + attention regulariser)"
+                                      if args.decoder else "caption decoder not included (bench.py --decoder adds it)"),
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "trunk_mfma_frac_of_peak": round(value / world * TRUNK_GFLOP_PER_IMG * 1e9 / (PEAK_BF16_DENSE_TFLOPS * 1e12), 4),

@@ -82,8 +82,10 @@ int ppv_zernike_max_order(void);
  *   forward: a = stride, off = -pad, div = 1, Wt = [Cout][R][S][Cin];
  *   dgrad:   a = 1, off = -(k-1-pad), div = stride, Wt = [Cin][R][S][Cout] taps flipped.
  * stat_part [stat_rows][2][N]: PRE-ZEROED partial (sum, sum of squares) of the bf16-rounded outputs (train-mode BN;
- * row tiles fold into row tile % stat_rows with f32 atomics; ppv_conv_stat_tiles(M) gives stat_rows) or NULL; addend [M][N] bf16 is added before rounding (residual-gradient accumulation) or NULL. */
-int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend,
+ * row tiles fold into row tile % stat_rows with f32 atomics; ppv_conv_stat_tiles(M) gives stat_rows) or NULL; addend [M][N] bf16 is added before rounding (residual-gradient accumulation) or NULL;
+ * mask_src [M][N] bf16 or NULL: output lanes whose mask_src lane is <= 0 are stored as 0 (the ReLU backward of the tensor
+ * the data gradient flows into, torchvision Bottleneck `out = relu(out + identity)`, folded into the store). */
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_src,
                   const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a,
                   int off, int div, int out_f32, int stat_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
@@ -116,7 +118,8 @@ int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, in
 int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* gpre, int B, int H, int W, int C,
                          ppv_stream_t stream);
 int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, ppv_stream_t stream);
-int ppv_adaptive_pool_bwd(const void* gy, void* gx, int B, int H, int W, int C, int E, int g_f32, ppv_stream_t stream);
+int ppv_adaptive_pool_bwd(const void* gy, void* gx, const void* mask_src, int B, int H, int W, int C, int E, int g_f32,
+                          ppv_stream_t stream);
 
 /* ---- FD camera PSF: Face-DeId/Camera/Optics.py:92-120 (+ losses :113,:124-125), complex64, N in {256, 512} ------
  * base = rad*(t*focus), chirp1, chirp3 [3][N][N] c64 and chirp2T [3][kx][ky] c64 are cached constants (Optics.py:94-107);

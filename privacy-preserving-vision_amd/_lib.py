@@ -61,7 +61,7 @@ PROTOTYPES = {
     "ppv_zernike_contract": (_I, [_P, _P, _P, _I, _L, _P]),
     "ppv_fd_psf_workspace_bytes": (_Z, [_I]),
     "ppv_fd_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
-    "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
+    "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
     "ppv_weight_layout_multi": (_I, [_P, _I, _I, _P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
@@ -79,7 +79,7 @@ PROTOTYPES = {
     "ppv_bn_relu_maxpool": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_maxpool_relu_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_adaptive_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "ppv_adaptive_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ppv_adaptive_pool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

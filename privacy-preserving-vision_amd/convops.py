@@ -98,14 +98,15 @@ def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
     out = torch.empty((B, Ho, Wo, Cout), dtype=F32 if out_f32 else BF16, device=x.device)
     kind = "conv_gemm<128>" if Cout % 128 == 0 else "conv_gemm<64>"
     _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
-        L().ppv_conv_gemm(ptr(x), ptr(wt), ptr(out), ptr(stat_part), None, ptr(zero_page(x.device)), B, H, W, Cin,
+        L().ppv_conv_gemm(ptr(x), ptr(wt), ptr(out), ptr(stat_part), None, None, ptr(zero_page(x.device)), B, H, W, Cin,
                           Ho, Wo, Cout, R, S, stride, -pad, 1, int(out_f32),
                           0 if stat_part is None else stat_part.shape[0], stream_ptr()), "ppv_conv_gemm"))
     return out
 
 
-def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False):
-    """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend)."""
+def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_of=None):
+    """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend);
+    relu_of: the conv input itself when it is a ReLU output -> lanes where it is <= 0 get a zero gradient."""
     B, Ho, Wo, Cout = g.shape
     Cin, R, S, _ = wd.shape
     H, W = in_hw
@@ -113,7 +114,7 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False):
     kind = "conv_gemm<128>" if Cin % 128 == 0 else "conv_gemm<64>"
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
     _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
-        L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
+        L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(relu_of), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
                           H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), 0, stream_ptr()), "ppv_conv_gemm"))
     return out
 
@@ -157,7 +158,7 @@ def stem_dgrad(g_raw, wsd):
     """g_raw [B,Ho,Wo,64] bf16 -> d/d(img) [B,3,2Ho,2Wo] f32 NCHW."""
     B, Ho, Wo, _ = g_raw.shape
     tmp = torch.empty((B * Ho * Wo, 16), dtype=F32, device=g_raw.device)
-    check(L().ppv_conv_gemm(ptr(g_raw), ptr(wsd), ptr(tmp), None, None, ptr(zero_page(g_raw.device)), B, Ho, Wo, 64,
+    check(L().ppv_conv_gemm(ptr(g_raw), ptr(wsd), ptr(tmp), None, None, None, ptr(zero_page(g_raw.device)), B, Ho, Wo, 64,
                             Ho, Wo, 16, 4, 4, 1, -1, 1, 1, 0, stream_ptr()), "ppv_conv_gemm(stem dgrad)")
     out = torch.empty((B, 3, 2 * Ho, 2 * Wo), dtype=F32, device=g_raw.device)
     check(L().ppv_stem_dgrad_scatter(ptr(tmp), ptr(out), B, Ho, Wo, stream_ptr()), "ppv_stem_dgrad_scatter")
@@ -225,10 +226,11 @@ def adaptive_pool_fwd(x, E, out_dtype=F32):
     return y
 
 
-def adaptive_pool_bwd(gy, in_hw):
+def adaptive_pool_bwd(gy, in_hw, relu_of=None):
+    """relu_of: the pooled tensor (a ReLU output) -> its mask is applied to the returned gradient."""
     B, E, _, C = gy.shape
     H, W = in_hw
     gx = torch.empty((B, H, W, C), dtype=BF16, device=gy.device)
-    check(L().ppv_adaptive_pool_bwd(ptr(gy.contiguous()), ptr(gx), B, H, W, C, E, int(gy.dtype == F32), stream_ptr()),
+    check(L().ppv_adaptive_pool_bwd(ptr(gy.contiguous()), ptr(gx), ptr(relu_of), B, H, W, C, E, int(gy.dtype == F32), stream_ptr()),
           "ppv_adaptive_pool_bwd")
     return gx

@@ -42,6 +42,13 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
     return __builtin_bit_cast(float, (unsigned)h << 16);
 }
 
+// keep the bf16 lanes of v whose mask_src lane is > 0 (ReLU mask of the tensor the gradient flows into)
+__device__ __forceinline__ uint4 relu_mask8(uint4 v, uint4 m) {
+    auto keep = [](unsigned w) { return ((short)(w & 0xffffu) > 0 ? 0xffffu : 0u) | ((int)w > 0xffff ? 0xffff0000u : 0u); };
+    v.x &= keep(m.x); v.y &= keep(m.y); v.z &= keep(m.z); v.w &= keep(m.w);
+    return v;
+}
+
 #define GLDS16(gptr, lptr)                                                                                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                  \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
@@ -52,7 +59,7 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
 template <int BN, int WM, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                            void* __restrict__ Out, float* __restrict__ stat_part,
-                                                           const bf16_t* __restrict__ addend,
+                                                           const bf16_t* __restrict__ addend, const bf16_t* __restrict__ mask_src,
                                                            const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                            int tiles_n, int stat_rows) {
     constexpr int BM = 128, BK = 64, WN = 4 / WM;
@@ -226,7 +233,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
         const int row = idx / CPR, ch = idx % CPR;
         const long m = m0 + row;
         if (idx < BM * CPR && m < g.M)
-            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+        {
+            uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+            if (mask_src) v = relu_mask8(v, *reinterpret_cast<const uint4*>(mask_src + m * g.N + n0 + ch * 8));
+            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
+        }
     }
 }
 
@@ -245,7 +256,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile(
 template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
-                                                                   const bf16_t* __restrict__ addend,
+                                                                   const bf16_t* __restrict__ addend, const bf16_t* __restrict__ mask_src,
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                                    int tiles_n, int stat_rows) {
     constexpr int NT = BM * 2, NWAVE = NT / 64;
@@ -457,7 +468,11 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                     const int row = idx / CPR, ch = idx % CPR;
                     const long m = m0 + pass * HR + row;
                     if (idx < HR * CPR && m < g.M)
-                        *reinterpret_cast<uint4*>(outp + m * g.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(sOh + row * LDO + ch * 16);
+                    {
+                        uint4 v = *reinterpret_cast<const uint4*>(sOh + row * LDO + ch * 16);
+                        if (mask_src) v = relu_mask8(v, *reinterpret_cast<const uint4*>(mask_src + m * g.N + n0 + ch * 8));
+                        *reinterpret_cast<uint4*>(outp + m * g.N + n0 + ch * 8) = v;
+                    }
                 }
                 __syncthreads();
             }
@@ -528,7 +543,11 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         const int row = idx / CPR, ch = idx % CPR;
         const long m = m0 + row;
         if (idx < BM * CPR && m < g.M)
-            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+        {
+            uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+            if (mask_src) v = relu_mask8(v, *reinterpret_cast<const uint4*>(mask_src + m * g.N + n0 + ch * 8));
+            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
+        }
     }
 }
 
@@ -591,8 +610,10 @@ int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
 // Generic NHWC bf16 gather-GEMM convolution (see file header).  X [B,Hs,Ws,Cs] bf16, Wt [N][R*S*Cs] bf16,
 // out [B*Ho*Wo][N] bf16 (out_f32 = 0) or f32 (out_f32 = 1: parity tests and the stem data gradient),
 // stat_part [stat_rows][2][N] f32 BN partial sums, PRE-ZEROED by the caller (may be null), addend [M][N] bf16 (may be null),
-// zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
-int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* zero_page,
+// mask_src [M][N] bf16 (may be null): output lanes whose mask_src lane is <= 0 are zeroed (ReLU backward folded into the
+// data-gradient store); zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_src,
+                  const void* zero_page,
                   int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
                   int out_f32, int stat_rows, hipStream_t stream) {
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
@@ -606,11 +627,13 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     const bf16_t* x = (const bf16_t*)X;
     const bf16_t* w = (const bf16_t*)Wt;
     const bf16_t* ad = (const bf16_t*)addend;
+    const bf16_t* mk = (const bf16_t*)mask_src;
+    if (mk && out_f32) return PPV_ERR_BAD_SIZE;                 // the mask applies to the bf16 store path only
     const bf16_t* z = (const bf16_t*)zero_page;
 #define PPV_LAUNCH(BN_, WM_, TN_)                                                                                       \
     do {                                                                                                                \
-        if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows); \
-        else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, z, g, TN_, stat_rows);        \
+        if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, mk, z, g, TN_, stat_rows); \
+        else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, mk, z, g, TN_, stat_rows);        \
     } while (0)
 #define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_)                                                                                  \
     do {                                                                                                                \
@@ -624,8 +647,8 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
             (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, z, g, tn, stat_rows);              \
-        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, z, g, tn, stat_rows);                      \
+        if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows);              \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows);                      \
     } while (0)
     // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages (BK 64),
     // 4 = 256 x 128 x 3 stages of BK 32, two workgroups per CU

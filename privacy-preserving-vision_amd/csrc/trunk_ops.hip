@@ -296,8 +296,9 @@ __global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const bf16_t* __
 }
 
 template <typename TG>
-__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const TG* __restrict__ gy, bf16_t* __restrict__ gx, int B, int H,
-                                                                int W, int C, int E) {
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const TG* __restrict__ gy, bf16_t* __restrict__ gx,
+                                                                const bf16_t* __restrict__ mask_src, int B, int H, int W, int C,
+                                                                int E) {
     const int c8n = C / 8;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long tot = (long)B * H * W * c8n;
@@ -321,6 +322,11 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const TG* __rest
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += (float)g[k] * inv;
         }
+    }
+    if (mask_src) {                                   // ReLU backward of the tensor that was pooled (y > 0)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((short)mask_src[i * 8 + k] <= 0) acc[k] = 0.f;
     }
     store8(gx + i * 8, acc);
 }
@@ -425,12 +431,14 @@ int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, in
     return ppv_last_error();
 }
 
-int ppv_adaptive_pool_bwd(const void* gy, void* gx, int B, int H, int W, int C, int E, int g_f32, hipStream_t stream) {
+// mask_src (bf16 [B][H][W][C], may be null): the pooled tensor itself; lanes where it is <= 0 get a zero gradient.
+int ppv_adaptive_pool_bwd(const void* gy, void* gx, const void* mask_src, int B, int H, int W, int C, int E, int g_f32,
+                          hipStream_t stream) {
     if (!gy || !gx) return PPV_ERR_NULL;
     const long tot = (long)B * H * W * (C / 8);
     const unsigned gb = (unsigned)((tot + 255) / 256);
-    if (g_f32) adaptive_pool_bwd_kernel<float><<<gb, 256, 0, stream>>>((const float*)gy, (bf16_t*)gx, B, H, W, C, E);
-    else adaptive_pool_bwd_kernel<__bf16><<<gb, 256, 0, stream>>>((const __bf16*)gy, (bf16_t*)gx, B, H, W, C, E);
+    if (g_f32) adaptive_pool_bwd_kernel<float><<<gb, 256, 0, stream>>>((const float*)gy, (bf16_t*)gx, (const bf16_t*)mask_src, B, H, W, C, E);
+    else adaptive_pool_bwd_kernel<__bf16><<<gb, 256, 0, stream>>>((const __bf16*)gy, (bf16_t*)gx, (const bf16_t*)mask_src, B, H, W, C, E);
     return ppv_last_error();
 }
 

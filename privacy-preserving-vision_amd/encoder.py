@@ -222,24 +222,28 @@ class _TrunkFn(torch.autograd.Function):
                     sync.push(db)
             return gx, gpre
 
-        g = co.adaptive_pool_bwd(g_out.contiguous(), ctx.last_hw)
+        # Gradients between blocks travel PRE-MASKED by the ReLU of the tensor they belong to: the mask of a block's output
+        # (yout > 0) is applied where that gradient is produced (adaptive-pool backward for the last block, the conv1
+        # data-gradient store of the following block otherwise).  bn3 / downsample-bn backward then need neither yout
+        # nor a separate masked copy: -2 tensors of the 4C-wide size per block against one extra mask read.
+        g = co.adaptive_pool_bwd(g_out.contiguous(), ctx.last_hw, relu_of=ctx.blocks[-1][-1])
         taps = getattr(enc, "_debug_block_grads", None)      # tests: per-block (g_out, g_in) taps, last block first
         for blk, sv in zip(reversed(enc._blocks), reversed(ctx.blocks)):
             g_blk_out = g
             r1, r2, r3, rd = blk
             xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout = sv
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
-            gx3, gpre = conv_bn_bwd(r3, g, yout, x3, c3, y2, True, want_gpre=True)
+            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0)
             gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
             gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)       # mask recomputed from x2 (no residual): y2 not read
             gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
             gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2)
             if rd is not None:
-                gxd, _ = conv_bn_bwd(rd, gpre, None, xd, cd, xin, False)
+                gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)
-                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_of=xin)
             else:
-                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gpre)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=g, relu_of=xin)
             if taps is not None:
                 taps.append((g_blk_out, g))
         g_img = None

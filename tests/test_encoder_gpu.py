@@ -90,8 +90,10 @@ def test_resnet101_stagewise_forward_backward():
         yo = ob(xo)
         worst_f = max(worst_f, rel_err(yout.float(), _nhwc(yo)))
         yo.backward(_nchw(g_out_blk))
-        worst_b = max(worst_b, _l2(g_in_blk.float(), _nhwc(xo.grad)))
-        assert _cos(g_in_blk, _nhwc(xo.grad)) > 0.999
+        # gradients travel between blocks already masked by the ReLU that produced the block input (encoder.py backward)
+        g_ref = _nhwc(xo.grad) * (xin.float().cpu() > 0)
+        worst_b = max(worst_b, _l2(g_in_blk.float(), g_ref))
+        assert _cos(g_in_blk, g_ref) > 0.999
         po = dict(ob.named_parameters())
         for n, p in pb.named_parameters():
             if p.requires_grad:

@@ -195,7 +195,118 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
                 D[(long)(m0 + wm * 32 + a * 16 + fk * 4 + j) * ldd + n0 + wn * 32 + c * 16 + fr] = acc[a][c][j] * scale;
 }
 
+// ============================================================================= on-the-fly windowed correlation
+// MI355X counterpart of the reference's only native code, RAFT/alt_cuda_corr/correlation_kernel.cu (corr_forward_kernel
+// :18-119, corr_backward_kernel :122-256), re-thought for wave64 rather than its 4x8-thread blocks with [32][33] tiles:
+//   forward  : ONE WAVE PER PIXEL, LANE = WINDOW POSITION.  The (2r+2)^2 <= 128 window positions of a pixel are spread
+//              over the lanes (two trips); each lane walks its own fmap2 row with 16-byte loads against the pixel's
+//              fmap1 row broadcast from LDS, so the C-long dot products need no cross-lane reduction at all; the window
+//              of products sits in LDS and every lane then blends its four bilinear corners for one or two outputs.
+//              fmap2 (<= 4 MB per level) lives in L2; nothing of size HW x HW is ever written.
+//   backward : ONE WAVE PER PIXEL, LANE = 4 CHANNELS.  d corr is folded back to the window (adjoint of the blend) in LDS,
+//              then the wave sweeps the window: d fmap1 accumulates in registers (plain store, the pixel is owned),
+//              d fmap2 rows take one 16-byte-per-lane f32 atomic burst per window position (as the reference does).
+// Layouts: fmap1 [B][H1][W1][C], fmap2 [B][H2][W2][C] f32 NHWC, coords [B][H1][W1][2] (x, y), out [B][(2r+1)^2][H1][W1],
+// channel = iy + (2r+1) * ix.  coords get no gradient (the reference leaves coords_grad zero).
+__global__ __launch_bounds__(256) void alt_corr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                           const float* __restrict__ coords, float* __restrict__ out, int H1,
+                                                           int W1, int H2, int W2, int C, int r, float scale) {
+    extern __shared__ float sm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rd = 2 * r + 1, wd = rd + 1, WIN = wd * wd;
+    float* sF1 = sm + wave * (C + 128);                       // [C] fmap1 row of this wave's pixel
+    float* sS = sF1 + C;                                      // [<=128] window of dot products
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 4 + wave;
+    if (pix >= H1 * W1) return;                               // (no block-wide barrier below: waves are independent)
+    const float* f1p = f1 + ((long)b * H1 * W1 + pix) * C;
+    for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(sF1 + c) = *reinterpret_cast<const float4*>(f1p + c);
+    const float x = coords[((long)b * H1 * W1 + pix) * 2], y = coords[((long)b * H1 * W1 + pix) * 2 + 1];
+    const float xf = floorf(x), yf = floorf(y);
+    const float dx = x - xf, dy = y - yf;
+    const int x0 = (int)xf - r, y0 = (int)yf - r;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int p = lane; p < WIN; p += 64) {
+        const int iy = p / wd, ix = p % wd;
+        const int h2 = y0 + iy, w2 = x0 + ix;
+        float s = 0.f;
+        if ((unsigned)h2 < (unsigned)H2 && (unsigned)w2 < (unsigned)W2) {
+            const float* q = f2 + (((long)b * H2 + h2) * W2 + w2) * C;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(q + c);
+                const float4 u = *reinterpret_cast<const float4*>(sF1 + c);     // same address in every lane: broadcast
+                a0 = fmaf(v.x, u.x, a0); a1 = fmaf(v.y, u.y, a1); a2 = fmaf(v.z, u.z, a2); a3 = fmaf(v.w, u.w, a3);
+            }
+            s = (a0 + a1) + (a2 + a3);
+        }
+        sS[p] = s * scale;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* o = out + (long)b * rd * rd * H1 * W1 + pix;
+    for (int k = lane; k < rd * rd; k += 64) {
+        const int j = k / rd, i = k % rd;                     // channel k = iy + rd * ix
+        const float v = (1.f - dy) * (1.f - dx) * sS[i * wd + j] + dy * (1.f - dx) * sS[(i + 1) * wd + j] +
+                        (1.f - dy) * dx * sS[i * wd + j + 1] + dy * dx * sS[(i + 1) * wd + j + 1];
+        o[(long)k * H1 * W1] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void alt_corr_bwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                           const float* __restrict__ coords, const float* __restrict__ gout,
+                                                           float* __restrict__ df1, float* __restrict__ df2, int H1, int W1,
+                                                           int H2, int W2, int C, int r, float scale) {
+    __shared__ float sG[4][96], sDS[4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rd = 2 * r + 1, wd = rd + 1, WIN = wd * wd;
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 4 + wave;
+    if (pix >= H1 * W1) return;
+    const float x = coords[((long)b * H1 * W1 + pix) * 2], y = coords[((long)b * H1 * W1 + pix) * 2 + 1];
+    const float xf = floorf(x), yf = floorf(y);
+    const float dx = x - xf, dy = y - yf;
+    const int x0 = (int)xf - r, y0 = (int)yf - r;
+    const float* go = gout + (long)b * rd * rd * H1 * W1 + pix;
+    for (int k = lane; k < rd * rd; k += 64) sG[wave][k] = go[(long)k * H1 * W1] * scale;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int p = lane; p < WIN; p += 64) {                    // adjoint of the four-corner blend
+        const int iy = p / wd, ix = p % wd;
+        float d = 0.f;
+        if (iy < rd && ix < rd) d += (1.f - dy) * (1.f - dx) * sG[wave][iy + rd * ix];
+        if (iy > 0 && ix < rd) d += dy * (1.f - dx) * sG[wave][(iy - 1) + rd * ix];
+        if (iy < rd && ix > 0) d += (1.f - dy) * dx * sG[wave][iy + rd * (ix - 1)];
+        if (iy > 0 && ix > 0) d += dy * dx * sG[wave][(iy - 1) + rd * (ix - 1)];
+        sDS[wave][p] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float* f1p = f1 + ((long)b * H1 * W1 + pix) * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 u = *reinterpret_cast<const float4*>(f1p + c);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < WIN; ++p) {
+            const int h2 = y0 + p / wd, w2 = x0 + p % wd;
+            if ((unsigned)h2 >= (unsigned)H2 || (unsigned)w2 >= (unsigned)W2) continue;       // wave-uniform
+            const float d = sDS[wave][p];
+            const long off = (((long)b * H2 + h2) * W2 + w2) * C + c;
+            if (df1) {
+                const float4 v = *reinterpret_cast<const float4*>(f2 + off);
+                acc.x = fmaf(d, v.x, acc.x); acc.y = fmaf(d, v.y, acc.y); acc.z = fmaf(d, v.z, acc.z); acc.w = fmaf(d, v.w, acc.w);
+            }
+            if (df2) {
+                atomicAdd(df2 + off, d * u.x); atomicAdd(df2 + off + 1, d * u.y);
+                atomicAdd(df2 + off + 2, d * u.z); atomicAdd(df2 + off + 3, d * u.w);
+            }
+        }
+        if (df1) *reinterpret_cast<float4*>(df1 + ((long)b * H1 * W1 + pix) * C + c) = acc;
+    }
+}
+
 }  // namespace ppv
+
 
 extern "C" {
 
@@ -252,6 +363,30 @@ int ppv_corr_volume_bwd(const float* gcorr, const float* f1, const float* f2, fl
     if (g_f1) ppv::sgemm_mfma_kernel<<<grid, 256, 0, stream>>>(f2, gcorr, g_f1, HW, HW, HW, HW, 1, scale, (long)C * HW, (long)HW * HW, (long)C * HW);
     // g_f2[c][j] = scale * sum_i f1[c][i] * G[i][j]   (B operand stored [K = i][N = j])
     if (g_f2) ppv::sgemm_mfma_kernel<<<grid, 256, 0, stream>>>(f1, gcorr, g_f2, HW, HW, HW, HW, 0, scale, (long)C * HW, (long)HW * HW, (long)C * HW);
+    return ppv_last_error();
+}
+
+// On-the-fly windowed correlation of one pyramid level (AlternateCorrBlock, corr.py:63-91 + alt_cuda_corr forward):
+// out [B][(2r+1)^2][H1][W1] = blend of <fmap1[b,h1,w1,:], fmap2[b, floor(y)-r+iy, floor(x)-r+ix, :]> * scale.
+// fmap1 [B][H1][W1][C], fmap2 [B][H2][W2][C] f32 NHWC, coords [B][H1][W1][2] (x, y).  C % 4 == 0, 1 <= r <= 4.
+int ppv_alt_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int H1, int W1, int H2,
+                     int W2, int C, int r, float scale, hipStream_t stream) {
+    if (!fmap1 || !fmap2 || !coords || !out) return PPV_ERR_NULL;
+    if (C % 4 || C < 4 || r < 1 || r > 4 || B < 1) return PPV_ERR_BAD_SIZE;
+    const size_t lds = 4 * (size_t)(C + 128) * sizeof(float);
+    if (lds > 64 * 1024) return PPV_ERR_BAD_SIZE;
+    ppv::alt_corr_fwd_kernel<<<dim3((H1 * W1 + 3) / 4, B), 256, lds, stream>>>(fmap1, fmap2, coords, out, H1, W1, H2, W2, C, r, scale);
+    return ppv_last_error();
+}
+
+// Adjoint (alt_cuda_corr backward): d_fmap1 [B][H1][W1][C] WRITTEN, d_fmap2 [B][H2][W2][C] ACCUMULATED with f32 atomics
+// (caller zeroes it); either may be null.  coords receive no gradient, as in the reference.
+int ppv_alt_corr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* gout, float* d_fmap1,
+                     float* d_fmap2, int B, int H1, int W1, int H2, int W2, int C, int r, float scale, hipStream_t stream) {
+    if (!fmap1 || !fmap2 || !coords || !gout) return PPV_ERR_NULL;
+    if (C % 4 || C < 4 || r < 1 || r > 4 || B < 1) return PPV_ERR_BAD_SIZE;
+    ppv::alt_corr_bwd_kernel<<<dim3((H1 * W1 + 3) / 4, B), 256, 0, stream>>>(fmap1, fmap2, coords, gout, d_fmap1, d_fmap2, H1, W1, H2,
+                                                                          W2, C, r, scale);
     return ppv_last_error();
 }
 

@@ -93,3 +93,58 @@ class CorrBlock:
 
     def __call__(self, coords):
         return _LookupFn.apply(coords, self.radius, self.shape, *self.corr_pyramid)
+
+
+class _AltCorrFn(torch.autograd.Function):
+    """One pyramid level of the on-the-fly correlation (f1, f2 NHWC f32; coords [B,H,W,2])."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, coords, radius):
+        L = _lib.lib()
+        B, H1, W1, C = f1.shape
+        _, H2, W2, _ = f2.shape
+        rd = 2 * radius + 1
+        out = torch.empty((B, rd * rd, H1, W1), dtype=torch.float32, device=f1.device)
+        scale = 1.0 / float(C) ** 0.5
+        check(L.ppv_alt_corr_fwd(ptr(f1), ptr(f2), ptr(coords), ptr(out), B, H1, W1, H2, W2, C, radius, scale, stream_ptr()),
+              "ppv_alt_corr_fwd")
+        ctx.save_for_backward(f1, f2, coords)
+        ctx.radius, ctx.scale = radius, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        f1, f2, coords = ctx.saved_tensors
+        L = _lib.lib()
+        B, H1, W1, C = f1.shape
+        _, H2, W2, _ = f2.shape
+        d1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        d2 = torch.zeros_like(f2) if ctx.needs_input_grad[1] else None
+        check(L.ppv_alt_corr_bwd(ptr(f1), ptr(f2), ptr(coords), ptr(g.contiguous()), ptr(d1), ptr(d2), B, H1, W1, H2, W2, C,
+                                 ctx.radius, ctx.scale, stream_ptr()), "ppv_alt_corr_bwd")
+        return d1, d2, None, None
+
+
+class AlternateCorrBlock:
+    """Drop-in for ``Face-DeId/RAFT/core/corr.py:63 AlternateCorrBlock`` — the memory-efficient correlation that the
+    reference backs with its CUDA extension ``alt_cuda_corr`` (and never wires into autograd; here gradients reach both
+    feature maps).  Same constructor and ``__call__(coords)``; output equals ``CorrBlock``'s (the pooled-feature and
+    pooled-volume pyramids are the same linear map) without ever materialising the HW x HW volume."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        import torch.nn.functional as F
+        if not fmap1.is_cuda:
+            raise RuntimeError("ppv_amd AlternateCorrBlock runs on an MI355X (fmap1/fmap2 must be cuda tensors); no CPU path")
+        self.num_levels, self.radius = num_levels, radius
+        self.f1 = fmap1.float().permute(0, 2, 3, 1).contiguous()            # corr.py:82: level-0 fmap1 at every level
+        self.f2 = []
+        f2 = fmap2.float()
+        for i in range(num_levels):
+            self.f2.append(f2.permute(0, 2, 3, 1).contiguous())
+            f2 = F.avg_pool2d(f2, 2, stride=2)                               # corr.py:72-73
+
+    def __call__(self, coords):
+        c = coords.float().permute(0, 2, 3, 1)
+        B, H, W, _ = c.shape
+        outs = [_AltCorrFn.apply(self.f1, self.f2[i], (c / 2 ** i).contiguous(), self.radius) for i in range(self.num_levels)]
+        return torch.stack(outs, dim=1).reshape(B, -1, H, W)

@@ -63,3 +63,36 @@ def test_hip_corrblock_backward_matches_oracle():
     blk = CorrBlock(b1, b2)
     ((blk(c1.cuda()) * w1.cuda()).sum() + (blk(c2.cuda()) * w2.cuda()).sum()).backward()
     assert rel_err(b1.grad, a1.grad) < 1e-4 and rel_err(b2.grad, a2.grad) < 1e-4
+
+
+def test_alt_corr_oracle_matches_reference_golden():
+    """The on-the-fly formulation (AlternateCorrBlock + alt_cuda_corr semantics) restated in oracle/corr.py equals the
+    reference CorrBlock's own output on the golden inputs (the two are the same linear map)."""
+    from oracle import corr as oc
+    g = load_golden("corr.npz")
+    out = oc.alt_corr(torch.from_numpy(g["f1"]), torch.from_numpy(g["f2"]), torch.from_numpy(g["coords"]))
+    assert rel_err(out, g["out"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_alt_corr_hip_matches_golden_and_oracle_grads():
+    from oracle import corr as oc
+    from ppv_amd.raft_corr import AlternateCorrBlock
+    g = load_golden("corr.npz")
+    f1, f2, coords = (torch.from_numpy(g[k]) for k in ("f1", "f2", "coords"))
+    a1, a2 = f1.cuda().requires_grad_(True), f2.cuda().requires_grad_(True)
+    out = AlternateCorrBlock(a1, a2, num_levels=4, radius=4)(coords.cuda())
+    assert out.shape == g["out"].shape and rel_err(out, g["out"]) < 1e-5
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
+    (out * w.cuda()).sum().backward()
+    o1, o2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    (oc.alt_corr(o1, o2, coords) * w).sum().backward()
+    assert rel_err(a1.grad, o1.grad) < 1e-4 and rel_err(a2.grad, o2.grad) < 1e-4
+    # a second shape: RAFT's real channel count, batch 2, coordinates partly outside the map, radius 3
+    gen = torch.Generator().manual_seed(5)
+    f1, f2 = torch.randn(2, 256, 16, 24, generator=gen), torch.randn(2, 256, 16, 24, generator=gen)
+    ys, xs = torch.meshgrid(torch.arange(16), torch.arange(24), indexing="ij")
+    coords = torch.stack([xs, ys], 0).float()[None].repeat(2, 1, 1, 1) + 6.0 * torch.randn(2, 2, 16, 24, generator=gen)
+    want = oc.alt_corr(f1, f2, coords, num_levels=3, radius=3)
+    got = AlternateCorrBlock(f1.cuda(), f2.cuda(), num_levels=3, radius=3)(coords.cuda())
+    assert rel_err(got, want) < 1e-5

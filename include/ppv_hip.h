@@ -152,12 +152,13 @@ int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums
                  int nch, int split, int nsum, int up, ppv_stream_t stream);
 
 /* on-the-fly windowed correlation = Face-DeId/RAFT/core/corr.py:63-91 AlternateCorrBlock + the reference's CUDA extension
- * RAFT/alt_cuda_corr/correlation_kernel.cu:18-119 (forward) / :122-256 (backward), one pyramid level per call, N = 1 coordinate
- * set per pixel; NHWC f32 maps, coords (x, y); no HW x HW volume is materialised */
-int ppv_alt_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int H1, int W1, int H2,
-                     int W2, int C, int r, float scale, ppv_stream_t stream);
+ * RAFT/alt_cuda_corr/correlation_kernel.cu:18-119 (forward) / :122-256 (backward), all pyramid levels per forward call (fmap2_levels / H2 / W2 are HOST arrays), N = 1
+ * coordinate set per pixel; NHWC f32 maps, coords (x, y); no HW x HW volume is materialised */
+int ppv_alt_corr_fwd(const float* fmap1, const float* const* fmap2_levels, const int* H2, const int* W2, int levels,
+                     const float* coords, float* out, int B, int H1, int W1, int C, int r, float scale, ppv_stream_t stream);
 int ppv_alt_corr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* gout, float* d_fmap1,
-                     float* d_fmap2, int B, int H1, int W1, int H2, int W2, int C, int r, float scale, ppv_stream_t stream);
+                     float* d_fmap2, int B, int H1, int W1, int H2, int W2, int C, int r, float scale, int level, int levels,
+                     ppv_stream_t stream);
 
 /* ---- soft-attention LSTM caption decoder, Image_Caption/models.py:57-218.  encoder_att is hoisted out
  * of the time loop (models.py:83 recomputes it every step) and runs through ppv_conv_gemm; these are the per-step kernels.

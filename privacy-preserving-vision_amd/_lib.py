@@ -53,8 +53,8 @@ PROTOTYPES = {
     "ppv_dec_combine": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ppv_dec_enc_grad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_corr_volume": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "ppv_alt_corr_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
-    "ppv_alt_corr_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "ppv_alt_corr_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "ppv_alt_corr_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "ppv_avgpool2": (_I, [_P, _P, _L, _I, _I, _P]),
     "ppv_corr_lookup_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_avgpool2_bwd_acc": (_I, [_P, _P, _L, _I, _I, _P]),

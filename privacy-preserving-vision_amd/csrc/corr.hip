@@ -198,19 +198,30 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
 // ============================================================================= on-the-fly windowed correlation
 // MI355X counterpart of the reference's only native code, RAFT/alt_cuda_corr/correlation_kernel.cu (corr_forward_kernel
 // :18-119, corr_backward_kernel :122-256), re-thought for wave64 rather than its 4x8-thread blocks with [32][33] tiles:
-//   forward  : ONE WAVE PER PIXEL, LANE = WINDOW POSITION.  The (2r+2)^2 <= 128 window positions of a pixel are spread
-//              over the lanes (two trips); each lane walks its own fmap2 row with 16-byte loads against the pixel's
-//              fmap1 row broadcast from LDS, so the C-long dot products need no cross-lane reduction at all; the window
-//              of products sits in LDS and every lane then blends its four bilinear corners for one or two outputs.
+//   forward  : ONE WAVE PER PIXEL; 16 lanes share a window position (256 contiguous bytes of its fmap2 row per load,
+//              4 positions per trip), the pixel's fmap1 row is read from LDS, the 16-lane partial dots fold with DPP
+//              row adds; the (2r+2)^2 <= 100 products sit in LDS and every lane then blends its four bilinear
+//              corners for one or two of the (2r+1)^2 outputs.
 //              fmap2 (<= 4 MB per level) lives in L2; nothing of size HW x HW is ever written.
 //   backward : ONE WAVE PER PIXEL, LANE = 4 CHANNELS.  d corr is folded back to the window (adjoint of the blend) in LDS,
 //              then the wave sweeps the window: d fmap1 accumulates in registers (plain store, the pixel is owned),
 //              d fmap2 rows take one 16-byte-per-lane f32 atomic burst per window position (as the reference does).
 // Layouts: fmap1 [B][H1][W1][C], fmap2 [B][H2][W2][C] f32 NHWC, coords [B][H1][W1][2] (x, y), out [B][(2r+1)^2][H1][W1],
 // channel = iy + (2r+1) * ix.  coords get no gradient (the reference leaves coords_grad zero).
-__global__ __launch_bounds__(256) void alt_corr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+struct AltLevels {
+    const float* f2[8];
+    int H2[8], W2[8];
+    int n;
+};
+
+// grid (ceil(H1*W1 / 4), B, levels): level l reads coords / 2^l (corr.py:87) and fills out[b][l][:][h1][w1]
+__global__ __launch_bounds__(256) void alt_corr_fwd_kernel(const float* __restrict__ f1, AltLevels lv,
                                                            const float* __restrict__ coords, float* __restrict__ out, int H1,
-                                                           int W1, int H2, int W2, int C, int r, float scale) {
+                                                           int W1, int C, int r, float scale) {
+    const int lvl = blockIdx.z;
+    const float* __restrict__ f2 = lv.f2[lvl];
+    const int H2 = lv.H2[lvl], W2 = lv.W2[lvl];
+    const float cdiv = 1.0f / (float)(1 << lvl);
     extern __shared__ float sm[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rd = 2 * r + 1, wd = rd + 1, WIN = wd * wd;
@@ -221,31 +232,40 @@ __global__ __launch_bounds__(256) void alt_corr_fwd_kernel(const float* __restri
     if (pix >= H1 * W1) return;                               // (no block-wide barrier below: waves are independent)
     const float* f1p = f1 + ((long)b * H1 * W1 + pix) * C;
     for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(sF1 + c) = *reinterpret_cast<const float4*>(f1p + c);
-    const float x = coords[((long)b * H1 * W1 + pix) * 2], y = coords[((long)b * H1 * W1 + pix) * 2 + 1];
+    // (x / 2^l is exact in binary floating point, so this equals the reference's coords / 2**i bit for bit)
+    const float x = coords[((long)b * H1 * W1 + pix) * 2] * cdiv, y = coords[((long)b * H1 * W1 + pix) * 2 + 1] * cdiv;
     const float xf = floorf(x), yf = floorf(y);
     const float dx = x - xf, dy = y - yf;
     const int x0 = (int)xf - r, y0 = (int)yf - r;
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int p = lane; p < WIN; p += 64) {
+    // 16 lanes share one window position (256 contiguous bytes of its fmap2 row per load), 4 positions per trip: a
+    // wave-load touches 8 cache lines instead of the 64 a lane-per-position walk would; the 16-lane sums are DPP row adds
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int p0 = 0; p0 < WIN; p0 += 4) {
+        const int p = p0 + grp;
         const int iy = p / wd, ix = p % wd;
         const int h2 = y0 + iy, w2 = x0 + ix;
         float s = 0.f;
-        if ((unsigned)h2 < (unsigned)H2 && (unsigned)w2 < (unsigned)W2) {
+        if (p < WIN && (unsigned)h2 < (unsigned)H2 && (unsigned)w2 < (unsigned)W2) {
             const float* q = f2 + (((long)b * H2 + h2) * W2 + w2) * C;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int c = 0; c < C; c += 4) {
+            for (int c = sub * 4; c < C; c += 64) {
                 const float4 v = *reinterpret_cast<const float4*>(q + c);
-                const float4 u = *reinterpret_cast<const float4*>(sF1 + c);     // same address in every lane: broadcast
+                const float4 u = *reinterpret_cast<const float4*>(sF1 + c);
                 a0 = fmaf(v.x, u.x, a0); a1 = fmaf(v.y, u.y, a1); a2 = fmaf(v.z, u.z, a2); a3 = fmaf(v.w, u.w, a3);
             }
             s = (a0 + a1) + (a2 + a3);
         }
-        sS[p] = s * scale;
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (sub == 0 && p < WIN) sS[p] = s * scale;
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float* o = out + (long)b * rd * rd * H1 * W1 + pix;
+    float* o = out + ((long)b * lv.n + lvl) * rd * rd * H1 * W1 + pix;
     for (int k = lane; k < rd * rd; k += 64) {
         const int j = k / rd, i = k % rd;                     // channel k = iy + rd * ix
         const float v = (1.f - dy) * (1.f - dx) * sS[i * wd + j] + dy * (1.f - dx) * sS[(i + 1) * wd + j] +
@@ -257,18 +277,19 @@ __global__ __launch_bounds__(256) void alt_corr_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void alt_corr_bwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                            const float* __restrict__ coords, const float* __restrict__ gout,
                                                            float* __restrict__ df1, float* __restrict__ df2, int H1, int W1,
-                                                           int H2, int W2, int C, int r, float scale) {
+                                                           int H2, int W2, int C, int r, float scale, int lvl, int nlv) {
     __shared__ float sG[4][96], sDS[4][128];
+    const float cdiv = 1.0f / (float)(1 << lvl);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rd = 2 * r + 1, wd = rd + 1, WIN = wd * wd;
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 4 + wave;
     if (pix >= H1 * W1) return;
-    const float x = coords[((long)b * H1 * W1 + pix) * 2], y = coords[((long)b * H1 * W1 + pix) * 2 + 1];
+    const float x = coords[((long)b * H1 * W1 + pix) * 2] * cdiv, y = coords[((long)b * H1 * W1 + pix) * 2 + 1] * cdiv;
     const float xf = floorf(x), yf = floorf(y);
     const float dx = x - xf, dy = y - yf;
     const int x0 = (int)xf - r, y0 = (int)yf - r;
-    const float* go = gout + (long)b * rd * rd * H1 * W1 + pix;
+    const float* go = gout + ((long)b * nlv + lvl) * rd * rd * H1 * W1 + pix;
     for (int k = lane; k < rd * rd; k += 64) sG[wave][k] = go[(long)k * H1 * W1] * scale;
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -366,27 +387,36 @@ int ppv_corr_volume_bwd(const float* gcorr, const float* f1, const float* f2, fl
     return ppv_last_error();
 }
 
-// On-the-fly windowed correlation of one pyramid level (AlternateCorrBlock, corr.py:63-91 + alt_cuda_corr forward):
-// out [B][(2r+1)^2][H1][W1] = blend of <fmap1[b,h1,w1,:], fmap2[b, floor(y)-r+iy, floor(x)-r+ix, :]> * scale.
-// fmap1 [B][H1][W1][C], fmap2 [B][H2][W2][C] f32 NHWC, coords [B][H1][W1][2] (x, y).  C % 4 == 0, 1 <= r <= 4.
-int ppv_alt_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int H1, int W1, int H2,
-                     int W2, int C, int r, float scale, hipStream_t stream) {
-    if (!fmap1 || !fmap2 || !coords || !out) return PPV_ERR_NULL;
-    if (C % 4 || C < 4 || r < 1 || r > 4 || B < 1) return PPV_ERR_BAD_SIZE;
+// On-the-fly windowed correlation, all pyramid levels in one launch (AlternateCorrBlock.__call__, corr.py:76-91 + the
+// alt_cuda_corr forward): out [B][levels][(2r+1)^2][H1][W1] = blend of <fmap1[b,h1,w1,:], fmap2_l[b, floor(y_l)-r+iy,
+// floor(x_l)-r+ix, :]> * scale with (x_l, y_l) = coords / 2^l.  fmap1 [B][H1][W1][C], fmap2_l [B][H2[l]][W2[l]][C] f32 NHWC
+// (host array of `levels` device pointers), coords [B][H1][W1][2] (x, y) at level 0.  C % 4 == 0, 1 <= r <= 4, levels <= 8.
+int ppv_alt_corr_fwd(const float* fmap1, const float* const* fmap2_levels, const int* H2, const int* W2, int levels,
+                     const float* coords, float* out, int B, int H1, int W1, int C, int r, float scale, hipStream_t stream) {
+    if (!fmap1 || !fmap2_levels || !H2 || !W2 || !coords || !out) return PPV_ERR_NULL;
+    if (C % 4 || C < 4 || r < 1 || r > 4 || B < 1 || levels < 1 || levels > 8) return PPV_ERR_BAD_SIZE;
     const size_t lds = 4 * (size_t)(C + 128) * sizeof(float);
     if (lds > 64 * 1024) return PPV_ERR_BAD_SIZE;
-    ppv::alt_corr_fwd_kernel<<<dim3((H1 * W1 + 3) / 4, B), 256, lds, stream>>>(fmap1, fmap2, coords, out, H1, W1, H2, W2, C, r, scale);
+    ppv::AltLevels lv;
+    lv.n = levels;
+    for (int i = 0; i < levels; ++i) {
+        if (!fmap2_levels[i]) return PPV_ERR_NULL;
+        lv.f2[i] = fmap2_levels[i]; lv.H2[i] = H2[i]; lv.W2[i] = W2[i];
+    }
+    ppv::alt_corr_fwd_kernel<<<dim3((H1 * W1 + 3) / 4, B, levels), 256, lds, stream>>>(fmap1, lv, coords, out, H1, W1, C, r, scale);
     return ppv_last_error();
 }
 
-// Adjoint (alt_cuda_corr backward): d_fmap1 [B][H1][W1][C] WRITTEN, d_fmap2 [B][H2][W2][C] ACCUMULATED with f32 atomics
-// (caller zeroes it); either may be null.  coords receive no gradient, as in the reference.
+// Adjoint of one level (alt_cuda_corr backward): gout [B][levels][(2r+1)^2][H1][W1]; d_fmap1 [B][H1][W1][C] WRITTEN with
+// this level's contribution, d_fmap2 [B][H2][W2][C] ACCUMULATED with f32 atomics (caller zeroes it); either may be null.
+// coords receive no gradient, as in the reference.
 int ppv_alt_corr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* gout, float* d_fmap1,
-                     float* d_fmap2, int B, int H1, int W1, int H2, int W2, int C, int r, float scale, hipStream_t stream) {
+                     float* d_fmap2, int B, int H1, int W1, int H2, int W2, int C, int r, float scale, int level, int levels,
+                     hipStream_t stream) {
     if (!fmap1 || !fmap2 || !coords || !gout) return PPV_ERR_NULL;
-    if (C % 4 || C < 4 || r < 1 || r > 4 || B < 1) return PPV_ERR_BAD_SIZE;
+    if (C % 4 || C < 4 || r < 1 || r > 4 || B < 1 || level < 0 || level >= levels) return PPV_ERR_BAD_SIZE;
     ppv::alt_corr_bwd_kernel<<<dim3((H1 * W1 + 3) / 4, B), 256, 0, stream>>>(fmap1, fmap2, coords, gout, d_fmap1, d_fmap2, H1, W1, H2,
-                                                                          W2, C, r, scale);
+                                                                          W2, C, r, scale, level, levels);
     return ppv_last_error();
 }
 

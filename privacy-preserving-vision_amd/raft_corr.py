@@ -96,33 +96,46 @@ class CorrBlock:
 
 
 class _AltCorrFn(torch.autograd.Function):
-    """One pyramid level of the on-the-fly correlation (f1, f2 NHWC f32; coords [B,H,W,2])."""
+    """All pyramid levels of the on-the-fly correlation in one launch (f1, f2_l NHWC f32; coords [B,H,W,2] at level 0)."""
 
     @staticmethod
-    def forward(ctx, f1, f2, coords, radius):
+    def forward(ctx, radius, coords, f1, *f2s):
+        import ctypes
         L = _lib.lib()
         B, H1, W1, C = f1.shape
-        _, H2, W2, _ = f2.shape
+        n = len(f2s)
         rd = 2 * radius + 1
-        out = torch.empty((B, rd * rd, H1, W1), dtype=torch.float32, device=f1.device)
+        out = torch.empty((B, n, rd * rd, H1, W1), dtype=torch.float32, device=f1.device)
         scale = 1.0 / float(C) ** 0.5
-        check(L.ppv_alt_corr_fwd(ptr(f1), ptr(f2), ptr(coords), ptr(out), B, H1, W1, H2, W2, C, radius, scale, stream_ptr()),
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in f2s])
+        hs = (ctypes.c_int * n)(*[t.shape[1] for t in f2s])
+        ws = (ctypes.c_int * n)(*[t.shape[2] for t in f2s])
+        check(L.ppv_alt_corr_fwd(ptr(f1), ptrs, hs, ws, n, ptr(coords), ptr(out), B, H1, W1, C, radius, scale, stream_ptr()),
               "ppv_alt_corr_fwd")
-        ctx.save_for_backward(f1, f2, coords)
+        ctx.save_for_backward(f1, coords, *f2s)
         ctx.radius, ctx.scale = radius, scale
         return out
 
     @staticmethod
     def backward(ctx, g):
-        f1, f2, coords = ctx.saved_tensors
+        f1, coords, *f2s = ctx.saved_tensors
         L = _lib.lib()
         B, H1, W1, C = f1.shape
-        _, H2, W2, _ = f2.shape
-        d1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
-        d2 = torch.zeros_like(f2) if ctx.needs_input_grad[1] else None
-        check(L.ppv_alt_corr_bwd(ptr(f1), ptr(f2), ptr(coords), ptr(g.contiguous()), ptr(d1), ptr(d2), B, H1, W1, H2, W2, C,
-                                 ctx.radius, ctx.scale, stream_ptr()), "ppv_alt_corr_bwd")
-        return d1, d2, None, None
+        n = len(f2s)
+        g = g.contiguous()
+        d1 = None
+        d2s = []
+        for i, f2 in enumerate(f2s):
+            want1, want2 = ctx.needs_input_grad[2], ctx.needs_input_grad[3 + i]
+            t1 = torch.empty_like(f1) if want1 else None
+            t2 = torch.zeros_like(f2) if want2 else None
+            if want1 or want2:
+                check(L.ppv_alt_corr_bwd(ptr(f1), ptr(f2), ptr(coords), ptr(g), ptr(t1), ptr(t2), B, H1, W1, f2.shape[1], f2.shape[2],
+                                         C, ctx.radius, ctx.scale, i, n, stream_ptr()), "ppv_alt_corr_bwd")
+            if want1:
+                d1 = t1 if d1 is None else d1.add_(t1)
+            d2s.append(t2)
+        return (None, None, d1) + tuple(d2s)
 
 
 class AlternateCorrBlock:
@@ -144,7 +157,6 @@ class AlternateCorrBlock:
             f2 = F.avg_pool2d(f2, 2, stride=2)                               # corr.py:72-73
 
     def __call__(self, coords):
-        c = coords.float().permute(0, 2, 3, 1)
+        c = coords.float().permute(0, 2, 3, 1).contiguous()
         B, H, W, _ = c.shape
-        outs = [_AltCorrFn.apply(self.f1, self.f2[i], (c / 2 ** i).contiguous(), self.radius) for i in range(self.num_levels)]
-        return torch.stack(outs, dim=1).reshape(B, -1, H, W)
+        return _AltCorrFn.apply(self.radius, c, self.f1, *self.f2).view(B, -1, H, W)

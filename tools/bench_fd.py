@@ -10,7 +10,7 @@ import torch
 import ppv_amd  # noqa: F401
 from ppv_amd.camera_optics import Camera
 from ppv_amd.fan import FAN
-from ppv_amd.raft_corr import CorrBlock
+from ppv_amd.raft_corr import CorrBlock, AlternateCorrBlock
 
 dev = torch.device("cuda", 0)
 B = 32
@@ -42,10 +42,19 @@ def corr_all():
             blk(coords[b:b + 1])
 
 
+def alt_all():
+    for b in range(B):                       # same loop with the on-the-fly correlation (no 64 MB volume per sample)
+        blk = AlternateCorrBlock(f1[b:b + 1], f2[b:b + 1])
+        for _ in range(20):
+            blk(coords[b:b + 1])
+
+
 t_cam = timeit(lambda: cam(x))
 xs_ = cam(x)
 t_fan = timeit(lambda: fan.get_heatmap(xs_, Privacy=True))
 t_corr = timeit(corr_all, n=2, w=1)
+t_alt = timeit(alt_all, n=2, w=1)
 print(json.dumps({"config": "FD Camera + FAN + RAFT CorrBlock, B=32 @512x512 (BASELINE.json configs[3]), forward",
                   "camera_ms": round(t_cam * 1e3, 3), "fan_ms": round(t_fan * 1e3, 3), "corr_32x(volume+20 lookups)_ms": round(t_corr * 1e3, 3),
+                  "altcorr_32x(20 on-the-fly lookups)_ms": round(t_alt * 1e3, 3),
                   "images_per_s_camera_fan": round(B / (t_cam + t_fan), 1)}))

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box from the repo root: kernel-trace stats of a B=128 bench run + the two PMC passes, summaries under
+# gpurun_out/prof_round/ (copy what is to be judged into profiles/).  The program itself follows `--` (no env / bash -c hops).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof_round
+mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+echo stats done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch.log 2>&1
+echo fetch done
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write.log 2>&1
+echo write done
+python tools/collect_pmc.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+rm -rf $O/fetch $O/write $O/stats
+python bench.py > $O/bench_default.json.log 2>$O/bench_default.err
+tail -1 $O/bench_default.json.log | cut -c1-300

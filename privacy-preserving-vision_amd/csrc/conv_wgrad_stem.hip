@@ -327,6 +327,157 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
             }
 }
 
+// ----------------------------------------------------------------------------- 3x3 / stride 1 / pad 1 wgrad, taps fused
+// conv_wgrad_pipe_kernel re-reads the G rows of an m-slice once per (tap, c-tile): 18 times for the layer-3 3x3 convs, and
+// its 9 taps fetch 9 shifted copies of the same X rows -- the kernel ran at the L2->LDS rate (453 MB per launch).  Here one
+// workgroup owns 128 (n) x 128 (c) x THREE taps (one kernel row r, s = 0..2):
+//   * the 64-row G stage is staged once and feeds all three taps;
+//   * X is staged ONCE as a halo tile: the 64/W image rows of the stage shifted by r-1, each with its W+2 columns
+//     (zero page outside the image), pixel-major [pixel][128 c]; tap s reads row (k / W) * (W + 2) + k % W + s of it
+//     through the same transposed ds_read_b64_tr_b16 fragments (the swizzle key follows the halo row);
+//   => 92 MAC per staged byte instead of 44, 12 tiles of 3 taps instead of 18 of one.
+// 8 waves: wave (wn, wc) owns 64 n x 32 c of every tap: acc[3][4][2] (96 VGPRs).  W in {8, 16, 32, 64}, H*W % 64 == 0.
+constexpr int W3_XSLOTS = 24;                                  // 4-pixel wave-instructions reserved per stage (<= 96 pixels)
+constexpr int W3_STAGE = 64 * 256 + W3_XSLOTS * 1024;          // G tile + halo tile
+
+template <int NSTAGE>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                               float* __restrict__ dW, const bf16_t* __restrict__ zero_page,
+                                                               WgradGeom g, int log2W) {
+    constexpr int NW = 8, GI = 16 / NW, XI = W3_XSLOTS / NW, L = GI + XI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int W = 1 << log2W, WP = W + 2, rows_ps = 64 >> log2W;          // image rows per 64-pixel stage
+    const int npix = rows_ps * WP, nslots = (npix + 3) >> 2;
+    const int ctiles = g.Cs / 128, ntiles = g.N / 128;
+    const int tiles = ntiles * ctiles * 3;
+    int zslice, tl;
+    if (g.xcd_group) {                                         // all tiles of an m-slice on one XCD: G / X rows come from its L2
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        zslice = (idx / tiles) * 8 + xcd;
+        tl = idx % tiles;
+    } else {
+        zslice = blockIdx.x / tiles;
+        tl = blockIdx.x % tiles;
+    }
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % ntiles) * 128, by = tl / ntiles;
+    const int r = by / ctiles, c0 = (by % ctiles) * 128;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    int nst = (int)((m_end - m_begin + 63) / 64);
+    if (nst <= 0) return;
+    const int HoWo = g.Ho * g.Wo;
+    const int rli = lane >> 4, lch = lane & 15;
+    const long zdX = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+
+    int st_next = 0;
+    auto stage = [&](int buf) {
+        char* sb = smem + buf * W3_STAGE;
+        const long mb = m_begin + (long)st_next * 64;
+        ++st_next;
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int q = i * NW + wave, row = q * 4 + rli;
+            const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+            GLDS16W(reinterpret_cast<const char*>(G) + ((mb + row) * g.N + n0 + gch * 8) * 2, sb + q * 1024);
+        }
+        const int b = (int)(mb / HoWo), row0 = (int)(mb % HoWo) >> log2W;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            int q = i * NW + wave;
+            if (q >= nslots) q -= nslots;                                 // spare slots repeat a valid one (same bytes, same place)
+            const int pp = q * 4 + rli;
+            const int pr = pp / WP, pc = pp - pr * WP;
+            const int ho = row0 + pr + r - 1, wo = pc - 1;
+            const int gch = (((lch >> 1) ^ trkey(pp)) << 1) | (lch & 1);
+            const bool ok = (pp < npix) & ((unsigned)ho < (unsigned)g.Hs) & ((unsigned)wo < (unsigned)W);
+            const long off = ok ? ((((long)b * g.Hs + ho) * W + wo) * g.Cs + c0 + gch * 8) * 2 : zdX;
+            GLDS16W(reinterpret_cast<const char*>(X) + off, sb + 64 * 256 + q * 1024);
+        }
+    };
+
+    f32x4 acc[3][4][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[s][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave >> 2, wc = wave & 3;
+
+    // transposed fragment of the halo tile for tap s: k-row r0 of the stage lives in halo row (r0 / W) * (W + 2) + r0 % W + s
+    auto x_issue = [&](s16x4& lo, s16x4& hi, const char* tile, int k0, int s, int colblock) {
+        const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int k = k0 + 8 * gq + q;
+        const int h0 = (k >> log2W) * WP + (k & (W - 1)) + s, h1 = h0 + 4;           // k % 8 < 4: k + 4 stays in the image row
+        const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(tile + h0 * 256 + (colblock ^ trkey(h0)) * 32 + p * 8);
+        const unsigned a1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(tile + h1 * 256 + (colblock ^ trkey(h1)) * 32 + p * 8);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    };
+
+    auto compute = [&](int buf) {
+        const char* tg = smem + buf * W3_STAGE;
+        const char* tx = tg + 64 * 256;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            s16x4 alo[4], ahi[4], blo[3][2], bhi[3][2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) tr_issue(alo[mi], ahi[mi], tg, kk * 32, wn * 4 + mi, lane);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) x_issue(blo[s][ni], bhi[s][ni], tx, kk * 32, s, wc * 2 + ni);
+            tr_wait_all();
+            bf16x8 af[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[mi], ahi[mi]);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const bf16x8 bf = tr_pack(blo[s][ni], bhi[s][ni]);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[s][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf, acc[s][mi][ni], 0, 0, 0);
+                }
+        }
+    };
+
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nst) stage(s0);
+    int rd = 0, wr = (NSTAGE - 1) % NSTAGE;
+    for (int t = 0; t < nst; ++t) {
+        const int younger = min(nst, t + NSTAGE - 1) - (t + 1);
+        if (younger >= NSTAGE - 2) wg_wait_vmcnt_le<(NSTAGE - 2) * L>();
+        else if (NSTAGE >= 4 && younger == NSTAGE - 3) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
+        else wg_wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nst) stage(wr);
+        compute(rd);
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const long wrow = 9L * g.Cs;
+    float* dst = dW + (long)zslice * g.slab_elems;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + mi * 16 + fq * 4 + j;
+                    const int c = c0 + wc * 32 + ni * 16 + fr;
+                    dst[(long)n * wrow + (long)(r * 3 + s) * g.Cs + c] = acc[s][mi][ni][j];
+                }
+}
+
 // sum of nslab slabs [N][R][S][C] f32 -> torch [N][C][R][S] f32
 __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __restrict__ dW, float* __restrict__ out, int N, int C,
                                                              int R, int S, int nslab) {
@@ -505,6 +656,17 @@ static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN
     *TN = tn;
 }
 
+// m-slices of the fused-tap 3x3 kernel: ~one workgroup per CU over (N/128) x (Cs/128) x 3 tiles
+static void wgrad3_plan(long M, int N, int Cs, long* splits, int* sps) {
+    const long stages = M / 64;
+    const int tiles = (N / 128) * (Cs / 128) * 3;
+    long sp = (256 + tiles - 1) / tiles;
+    if (sp > stages / 8) sp = stages / 8;
+    if (sp < 1) sp = 1;
+    *sps = (int)((stages + sp - 1) / sp);
+    *splits = (stages + *sps - 1) / *sps;
+}
+
 // bytes of f32 scratch ppv_conv_wgrad needs (per-slice slabs of the [N][R][S][Cs] gradient)
 size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
     int TN, sps;
@@ -512,6 +674,12 @@ size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
     int variant = g_wgrad_variant & 0xff;
     if (variant == 0) variant = (N % 256 == 0) ? 3 : 1;
     wgrad_plan(M, N, R, S, Cs, variant, &TN, &splits, &sps);
+    if (R == 3 && S == 3 && M % 64 == 0) {                       // the fused-tap kernel may be chosen: cover its plan too
+        long sp3;
+        int sps3;
+        wgrad3_plan(M, N, Cs, &sp3, &sps3);
+        if (sp3 > splits) splits = sp3;
+    }
     return (size_t)splits * N * R * S * Cs * sizeof(float);
 }
 
@@ -532,13 +700,34 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         variant = (N % 256 == 0) ? 3 : 1;                      //   256-wide pipelined tiles win where they exist,
         g.xcd_group = (R * S == 1) ? 1 : 0;                    //   XCD grouping pays for 1x1 only
     }
+    const long elems = (long)N * R * S * Cs;
+    float* slabs = (float*)scratch;
+    const bool w_ok = Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64;
+    if (R == 3 && S == 3 && stride == 1 && pad == 1 && Hs == Ho && Ws == Wo && w_ok && (Ho * Wo) % 64 == 0 &&
+        ((g_wgrad_variant & 0xff) == 0 || (g_wgrad_variant & 0xff) == 4)) {
+        long sp3;
+        int sps3;
+        wgrad3_plan(g.M, N, Cs, &sp3, &sps3);
+        g.stages_per_split = sps3;
+        g.splits = (int)sp3;
+        g.slab_elems = elems;
+        constexpr int NS = 3, lds = NS * W3_STAGE;   // a 4th stage (160 KB) measured no faster: the loop is compute-side bound
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        const int log2W = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
+        g.xcd_group = (g_wgrad_variant & 0x200) ? 1 : 0;         // XCD grouping measured slower here (111 vs 88 us, layer 3)
+        const long t3 = (long)(N / 128) * (Cs / 128) * 3;
+        conv_wgrad3x3_kernel<NS><<<(unsigned)(g.xcd_group ? 8 * ((sp3 + 7) / 8) * t3 : sp3 * t3), 512, lds, stream>>>(
+            (const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
+        wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
+        return ppv_last_error();
+    }
+    if (variant == 4) variant = (N % 256 == 0) ? 3 : 1;
     int TN, sps;
     long splits;
     wgrad_plan(g.M, N, R, S, Cs, variant, &TN, &splits, &sps);
     g.stages_per_split = sps;
     g.splits = (int)splits;
-    const long elems = (long)N * R * S * Cs;
-    float* slabs = (float*)scratch;
     const int tiles = (N / TN) * (R * S * (Cs / 128));
     if (variant == 1) {                                        // two-stage kernel, atomics into one zeroed accumulator
         g.slab_elems = 0;
@@ -565,7 +754,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     return ppv_last_error();
 }
 
-// tuning / A-B hook: low byte 0 auto, 1 two-stage, 2 pipe TN=128, 3 pipe TN=256; 0x100 disables XCD grouping
+// tuning / A-B hook: low byte 0 auto, 1 two-stage, 2 pipe TN=128, 3 pipe TN=256, 4 = auto (fused-tap 3x3 allowed; 1-3 force the
+// per-tap kernels); 0x100 disables XCD grouping
 int ppv_wgrad_set_variant(int v) { g_wgrad_variant = v; return PPV_OK; }
 
 // mode 0: forward layout [64][24][8] bf16; mode 1: data-gradient layout [16][4][4][64] bf16

@@ -20,7 +20,8 @@ def r16(t):
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", [(4, 16, 128, 128, 3, 1), (2, 16, 256, 128, 1, 1), (3, 16, 128, 256, 3, 2),
-                                                   (2, 8, 256, 512, 1, 2), (9, 8, 128, 128, 3, 1)])
+                                                   (2, 8, 256, 512, 1, 2), (9, 8, 128, 128, 3, 1), (2, 32, 128, 256, 3, 1),
+                                                   (3, 16, 256, 256, 3, 1), (1, 64, 128, 128, 3, 1)])
 def test_conv_wgrad(B, H, Cin, Cout, k, stride):
     import ppv_amd.convops as co
     g0 = torch.Generator().manual_seed(0)

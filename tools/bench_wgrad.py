@@ -12,8 +12,8 @@ for cin, cout, k, h in SH:
     acc = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
     fl = 2.0 * B * h * h * cout * cin * k * k
     line = f"cin {cin:5d} cout {cout:5d} k{k} h{h:3d}:"
-    for v in (1, 2, 0x102, 3, 0x103):
-        if (v & 0xff) == 3 and cout % 256:
+    for v in (0, 1, 3, 0x103):
+        if v and (v & 0xff) == 3 and cout % 256:
             continue
         co.L().ppv_wgrad_set_variant(v)
         for i in range(NB):

@@ -417,31 +417,40 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const bf16_t* __r
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
     };
 
+    // six units per stage (2 k-halves x 3 taps, 8 MFMAs each); the fragments of unit u+1 (and the G fragments of the second
+    // k-half) are in flight under the MFMAs of unit u
     auto compute = [&](int buf) {
         const char* tg = smem + buf * W3_STAGE;
         const char* tx = tg + 64 * 256;
+        s16x4 alo[2][4], ahi[2][4], blo[2][2], bhi[2][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            s16x4 alo[4], ahi[4], blo[3][2], bhi[3][2];
+        for (int mi = 0; mi < 4; ++mi) tr_issue(alo[0][mi], ahi[0][mi], tg, 0, wn * 4 + mi, lane);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) tr_issue(alo[mi], ahi[mi], tg, kk * 32, wn * 4 + mi, lane);
+        for (int ni = 0; ni < 2; ++ni) x_issue(blo[0][ni], bhi[0][ni], tx, 0, 0, wc * 2 + ni);
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) x_issue(blo[s][ni], bhi[s][ni], tx, kk * 32, s, wc * 2 + ni);
+        for (int u = 0; u < 6; ++u) {
+            const int kk = u / 3, s = u % 3;
             tr_wait_all();
+            if (u + 1 < 6) {
+                const int kk1 = (u + 1) / 3, s1 = (u + 1) % 3;
+                if (s1 == 0) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) tr_issue(alo[kk1][mi], ahi[kk1][mi], tg, kk1 * 32, wn * 4 + mi, lane);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) x_issue(blo[(u + 1) & 1][ni], bhi[(u + 1) & 1][ni], tx, kk1 * 32, s1, wc * 2 + ni);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             bf16x8 af[4];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[mi], ahi[mi]);
+            for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[kk][mi], ahi[kk][mi]);
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int ni = 0; ni < 2; ++ni) {
+                const bf16x8 bf = tr_pack(blo[u & 1][ni], bhi[u & 1][ni]);
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const bf16x8 bf = tr_pack(blo[s][ni], bhi[s][ni]);
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[s][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf, acc[s][mi][ni], 0, 0, 0);
-                }
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[s][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf, acc[s][mi][ni], 0, 0, 0);
+            }
         }
     };
 

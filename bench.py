@@ -95,7 +95,14 @@ def make_step(camera, encoder, batch, device, sync, decoder=None):
         opt_cam.zero_grad(set_to_none=True)
         loss.backward()                        # encoder gradients are all-reduced inside backward (side stream)
         if sync is not None:
+            sync.flush()                       # tail bucket + make this stream wait for every all-reduce
             sync.reduce_now([p.grad for p in cam_params])
+            if os.environ.get("PPV_CHECK_SYNC"):                                  # rehearsal check: ranks agree on every gradient
+                for p in enc_params + cam_params:
+                    lo, hi = p.grad.detach().clone(), p.grad.detach().clone()
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                    assert torch.equal(lo, hi), "gradient differs across ranks after the all-reduce"
         opt_cam.step()
         grads = [p.grad for p in enc_params]                                      # clip_gradient, train.py:311-316
         torch._foreach_clamp_min_(grads, -5.0)

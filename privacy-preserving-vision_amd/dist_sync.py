@@ -56,8 +56,13 @@ class GradSync:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
 
+    def launch_pending(self):
+        """Start the all-reduce of the last, partly filled bucket (called when the producer has no more gradients)."""
+        self._launch()
+
     def flush(self):
-        """Launch what is left and make the compute stream wait for every outstanding all-reduce."""
+        """Launch what is left and make the current stream wait for every outstanding all-reduce.  MUST run between
+        ``backward()`` and the optimiser step (bench.py does; a training script calls ``encoder.grad_sync.flush()``)."""
         self._launch()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)

@@ -259,6 +259,8 @@ class _TrunkFn(torch.autograd.Function):
                 grads[st.bn.weight], grads[st.bn.bias] = dg, db
             if needs_img:
                 g_img = co.stem_dgrad(gx0, st.wd(tok))
+        if enc.grad_sync is not None:
+            enc.grad_sync.launch_pending()       # the tail bucket starts now; the caller flush()es before optimizer.step()
         return (None, g_img) + tuple(grads.get(p) for p in enc._param_list())
 
 

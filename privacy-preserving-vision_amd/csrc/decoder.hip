@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256) void dec_score_fwd_kernel(const bf16_t* __rest
 // ----------------------------------------------------------------------------- softmax + context + gate
 // grid (bt, ceil(E / 256)): every workgroup redoes the (cheap) softmax of its image, then owns 256 context channels.
 // alpha_out [bt][P] (written by channel slab 0), awe_save [bt][E] (ungated), xh[b*ldx + x_off + e] = gate * awe.
+// SOFTMAX = false: ebuf already holds the P mixing coefficients of the image (compact path: P = cells, coefficients = beta).
+template <bool SOFTMAX>
 __global__ __launch_bounds__(256) void dec_ctx_fwd_kernel(const bf16_t* __restrict__ encs, const float* __restrict__ ebuf,
                                                           const float* __restrict__ hproj, int ldh, int gate_off,
                                                           float* __restrict__ alpha_out, float* __restrict__ awe_save,
@@ -137,21 +139,25 @@ __global__ __launch_bounds__(256) void dec_ctx_fwd_kernel(const bf16_t* __restri
     float* sRed = sm + P;            // [8][256]
     __shared__ float s4[4];
     const int b = blockIdx.x, c0 = blockIdx.y * 256, tid = threadIdx.x;
-    float m = -3.4e38f;
-    for (int p = tid; p < P; p += 256) m = fmaxf(m, ebuf[(long)b * P + p]);
-    m = block_max(m, s4);
-    float s = 0.f;
-    for (int p = tid; p < P; p += 256) {
-        const float v = __expf(ebuf[(long)b * P + p] - m);
-        sAl[p] = v;
-        s += v;
-    }
-    s = block_sum(s, s4);
-    const float inv = 1.f / s;
-    for (int p = tid; p < P; p += 256) {
-        const float a = sAl[p] * inv;
-        sAl[p] = a;
-        if (blockIdx.y == 0) alpha_out[(long)b * P + p] = a;
+    if (SOFTMAX) {
+        float m = -3.4e38f;
+        for (int p = tid; p < P; p += 256) m = fmaxf(m, ebuf[(long)b * P + p]);
+        m = block_max(m, s4);
+        float s = 0.f;
+        for (int p = tid; p < P; p += 256) {
+            const float v = __expf(ebuf[(long)b * P + p] - m);
+            sAl[p] = v;
+            s += v;
+        }
+        s = block_sum(s, s4);
+        const float inv = 1.f / s;
+        for (int p = tid; p < P; p += 256) {
+            const float a = sAl[p] * inv;
+            sAl[p] = a;
+            if (blockIdx.y == 0) alpha_out[(long)b * P + p] = a;
+        }
+    } else {
+        for (int p = tid; p < P; p += 256) sAl[p] = ebuf[(long)b * P + p];
     }
     __syncthreads();
     const int cg = tid & 31, pg = tid >> 5, c = c0 + cg * 8;
@@ -378,6 +384,186 @@ __global__ __launch_bounds__(256) void dec_enc_grad_kernel(const float* __restri
     }
 }
 
+// ============================================================================= compact attention (pooled-map structure)
+// The Encoder's output is AdaptiveAvgPool2d(36) of an 8 x 8 map (models.py:27,39): every one of the P = 1296 "pixels" is the
+// mean of 1, 2 or 4 of the C = 64 cells, and only Q = 225 distinct (cell set) classes exist.  encoder_att, the mean and the
+// weighted context are linear, so they commute with the pooling:
+//     att1[b,p,:] = sum_k w_q att1c[b, cell_k(q), :],   awe = sum_c beta_c feat[b,c,:],   beta_c = sum_{q: c in q} mult_q alpha_q w_q
+// with q = class(p).  A step then streams C*(A+E) instead of P*(A+E) values per image (20x fewer bytes), the tables stay
+// L2-resident, and the result is the same function of the same numbers (f32 accumulation of bf16 cells).
+// Tables (device, built on the host from the pooling geometry): cls_cells [Q][4] (-1 = unused), cls_w [Q] = 1 / #cells,
+// cls_mult [Q] = pixels in the class, pix_class [P].
+struct ClassTables {
+    const int* cells;      // [Q][4]
+    const float* w;        // [Q]
+    const float* mult;     // [Q]
+    const int* pix_class;  // [P]
+};
+
+// grid (bt), 256 threads; LDS: att1c[b] (C*A bf16) | att2 [A] | w_full [A] | e / alpha [Q] | beta [C]
+__global__ __launch_bounds__(256) void decc_score_fwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
+                                                             int ldh, const float* __restrict__ wfull, ClassTables tb,
+                                                             float* __restrict__ alpha_out, float* __restrict__ alq_out,
+                                                             float* __restrict__ beta_out, int P, int Q, int C, int A) {
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    bf16_t* sT = reinterpret_cast<bf16_t*>(smc);
+    float* sA2 = reinterpret_cast<float*>(smc + (size_t)C * A * 2);
+    float* sW = sA2 + A;
+    float* sE = sW + A;
+    float* sBeta = sE + Q;
+    __shared__ float s4[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
+    for (int i = tid; i < C * A / 8; i += 256) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    for (int a = tid; a < A; a += 256) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
+    for (int c = tid; c < C; c += 256) sBeta[c] = 0.f;
+    __syncthreads();
+    for (int q = wave; q < Q; q += 4) {
+        const float wq = tb.w[q];
+        int cell[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cell[k] = tb.cells[q * 4 + k];
+        float acc = 0.f;
+        for (int a0 = lane * 8; a0 < A; a0 += 512) {
+            float pre[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pre[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (cell[k] < 0) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(sT + (long)cell[k] * A + a0);
+                pre[0] += bflo(v.x); pre[1] += bfhi(v.x); pre[2] += bflo(v.y); pre[3] += bfhi(v.y);
+                pre[4] += bflo(v.z); pre[5] += bfhi(v.z); pre[6] += bflo(v.w); pre[7] += bfhi(v.w);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += fmaxf(pre[k] * wq + sA2[a0 + k], 0.f) * sW[a0 + k];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) sE[q] = acc;
+    }
+    __syncthreads();
+    float m = -3.4e38f;
+    for (int q = tid; q < Q; q += 256) m = fmaxf(m, sE[q]);
+    m = block_max(m, s4);
+    float z = 0.f;
+    for (int q = tid; q < Q; q += 256) {
+        const float v = __expf(sE[q] - m);
+        sE[q] = v;
+        z += v * tb.mult[q];
+    }
+    z = block_sum(z, s4);
+    const float inv = 1.f / z;
+    for (int q = tid; q < Q; q += 256) {
+        const float al = sE[q] * inv;                               // alpha of EVERY pixel of class q
+        sE[q] = al;
+        alq_out[(long)b * Q + q] = al;
+        const float bw = al * tb.mult[q] * tb.w[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tb.cells[q * 4 + k];
+            if (c >= 0) atomicAdd(&sBeta[c], bw);
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) alpha_out[(long)b * P + p] = sE[tb.pix_class[p]];
+    for (int c = tid; c < C; c += 256) beta_out[(long)b * C + c] = sBeta[c];
+}
+
+// grid (bt), 256 threads.  dfb [bt][C] = d awe . feat[b,c,:] (from dec_ctx_bwd_kernel run on the cells), galpha [bt][P] or null
+// = the caller's gradient on the returned per-pixel alphas.  Class-total softmax/relu backward, then per 256-channel pass:
+// d att1c[b][c][a] += w_q d pre_q[a] (LDS f32 tile, then one coalesced read-modify-write), d att2 / d w_full by atomics.
+__global__ __launch_bounds__(256) void decc_score_bwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
+                                                             int ldh, const float* __restrict__ wfull, ClassTables tb,
+                                                             const float* __restrict__ alq, const float* __restrict__ dfb,
+                                                             const float* __restrict__ galpha, float* __restrict__ datt1c,
+                                                             float* __restrict__ dhproj, float* __restrict__ dwfull, int P, int Q,
+                                                             int C, int A) {
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    float* sD = reinterpret_cast<float*>(smc);                     // [C][256] f32
+    bf16_t* sT = reinterpret_cast<bf16_t*>(smc + (size_t)C * 256 * 4);   // [C][256] bf16
+    float* sDe = reinterpret_cast<float*>(smc + (size_t)C * 256 * 6);    // [Q] class-total d e
+    float* sGa = sDe + Q;                                                // [Q]
+    __shared__ float s4[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int q = tid; q < Q; q += 256) sGa[q] = 0.f;
+    __syncthreads();
+    if (galpha)
+        for (int p = tid; p < P; p += 256) atomicAdd(&sGa[tb.pix_class[p]], galpha[(long)b * P + p]);
+    __syncthreads();
+    float part = 0.f;
+    for (int q = tid; q < Q; q += 256) {
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tb.cells[q * 4 + k];
+            if (c >= 0) d += dfb[(long)b * C + c];
+        }
+        const float Dq = tb.mult[q] * tb.w[q] * d + sGa[q];
+        sGa[q] = Dq;
+        part += alq[(long)b * Q + q] * Dq;
+    }
+    const float S = block_sum(part, s4);
+    for (int q = tid; q < Q; q += 256) sDe[q] = alq[(long)b * Q + q] * (sGa[q] - tb.mult[q] * S);
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += 256) {                                  // 256-channel passes
+        const int na = min(256, A - a0);
+        for (int i = tid; i < C * 256; i += 256) sD[i] = 0.f;
+        for (int i = tid; i < C * (na / 8); i += 256) {
+            const int c = i / (na / 8), ch = i % (na / 8);
+            *reinterpret_cast<uint4*>(sT + c * 256 + ch * 8) = *reinterpret_cast<const uint4*>(att1c + ((long)b * C + c) * A + a0 + ch * 8);
+        }
+        __syncthreads();
+        const int al = lane * 4;                                           // this lane's 4 channels of the pass
+        float da2[4] = {0.f, 0.f, 0.f, 0.f}, dw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (al < na) {
+            float a2[4], wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a2[k] = hproj[(long)b * ldh + a0 + al + k]; wv[k] = wfull[a0 + al + k]; }
+            for (int q = wave; q < Q; q += 4) {
+                const float wq = tb.w[q], de = sDe[q];
+                int cell[4];
+                float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cell[k] = tb.cells[q * 4 + k];
+                    if (cell[k] < 0) continue;
+                    const uint2 v = *reinterpret_cast<const uint2*>(sT + cell[k] * 256 + al);
+                    pre[0] += bflo(v.x); pre[1] += bfhi(v.x); pre[2] += bflo(v.y); pre[3] += bfhi(v.y);
+                }
+                float dp[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float pr = pre[k] * wq + a2[k];
+                    dw[k] += de * fmaxf(pr, 0.f);
+                    dp[k] = pr > 0.f ? de * wv[k] : 0.f;
+                    da2[k] += dp[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cell[k] < 0) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(&sD[cell[k] * 256 + al + j], wq * dp[j]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                atomicAdd(&dhproj[(long)b * ldh + a0 + al + k], da2[k]);
+                atomicAdd(&dwfull[a0 + al + k], dw[k]);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < C * (na / 4); i += 256) {
+            const int c = i / (na / 4), ch = i % (na / 4);
+            float4* g = reinterpret_cast<float4*>(datt1c + ((long)b * C + c) * A + a0 + ch * 4);
+            const float4 d = *reinterpret_cast<const float4*>(sD + c * 256 + ch * 4);
+            float4 v = *g;
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            *g = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -406,7 +592,7 @@ int ppv_dec_attend_fwd(const void* att1, const void* encs, const float* hproj, i
     const int PS = dec_slab(P);
     dec_score_fwd_kernel<<<dim3(bt, (P + PS - 1) / PS), 256, 2 * A * sizeof(float), stream>>>((const bf16_t*)att1, hproj, ldh, wfull,
                                                                                              ebuf, P, A, PS);
-    dec_ctx_fwd_kernel<<<dim3(bt, (E + 255) / 256), 256, (P + 8 * 256) * sizeof(float), stream>>>(
+    dec_ctx_fwd_kernel<true><<<dim3(bt, (E + 255) / 256), 256, (P + 8 * 256) * sizeof(float), stream>>>(
         (const bf16_t*)encs, ebuf, hproj, ldh, A, alpha_out, awe_save, xh, ldx, x_off, P, E);
     return ppv_last_error();
 }
@@ -468,6 +654,49 @@ int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, 
         attr_set = true;
     }
     dec_enc_grad_kernel<<<dim3(B, (P + 47) / 48, E / 256), 256, lds, stream>>>(part, dmean, alpha, dawe, order, out, B, P, E, T);
+    return ppv_last_error();
+}
+
+// Compact-attention step (see "compact attention" above) for the first bt sorted images.  att1c [B][C][A] bf16 (encoder_att of
+// the CELLS, no bias), feat [B][C][E] bf16, tables on the device; writes alpha_out [bt][P] (per pixel, as the reference
+// returns it), alq_out [bt][Q], beta_out [bt][C], awe_save [bt][E] and the gated context into xh.  C*A*2 + (2A+Q+C)*4 <= 150 KB.
+int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj, int ldh, const float* wfull, const int* cls_cells,
+                        const float* cls_w, const float* cls_mult, const int* pix_class, float* alpha_out, float* alq_out,
+                        float* beta_out, float* awe_save, float* xh, int ldx, int x_off, int bt, int P, int Q, int C, int A, int E,
+                        hipStream_t stream) {
+    if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !alpha_out || !alq_out ||
+        !beta_out || !awe_save || !xh)
+        return PPV_ERR_NULL;
+    const size_t lds = (size_t)C * A * 2 + (size_t)(2 * A + Q + C) * 4;
+    if (bt < 1 || A % 8 || E % 8 || A > 2048 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    ClassTables tb{cls_cells, cls_w, cls_mult, pix_class};
+    decc_score_fwd_kernel<<<bt, 256, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, alpha_out, alq_out, beta_out, P, Q, C, A);
+    dec_ctx_fwd_kernel<false><<<dim3(bt, (E + 255) / 256), 256, (C + 8 * 256) * sizeof(float), stream>>>(
+        (const bf16_t*)feat, beta_out, hproj, ldh, A, nullptr, awe_save, xh, ldx, x_off, C, E);
+    return ppv_last_error();
+}
+
+// Adjoint of ppv_decc_attend_fwd.  dfb [bt][C] scratch; datt1c [B][C][A] f32 ACCUMULATED; dhproj first A columns PRE-ZEROED;
+// dwfull ACCUMULATED; dawe_out [bt][E] (kept for the batched beta^T . d awe GEMM); galpha [bt][P] or null.  C*1536 + 8Q <= 150 KB.
+int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj, int ldh, const float* wfull, const int* cls_cells,
+                        const float* cls_w, const float* cls_mult, const int* pix_class, const float* alq, const float* awe_save,
+                        const float* dxh, int ldx, int x_off, const float* galpha, float* dhproj, float* dawe_out, float* dfb,
+                        float* datt1c, float* dwfull, int bt, int P, int Q, int C, int A, int E, hipStream_t stream) {
+    if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !alq || !awe_save || !dxh ||
+        !dhproj || !dawe_out || !dfb || !datt1c || !dwfull)
+        return PPV_ERR_NULL;
+    const size_t lds = (size_t)C * 256 * 6 + (size_t)Q * 8;
+    if (bt < 1 || A % 8 || E % 8 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    const int PS = dec_slab(C);
+    dec_ctx_bwd_kernel<<<dim3(bt, (C + PS - 1) / PS), 256, E * sizeof(float), stream>>>(
+        (const bf16_t*)feat, dxh, ldx, x_off, hproj, ldh, A, awe_save, nullptr, dhproj, dawe_out, dfb, C, E, PS);
+    ClassTables tb{cls_cells, cls_w, cls_mult, pix_class};
+    decc_score_bwd_kernel<<<bt, 256, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, alq, dfb, galpha, datt1c, dhproj, dwfull,
+                                                    P, Q, C, A);
     return ppv_last_error();
 }
 

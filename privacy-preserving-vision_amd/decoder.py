@@ -16,6 +16,12 @@ How the step is organised (result-identical restructuring, not an approximation)
   the context path's encoder gradient is one batched GEMM alpha^T . d awe, the score path's is accumulated in f32 per
   step and finished with the bf16 MFMA data-/weight-gradient kernels (``ppv_conv_gemm`` / ``ppv_conv_wgrad``).
 
+Compact path.  ``ppv_amd.encoder.Encoder`` hands over, next to the reference-shaped ``[B,36,36,2048]`` tensor, the 8x8 map
+it was average-pooled from (attribute ``_ppv_cells`` on the returned tensor).  encoder_att, the mean and the attention-weighted
+sum are linear, so they commute with that pooling: the decoder then works on the 64 cells and the 225 distinct pixel classes
+(``ppv_decc_attend_*``), streams 20x fewer bytes per step, and sends its gradient straight to the 8x8 map.  Same function of
+the same numbers; any other ``encoder_out`` takes the general path.
+
 Precision: BASELINE.json config 3 (bf16 storage, f32 accumulate) — att1 / encs are bf16; the LSTM state, softmax, all
 reductions and all small per-step GEMMs are f32.  The per-step dense GEMMs (h projections, LSTM gates, vocabulary
 scores) are plain library GEMMs (``torch.addmm`` -> rocBLAS); everything else is libppv_hip.  No CPU path.
@@ -40,36 +46,68 @@ class Attention(nn.Module):
         self.full_att = nn.Linear(attention_dim, 1)
 
 
-def _attend_fwd(att1, encs, hproj, wfull, ebuf, alpha, awe, xh, x_off, bt, P, A, E):
-    check(L().ppv_dec_attend_fwd(ptr(att1), ptr(encs), ptr(hproj), hproj.shape[-1], ptr(wfull), ptr(ebuf), ptr(alpha), ptr(awe),
-                                 ptr(xh), xh.shape[-1], x_off, bt, P, A, E, stream_ptr()), "ppv_dec_attend_fwd")
+def _pool_tables(Hc, Wc, Eo, dev):
+    """Pixel classes of AdaptiveAvgPool2d(Eo) over an Hc x Wc map (torch window rule: [floor(i*n/Eo), ceil((i+1)*n/Eo)) ).
+    -> dict with device tensors cells [Q,4] int32 (-1 unused), w [Q], mult [Q], pix_class [P], gamma [C]; None if a pixel
+    averages more than 4 cells (then the general path is used)."""
+    def win(n):
+        return [(i * n // Eo, -((-(i + 1) * n) // Eo)) for i in range(Eo)]
+    wy, wx = win(Hc), win(Wc)
+    classes, pix = {}, []
+    for i in range(Eo):
+        for j in range(Eo):
+            pix.append(classes.setdefault((wy[i], wx[j]), len(classes)))
+    cells, w, mult = [], [], [0] * len(classes)
+    for q in pix:
+        mult[q] += 1
+    for ((y0, y1), (x0, x1)), q in sorted(classes.items(), key=lambda kv: kv[1]):
+        cs = [y * Wc + x for y in range(y0, y1) for x in range(x0, x1)]
+        if len(cs) > 4:
+            return None
+        cells.append(cs + [-1] * (4 - len(cs)))
+        w.append(1.0 / len(cs))
+    gamma = [0.0] * (Hc * Wc)
+    for q, cs in enumerate(cells):
+        for c in cs:
+            if c >= 0:
+                gamma[c] += mult[q] * w[q] / len(pix)
+    t = lambda v, dt: torch.tensor(v, dtype=dt, device=dev)
+    return {"cells": t(cells, torch.int32), "w": t(w, F32), "mult": t(mult, F32), "pix": t(pix, torch.int32), "gamma": t(gamma, F32),
+            "Q": len(classes), "P": len(pix)}
 
 
 class _DecoderFn(torch.autograd.Function):
-    """Whole decoder forward / hand-written BPTT.  Inputs after (module, static info): encoder_out f32 [B,...,E], then
-    the 18 parameters in ``DecoderWithAttention._plist`` order."""
+    """Whole decoder forward / hand-written BPTT.  ``src`` is encoder_out f32 [B,...,E] (general path, tables None) or the
+    cell map bf16 [B,Hc,Wc,E] (compact path); then the 19 parameters in ``DecoderWithAttention._plist`` order."""
 
     @staticmethod
-    def forward(ctx, mod, caps, order, dec_len, drop_mask_seed, enc, *params):
+    def forward(ctx, mod, caps, order, dec_len, tables, n_pix, src, *params):
         (w_enc, b_enc, w_dec, b_dec, w_full, b_full, w_emb, w_ih, w_hh, b_ih, b_hh, w_h0, b_h0, w_c0, b_c0, w_fb, b_fb,
          w_fc, b_fc) = params
-        dev = enc.device
-        B, E = enc.shape[0], enc.shape[-1]
-        P = enc.numel() // (B * E)
+        dev = src.device
+        B, E = src.shape[0], src.shape[-1]
+        compact = tables is not None
         A, D, M, V = w_enc.shape[0], w_hh.shape[1], w_emb.shape[1], w_fc.shape[0]
         if E % 128 or A % 128:
             raise ValueError("ppv_amd decoder: encoder_dim and attention_dim must be multiples of 128 (MFMA GEMM tiles)")
         T = max(dec_len)
         bts = [sum(1 for l in dec_len if l > t) for t in range(T)]
         X = M + E + D                                            # LSTM GEMM input row: [embedding | gated context | h]
+        P = n_pix
 
-        # ---- once per forward
-        enc_c = enc.contiguous().float()
-        encs = torch.empty((B, P, 1, E), dtype=BF16, device=dev)
-        mean = torch.zeros((B, E), dtype=F32, device=dev)
-        check(L().ppv_dec_prepare(ptr(enc_c), ptr(order), ptr(encs), ptr(mean), B, P, E, stream_ptr()), "ppv_dec_prepare")
+        # ---- once per forward: the streamed tables (R rows per image) and the hoisted encoder_att GEMM
+        if compact:
+            R = src.shape[1] * src.shape[2]
+            rows = src.detach()[order].reshape(B, R, 1, E).contiguous()        # cells in sorted batch order, bf16
+            mean = torch.einsum("c,bce->be", tables["gamma"], rows.view(B, R, E).float())
+        else:
+            R = P
+            rows = torch.empty((B, R, 1, E), dtype=BF16, device=dev)
+            mean = torch.zeros((B, E), dtype=F32, device=dev)
+            check(L().ppv_dec_prepare(ptr(src.contiguous().float()), ptr(order), ptr(rows), ptr(mean), B, R, E, stream_ptr()),
+                  "ppv_dec_prepare")
         wl_enc = co.weight_layout(w_enc.detach().view(A, E, 1, 1), 0)
-        att1 = co.conv_fwd(encs, wl_enc, 1, 0)                   # [B,P,1,A] bf16, no bias (folded below)
+        att = co.conv_fwd(rows, wl_enc, 1, 0)                    # [B,R,1,A] bf16, no bias (folded below)
         w1 = torch.cat([w_dec, w_fb], 0).detach()                # [A+E, D]: decoder_att | f_beta
         b1 = torch.cat([b_dec + b_enc, b_fb], 0).detach()
         w2 = torch.cat([w_ih, w_hh], 1).detach()                 # [4D, X]
@@ -89,15 +127,28 @@ class _DecoderFn(torch.autograd.Function):
         AL = torch.zeros((T, B, P), dtype=F32, device=dev)
         G = torch.zeros((T, B, 4 * D), dtype=F32, device=dev)
         HS = torch.zeros((T, B, D), dtype=F32, device=dev)
-        ebuf = torch.empty((B, P), dtype=F32, device=dev)
         z = torch.empty((B, 4 * D), dtype=F32, device=dev)
+        if compact:
+            Q = tables["Q"]
+            ALQ = torch.zeros((T, B, Q), dtype=F32, device=dev)
+            BETA = torch.zeros((T, B, R), dtype=F32, device=dev)
+        else:
+            ebuf = torch.empty((B, P), dtype=F32, device=dev)
+            ALQ = BETA = None
         w1t, w2t = w1.t(), w2.t()
+        lib = L()
         for t in range(T):
             bt = bts[t]
             torch.addmm(b1, XH[t, :bt, M + E:], w1t, out=HP[t, :bt])
-            _attend_fwd(att1, encs, HP[t], wfull, ebuf, AL[t], AW[t], XH[t], M, bt, P, A, E)
+            if compact:
+                check(lib.ppv_decc_attend_fwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(tables["cells"]), ptr(tables["w"]),
+                                              ptr(tables["mult"]), ptr(tables["pix"]), ptr(AL[t]), ptr(ALQ[t]), ptr(BETA[t]),
+                                              ptr(AW[t]), ptr(XH[t]), X, M, bt, P, Q, R, A, E, stream_ptr()), "ppv_decc_attend_fwd")
+            else:
+                check(lib.ppv_dec_attend_fwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(ebuf), ptr(AL[t]), ptr(AW[t]),
+                                             ptr(XH[t]), X, M, bt, P, A, E, stream_ptr()), "ppv_dec_attend_fwd")
             torch.addmm(b2, XH[t, :bt], w2t, out=z[:bt])
-            check(L().ppv_lstm_cell_fwd(ptr(z), ptr(C[t]), ptr(G[t]), ptr(C[t + 1]), ptr(HS[t]), D, ptr(XH[t + 1, :, M + E:]), X,
+            check(lib.ppv_lstm_cell_fwd(ptr(z), ptr(C[t]), ptr(G[t]), ptr(C[t + 1]), ptr(HS[t]), D, ptr(XH[t + 1, :, M + E:]), X,
                                         bt, D, stream_ptr()), "ppv_lstm_cell_fwd")
         valid = torch.zeros((T, B, 1), dtype=F32, device=dev)
         for t in range(T):
@@ -111,18 +162,19 @@ class _DecoderFn(torch.autograd.Function):
         preds = torch.addmm(b_fc.detach(), HD.view(T * B, D), w_fc.detach().t()).view(T, B, V)
         preds.mul_(valid)                                        # positions past a caption's end stay exactly 0 (models.py:194)
 
-        ctx.mod, ctx.dims = mod, (B, P, E, A, D, M, V, T, X)
-        ctx.bts, ctx.caps, ctx.order = bts, caps, order
-        ctx.saved = (encs, att1, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, G, HD, dmask, valid, w_fc.detach(), w_enc.detach())
-        ctx.enc_shape = enc.shape
+        ctx.mod, ctx.dims = mod, (B, P, R, E, A, D, M, V, T, X)
+        ctx.bts, ctx.caps, ctx.order, ctx.tables = bts, caps, order, tables
+        ctx.saved = (rows, att, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, ALQ, BETA, G, HD, dmask, valid, w_fc.detach(), w_enc.detach())
+        ctx.src_shape, ctx.src_dtype = src.shape, src.dtype
         return preds.transpose(0, 1), AL.transpose(0, 1)
 
     @staticmethod
     def backward(ctx, g_preds, g_alphas):
-        B, P, E, A, D, M, V, T, X = ctx.dims
-        encs, att1, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, G, HD, dmask, valid, w_fc, w_enc = ctx.saved
-        bts, caps, order = ctx.bts, ctx.caps, ctx.order
-        dev = encs.device
+        B, P, R, E, A, D, M, V, T, X = ctx.dims
+        rows, att, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, ALQ, BETA, G, HD, dmask, valid, w_fc, w_enc = ctx.saved
+        bts, caps, order, tables = ctx.bts, ctx.caps, ctx.order, ctx.tables
+        compact = tables is not None
+        dev = rows.device
         if g_preds is None:
             gp = torch.zeros((T, B, V), dtype=F32, device=dev)
         else:
@@ -139,23 +191,31 @@ class _DecoderFn(torch.autograd.Function):
         DHP = torch.zeros((T, B, A + E), dtype=F32, device=dev)
         DX = torch.zeros((T, B, X), dtype=F32, device=dev)
         DAW = torch.zeros((T, B, E), dtype=F32, device=dev)
-        datt1 = torch.zeros((B, P, 1, A), dtype=F32, device=dev)
+        datt = torch.zeros((B, R, 1, A), dtype=F32, device=dev)
         dwfull = torch.zeros(A, dtype=F32, device=dev)
-        dalpha = torch.empty((B, P), dtype=F32, device=dev)
+        scratch = torch.empty((B, R), dtype=F32, device=dev)     # d alpha per pixel (general) / d awe . cell (compact)
         dh_next = torch.zeros((B, D), dtype=F32, device=dev)
         dc_a = torch.zeros((B, D), dtype=F32, device=dev)
         dc_b = torch.zeros((B, D), dtype=F32, device=dev)
         dh = torch.empty((B, D), dtype=F32, device=dev)
+        lib = L()
         for t in range(T - 1, -1, -1):
             bt = bts[t]
             torch.add(dHS[t, :bt], dh_next[:bt], out=dh[:bt])
-            check(L().ppv_lstm_cell_bwd(ptr(G[t]), ptr(C[t]), ptr(C[t + 1]), ptr(dh), ptr(dc_a), ptr(DZ[t]), ptr(dc_b), bt, D,
+            check(lib.ppv_lstm_cell_bwd(ptr(G[t]), ptr(C[t]), ptr(C[t + 1]), ptr(dh), ptr(dc_a), ptr(DZ[t]), ptr(dc_b), bt, D,
                                         stream_ptr()), "ppv_lstm_cell_bwd")
             dc_a, dc_b = dc_b, dc_a                               # rows >= bt of the new dc_a are still zero from earlier steps
             torch.mm(DZ[t, :bt], w2, out=DX[t, :bt])
-            check(L().ppv_dec_attend_bwd(ptr(att1), ptr(encs), ptr(HP[t]), A + E, ptr(wfull), ptr(AL[t]), ptr(AW[t]), ptr(DX[t]), X, M,
-                                         ptr(ga[t]) if ga is not None else None, ptr(DHP[t]), ptr(DAW[t]), ptr(dalpha),
-                                         ptr(datt1), ptr(dwfull), bt, P, A, E, stream_ptr()), "ppv_dec_attend_bwd")
+            gat = ptr(ga[t]) if ga is not None else None
+            if compact:
+                check(lib.ppv_decc_attend_bwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(tables["cells"]), ptr(tables["w"]),
+                                              ptr(tables["mult"]), ptr(tables["pix"]), ptr(ALQ[t]), ptr(AW[t]), ptr(DX[t]), X, M, gat,
+                                              ptr(DHP[t]), ptr(DAW[t]), ptr(scratch), ptr(datt), ptr(dwfull), bt, P, tables["Q"], R, A, E,
+                                              stream_ptr()), "ppv_decc_attend_bwd")
+            else:
+                check(lib.ppv_dec_attend_bwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(AL[t]), ptr(AW[t]), ptr(DX[t]), X, M,
+                                             gat, ptr(DHP[t]), ptr(DAW[t]), ptr(scratch), ptr(datt), ptr(dwfull), bt, P, A, E,
+                                             stream_ptr()), "ppv_dec_attend_bwd")
             torch.addmm(DX[t, :bt, M + E:], DHP[t, :bt], w1, out=dh_next[:bt])
 
         # ---- batched over all steps
@@ -170,25 +230,31 @@ class _DecoderFn(torch.autograd.Function):
         dmean = dhc0 @ w0                                         # [B, E]
 
         # ---- encoder side: score path through the bf16 MFMA kernels, context path as one batched GEMM
-        datt1_bf = datt1.to(BF16)
-        d_wenc = co.conv_wgrad(datt1_bf, encs, 1, 1, 1, 0).view(A, E)
-        g_enc = None
-        if ctx.needs_input_grad[5]:
+        datt_bf = datt.to(BF16)
+        d_wenc = co.conv_wgrad(datt_bf, rows, 1, 1, 1, 0).view(A, E)
+        g_src = None
+        if ctx.needs_input_grad[6]:
             wl_d = co.weight_layout(w_enc.view(A, E, 1, 1), 1)
-            acc = co.conv_dgrad(datt1_bf, wl_d, 1, 0, (P, 1), out_f32=True).view(B, P, E)
-            g_enc = torch.empty((B, P, E), dtype=F32, device=dev)
-            if E % 256 == 0 and T <= 128:                         # one pass: + alpha^T . d awe + d mean / P, un-sorted
-                check(L().ppv_dec_enc_grad(ptr(acc), ptr(dmean), ptr(AL), ptr(DAW), ptr(order), ptr(g_enc), B, P, E, T,
-                                           stream_ptr()), "ppv_dec_enc_grad")
+            acc = co.conv_dgrad(datt_bf, wl_d, 1, 0, (R, 1), out_f32=True).view(B, R, E)
+            if compact:                                           # + beta^T . d awe + gamma (x) d mean, un-sorted, on the cell map
+                acc.baddbmm_(BETA.permute(1, 2, 0), DAW.transpose(0, 1))
+                acc.add_(tables["gamma"].view(1, R, 1) * dmean.view(B, 1, E))
+                g_src = torch.empty(ctx.src_shape, dtype=ctx.src_dtype, device=dev)
+                g_src[order] = acc.view((B,) + tuple(ctx.src_shape[1:])).to(ctx.src_dtype)
             else:
-                acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
-                check(L().ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_enc), B, P, E, stream_ptr()), "ppv_dec_combine")
-            g_enc = g_enc.view(ctx.enc_shape)
+                g_src = torch.empty((B, R, E), dtype=F32, device=dev)
+                if E % 256 == 0 and T <= 128:                     # one pass: + alpha^T . d awe + d mean / P, un-sorted
+                    check(lib.ppv_dec_enc_grad(ptr(acc), ptr(dmean), ptr(AL), ptr(DAW), ptr(order), ptr(g_src), B, R, E, T,
+                                               stream_ptr()), "ppv_dec_enc_grad")
+                else:
+                    acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
+                    check(lib.ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_src), B, R, E, stream_ptr()), "ppv_dec_combine")
+                g_src = g_src.view(ctx.src_shape)
         d_batt = d_b1[:A]
         grads = (d_wenc, d_batt, d_w1[:A], d_batt.clone(), dwfull.view(1, A), torch.zeros(1, dtype=F32, device=dev), d_emb,
                  d_w2[:, :M + E], d_w2[:, M + E:], d_b2, d_b2.clone(), d_w0[:D], d_b0[:D], d_w0[D:], d_b0[D:], d_w1[A:], d_b1[A:],
                  d_wfc, d_bfc)
-        return (None, None, None, None, None, g_enc) + grads
+        return (None, None, None, None, None, None, g_src) + grads
 
 
 class DecoderWithAttention(nn.Module):
@@ -207,6 +273,8 @@ class DecoderWithAttention(nn.Module):
         self.f_beta = nn.Linear(decoder_dim, encoder_dim)
         self.sigmoid = nn.Sigmoid()
         self.fc = nn.Linear(decoder_dim, vocab_size)
+        self.use_compact = True              # take the pooled-map path when encoder_out carries its cell map
+        self._tables = {}
         self.init_weights()
 
     def init_weights(self):
@@ -236,5 +304,17 @@ class DecoderWithAttention(nn.Module):
         lens, order = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
         caps = encoded_captions[order]
         dec_len = (lens - 1).tolist()                                               # models.py:193
-        preds, alphas = _DecoderFn.apply(self, caps, order.contiguous(), dec_len, None, encoder_out, *self._plist())
+        n_pix = encoder_out.numel() // (encoder_out.shape[0] * encoder_out.shape[-1])
+        src, tables = encoder_out, None
+        cells = getattr(encoder_out, "_ppv_cells", None)          # set by ppv_amd.encoder.Encoder on the tensor it returns
+        if (cells is not None and self.use_compact and cells.dim() == 4 and cells.shape[0] == encoder_out.shape[0]
+                and cells.shape[-1] == encoder_out.shape[-1] and encoder_out.dim() == 4 and encoder_out.shape[1] == encoder_out.shape[2]):
+            key = (cells.shape[1], cells.shape[2], encoder_out.shape[1], str(cells.device))
+            if key not in self._tables:
+                self._tables[key] = _pool_tables(cells.shape[1], cells.shape[2], encoder_out.shape[1], cells.device)
+            tb = self._tables[key]
+            R, A = cells.shape[1] * cells.shape[2], self.attention_dim
+            if tb is not None and R * A * 2 + (2 * A + tb["Q"] + R) * 4 <= 150 * 1024 and R * 1536 + 8 * tb["Q"] <= 150 * 1024:
+                src, tables = cells, tb
+        preds, alphas = _DecoderFn.apply(self, caps, order.contiguous(), dec_len, tables, n_pix, src, *self._plist())
         return preds, caps, dec_len, alphas, order

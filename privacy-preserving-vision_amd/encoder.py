@@ -177,11 +177,15 @@ class _TrunkFn(torch.autograd.Function):
             torch._foreach_add_(enc._nbt, 1)
         ctx.enc, ctx.saved, ctx.blocks, ctx.train, ctx.tok = enc, saved, blocks, train, tok
         ctx.img_shape, ctx.last_hw = images.shape, (x.shape[1], x.shape[2])
-        return out
+        ctx.set_materialize_grads(False)
+        # second output: the map the pool up-sampled (a view of the last block's output, so that returning it does not
+        # alias a saved tensor): ppv_amd.decoder works on it directly and sends its gradient here (decoder.py "compact path")
+        return out, x.view(x.shape)
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_cells=None):
         enc = ctx.enc
+        dev0 = (g_out if g_out is not None else g_cells).device
         if not ctx.train:
             raise NotImplementedError("backward through eval-mode BatchNorm is outside the reference's use (validate() "
                                       "runs under no_grad, train.py:355-451)")
@@ -194,11 +198,11 @@ class _TrunkFn(torch.autograd.Function):
                 if rec_ is not None and rec_.conv.weight.requires_grad:
                     w_ = rec_.conv.weight
                     need = max(need, co.wgrad_scratch_bytes(gy_.numel() // gy_.shape[-1], w_.shape[0], rec_.k, rec_.k, w_.shape[1]))
-        wscratch = torch.empty(max(need, 16), dtype=torch.uint8, device=g_out.device)
+        wscratch = torch.empty(max(need, 16), dtype=torch.uint8, device=dev0)
 
         # one zeroed pool for every BN's [32][2][C] backward partial sums of this step
         bn_ch = sum(r.conv.out_channels for blk_ in enc._blocks for r in blk_ if r is not None) + 64
-        bpool = torch.zeros(64 * bn_ch, dtype=torch.float32, device=g_out.device)
+        bpool = torch.zeros(64 * bn_ch, dtype=torch.float32, device=dev0)
         boff = [0]
 
         def bn_part(C):
@@ -226,7 +230,11 @@ class _TrunkFn(torch.autograd.Function):
         # (yout > 0) is applied where that gradient is produced (adaptive-pool backward for the last block, the conv1
         # data-gradient store of the following block otherwise).  bn3 / downsample-bn backward then need neither yout
         # nor a separate masked copy: -2 tensors of the 4C-wide size per block against one extra mask read.
-        g = co.adaptive_pool_bwd(g_out.contiguous(), ctx.last_hw, relu_of=ctx.blocks[-1][-1])
+        last = ctx.blocks[-1][-1]
+        g = co.adaptive_pool_bwd(g_out.contiguous(), ctx.last_hw, relu_of=last) if g_out is not None else None
+        if g_cells is not None:                              # gradient that arrived on the un-pooled map: mask + bf16 (E == H: 1x1 windows)
+            gc = co.adaptive_pool_bwd(g_cells.contiguous(), ctx.last_hw, relu_of=last)
+            g = gc if g is None else g.add_(gc)
         taps = getattr(enc, "_debug_block_grads", None)      # tests: per-block (g_out, g_in) taps, last block first
         for blk, sv in zip(reversed(enc._blocks), reversed(ctx.blocks)):
             g_blk_out = g
@@ -332,7 +340,9 @@ class Encoder(nn.Module):
     def forward(self, images):
         if not images.is_cuda:
             raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
-        return _TrunkFn.apply(self, images, *self._param_list())
+        out, cells = _TrunkFn.apply(self, images, *self._param_list())
+        out._ppv_cells = cells             # the 8x8 map behind the up-sampled output (consumed by ppv_amd.decoder, ignored otherwise)
+        return out
 
     def fine_tune(self, fine_tune=True):
         """models.py:43-54: freeze everything, then un-freeze children [5:] (layer2..4)."""

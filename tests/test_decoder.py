@@ -117,3 +117,69 @@ def test_hip_decoder_vs_oracle_ragged_and_train_mode():
     dec.train()
     p3 = dec(enc.cuda(), caps.cuda(), caplens.cuda())[0]
     assert torch.isfinite(p3).all() and _l2(p3.detach().cpu()[inv2], p1.detach()[inv1]) > 1e-3      # dropout active
+
+
+@pytest.mark.gpu
+def test_hip_decoder_compact_path_equals_general_semantics():
+    """Compact path (decoder works on the cell map behind an adaptive-average-pooled encoder_out) against the oracle run on
+    the pooled tensor: predictions, alphas, parameter gradients and the gradient that reaches the cell map."""
+    import torch.nn.functional as F
+    import ppv_amd.decoder as pd
+    from oracle.decoder import DecoderWithAttention as Ref, caption_loss
+    torch.manual_seed(2)
+    B, E, A, M, D, V, L, Hc, Eo = 6, 256, 128, 32, 48, 40, 8, 4, 9
+    ref = Ref(A, M, D, V, encoder_dim=E, dropout=0.5).eval()
+    fill_by_name(ref)
+    dec = pd.DecoderWithAttention(A, M, D, V, encoder_dim=E, dropout=0.5).eval()
+    dec.load_state_dict(ref.state_dict())
+    dec = dec.cuda()
+    cells = torch.relu(torch.randn(B, Hc, Hc, E)).bfloat16()
+    caps = torch.randint(0, V, (B, L))
+    caplens = torch.tensor([[8], [3], [5], [5], [2], [7]])
+
+    def pooled(c):
+        return F.adaptive_avg_pool2d(c.float().permute(0, 3, 1, 2), Eo).permute(0, 2, 3, 1).contiguous()
+
+    c1 = cells.float().requires_grad_(True)
+    p1, s1, d1, a1, o1 = ref(pooled(c1), caps, caplens)
+    caption_loss(p1, s1, d1, a1).backward()
+
+    c2 = cells.cuda().requires_grad_(True)
+    out = pooled(c2.detach())
+    out._ppv_cells = c2
+    p2, s2, d2, a2, o2 = dec(out, caps.cuda(), caplens.cuda())
+    assert d1 == d2 and o1.tolist() == o2.tolist()
+    assert _l2(p2.detach().cpu(), p1.detach()) < 1e-2 and _l2(a2.detach().cpu(), a1.detach()) < 1e-2
+    assert abs(float(a2.detach().sum(-1)[0, 0]) - 1.0) < 1e-5                       # per-pixel alphas still sum to one
+    caption_loss(p2.cpu(), s2.cpu(), d2, a2.cpu()).backward()
+    assert c2.grad is not None and c2.grad.dtype == torch.bfloat16
+    assert _l2(c2.grad.float().cpu(), c1.grad) < 3e-2 and _cos(c2.grad.float().cpu(), c1.grad) > 0.999
+    for (n, q), (_, r) in zip(dec.named_parameters(), ref.named_parameters()):
+        if n != "attention.full_att.bias":
+            assert _l2(q.grad.cpu(), r.grad) < 6e-2 and _cos(q.grad.cpu(), r.grad) > 0.998, (n, _l2(q.grad.cpu(), r.grad))
+    # the general path on the same pooled tensor (no cell map attached) gives the same predictions
+    dec.zero_grad()
+    p3 = dec(pooled(cells.cuda()), caps.cuda(), caplens.cuda())[0]
+    assert _l2(p3.detach().cpu(), p2.detach().cpu()) < 1e-2
+
+
+@pytest.mark.gpu
+def test_encoder_hands_cell_map_to_decoder():
+    """Encoder -> Decoder end to end on the device: the compact path is taken and gradients reach the trunk."""
+    import ppv_amd.decoder as pd
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(encoded_image_size=9, layers=(1, 1, 1, 1)).cuda().train()
+    dec = pd.DecoderWithAttention(128, 32, 48, 30, encoder_dim=2048, dropout=0.0).cuda().train()
+    img = torch.rand(3, 3, 64, 64, device="cuda")
+    out = enc(img)
+    assert out.shape == (3, 9, 9, 2048) and out._ppv_cells.shape == (3, 2, 2, 2048)
+    caps = torch.randint(0, 30, (3, 6), device="cuda")
+    preds, _, dl, alphas, _ = dec(out, caps, torch.tensor([[6], [4], [5]], device="cuda"))
+    (preds.sum() + alphas.sum()).backward()
+    g = [p.grad for p in enc.parameters() if p.requires_grad]
+    assert all(x is not None and torch.isfinite(x).all() for x in g) and any(float(x.abs().max()) > 0 for x in g)
+    # same step through the general path (cell map ignored): same predictions
+    dec.use_compact = False
+    preds2 = dec(enc(img), caps, torch.tensor([[6], [4], [5]], device="cuda"))[0]
+    assert _l2(preds2.detach().cpu(), preds.detach().cpu()) < 2e-2

@@ -184,9 +184,10 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
                         float* beta_out, float* awe_save, float* xh, int ldx, int x_off, int bt, int P, int Q, int C, int A, int E,
                         ppv_stream_t stream);
 int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj, int ldh, const float* wfull, const int* cls_cells,
-                        const float* cls_w, const float* cls_mult, const int* pix_class, const float* alq, const float* awe_save,
-                        const float* dxh, int ldx, int x_off, const float* galpha, float* dhproj, float* dawe_out, float* dfb,
-                        float* datt1c, float* dwfull, int bt, int P, int Q, int C, int A, int E, ppv_stream_t stream);
+                        const float* cls_w, const float* cls_mult, const int* pix_class, const int* cell_cls, const float* alq,
+                        const float* awe_save, const float* dxh, int ldx, int x_off, const float* galpha, float* dhproj,
+                        float* dawe_out, float* dfb, float* datt1c, float* dwfull, int bt, int P, int Q, int C, int A, int E,
+                        ppv_stream_t stream);
 int ppv_dec_combine(const float* acc, const float* dmean, const long* order, float* out, int B, int P, int E, ppv_stream_t stream);
 
 /* backward of the FD camera: sensor image -> PSF (Optics.py:126-128), PSF + losses -> height map (Optics.py:92-120),

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void dec_ctx_bwd_kernel(const bf16_t* __restri
 // ----------------------------------------------------------------------------- score backward
 // grid (bt, ceil(P / PS)).  d e_p = alpha_p (d alpha_p - sum_q alpha_q d alpha_q);  pre = att1 + att2;
 // d att1[b][p][a] += [pre > 0] d e_p w_a  (f32 read-modify-write);  d att2[b][a] += same summed over p (atomics into
-// dhproj[:, 0:A], pre-zeroed);  d w_full[a] += d e_p relu(pre)  (atomics).  A <= 2048.
+// dhproj[:, 0:A], pre-zeroed);  d w_full[b][a] += d e_p relu(pre)  (atomics, per-image rows).  A <= 2048.
 __global__ __launch_bounds__(256) void dec_score_bwd_kernel(const bf16_t* __restrict__ att1, const float* __restrict__ hproj, int ldh,
                                                             const float* __restrict__ wfull, const float* __restrict__ alpha,
                                                             const float* __restrict__ dalpha, float* __restrict__ datt1,
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void dec_score_bwd_kernel(const bf16_t* __rest
     __syncthreads();
     for (int a = tid; a < A; a += 256) {
         atomicAdd(&dhproj[(long)b * ldh + a], sAcc[a]);
-        atomicAdd(&dwfull[a], sAcc[A + a]);
+        atomicAdd(&dwfull[(long)b * A + a], sAcc[A + a]);        // per-image rows (a single shared row serialises 3456 adders)
     }
 }
 
@@ -469,22 +469,29 @@ __global__ __launch_bounds__(256) void decc_score_fwd_kernel(const bf16_t* __res
     for (int c = tid; c < C; c += 256) beta_out[(long)b * C + c] = sBeta[c];
 }
 
-// grid (bt), 256 threads.  dfb [bt][C] = d awe . feat[b,c,:] (from dec_ctx_bwd_kernel run on the cells), galpha [bt][P] or null
-// = the caller's gradient on the returned per-pixel alphas.  Class-total softmax/relu backward, then per 256-channel pass:
-// d att1c[b][c][a] += w_q d pre_q[a] (LDS f32 tile, then one coalesced read-modify-write), d att2 / d w_full by atomics.
+// grid (bt, ceil(C / 16)), 256 threads: workgroup y owns 16 cells of image b.  dfb [bt][C] = d awe . feat[b,c,:] (from
+// dec_ctx_bwd_kernel run on the cells), galpha [bt][P] or null = the caller's gradient on the returned per-pixel alphas.
+// Class-total softmax backward (every workgroup of the image redoes the 225-term prelude), then GATHER form of the relu /
+// encoder_att backward: a cell sums w_q d pre_q over the <= 12 classes it belongs to (cell_cls [C][12], -1 padded) -- no
+// atomics on the big accumulator, one read-modify-write of the cell's d att1c row; d att2 / d w_full are taken once per class
+// (by the workgroup that owns the class's first cell) with f32 atomics.
 __global__ __launch_bounds__(256) void decc_score_bwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
                                                              int ldh, const float* __restrict__ wfull, ClassTables tb,
-                                                             const float* __restrict__ alq, const float* __restrict__ dfb,
-                                                             const float* __restrict__ galpha, float* __restrict__ datt1c,
-                                                             float* __restrict__ dhproj, float* __restrict__ dwfull, int P, int Q,
-                                                             int C, int A) {
+                                                             const int* __restrict__ cell_cls, const float* __restrict__ alq,
+                                                             const float* __restrict__ dfb, const float* __restrict__ galpha,
+                                                             float* __restrict__ datt1c, float* __restrict__ dhproj,
+                                                             float* __restrict__ dwfull, int P, int Q, int C, int A) {
     extern __shared__ __attribute__((aligned(16))) char smc[];
-    float* sD = reinterpret_cast<float*>(smc);                     // [C][256] f32
-    bf16_t* sT = reinterpret_cast<bf16_t*>(smc + (size_t)C * 256 * 4);   // [C][256] bf16
-    float* sDe = reinterpret_cast<float*>(smc + (size_t)C * 256 * 6);    // [Q] class-total d e
-    float* sGa = sDe + Q;                                                // [Q]
+    bf16_t* sT = reinterpret_cast<bf16_t*>(smc);                          // [C][A] bf16
+    float* sA2 = reinterpret_cast<float*>(smc + (size_t)C * A * 2);       // [A]
+    float* sW = sA2 + A;                                                  // [A]
+    float* sDe = sW + A;                                                  // [Q] class-total d e
+    float* sGa = sDe + Q;                                                 // [Q]
     __shared__ float s4[4];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
+    for (int i = tid; i < C * A / 8; i += 256) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    for (int a = tid; a < A; a += 256) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
     for (int q = tid; q < Q; q += 256) sGa[q] = 0.f;
     __syncthreads();
     if (galpha)
@@ -505,62 +512,46 @@ __global__ __launch_bounds__(256) void decc_score_bwd_kernel(const bf16_t* __res
     const float S = block_sum(part, s4);
     for (int q = tid; q < Q; q += 256) sDe[q] = alq[(long)b * Q + q] * (sGa[q] - tb.mult[q] * S);
     __syncthreads();
-    for (int a0 = 0; a0 < A; a0 += 256) {                                  // 256-channel passes
-        const int na = min(256, A - a0);
-        for (int i = tid; i < C * 256; i += 256) sD[i] = 0.f;
-        for (int i = tid; i < C * (na / 8); i += 256) {
-            const int c = i / (na / 8), ch = i % (na / 8);
-            *reinterpret_cast<uint4*>(sT + c * 256 + ch * 8) = *reinterpret_cast<const uint4*>(att1c + ((long)b * C + c) * A + a0 + ch * 8);
-        }
-        __syncthreads();
-        const int al = lane * 4;                                           // this lane's 4 channels of the pass
-        float da2[4] = {0.f, 0.f, 0.f, 0.f}, dw[4] = {0.f, 0.f, 0.f, 0.f};
-        if (al < na) {
-            float a2[4], wv[4];
+    const int c_lo = blockIdx.y * 16, c_hi = min(c_lo + 16, C);
+    for (int a0 = lane * 8; a0 < A; a0 += 512) {
+        float a2[8], wv[8], da2[8], dw[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a2[k] = hproj[(long)b * ldh + a0 + al + k]; wv[k] = wfull[a0 + al + k]; }
-            for (int q = wave; q < Q; q += 4) {
+        for (int k = 0; k < 8; ++k) { a2[k] = sA2[a0 + k]; wv[k] = sW[a0 + k]; da2[k] = dw[k] = 0.f; }
+        for (int c = c_lo + wave; c < c_hi; c += 4) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 12; ++j) {
+                const int q = cell_cls[c * 12 + j];
+                if (q < 0) break;                                          // wave-uniform
                 const float wq = tb.w[q], de = sDe[q];
-                int cell[4];
-                float pre[4] = {0.f, 0.f, 0.f, 0.f};
+                const bool first = tb.cells[q * 4] == c;                   // this workgroup accounts the class for d att2 / d w
+                float pre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    cell[k] = tb.cells[q * 4 + k];
-                    if (cell[k] < 0) continue;
-                    const uint2 v = *reinterpret_cast<const uint2*>(sT + cell[k] * 256 + al);
+                    const int cc = tb.cells[q * 4 + k];
+                    if (cc < 0) continue;
+                    const uint4 v = *reinterpret_cast<const uint4*>(sT + (long)cc * A + a0);
                     pre[0] += bflo(v.x); pre[1] += bfhi(v.x); pre[2] += bflo(v.y); pre[3] += bfhi(v.y);
+                    pre[4] += bflo(v.z); pre[5] += bfhi(v.z); pre[6] += bflo(v.w); pre[7] += bfhi(v.w);
                 }
-                float dp[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 8; ++k) {
                     const float pr = pre[k] * wq + a2[k];
-                    dw[k] += de * fmaxf(pr, 0.f);
-                    dp[k] = pr > 0.f ? de * wv[k] : 0.f;
-                    da2[k] += dp[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (cell[k] < 0) continue;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) atomicAdd(&sD[cell[k] * 256 + al + j], wq * dp[j]);
+                    const float dp = pr > 0.f ? de * wv[k] : 0.f;
+                    acc[k] += wq * dp;
+                    if (first) { da2[k] += dp; dw[k] += de * fmaxf(pr, 0.f); }
                 }
             }
+            float4* g = reinterpret_cast<float4*>(datt1c + ((long)b * C + c) * A + a0);
+            float4 v0 = g[0], v1 = g[1];
+            v0.x += acc[0]; v0.y += acc[1]; v0.z += acc[2]; v0.w += acc[3];
+            v1.x += acc[4]; v1.y += acc[5]; v1.z += acc[6]; v1.w += acc[7];
+            g[0] = v0; g[1] = v1;
+        }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                atomicAdd(&dhproj[(long)b * ldh + a0 + al + k], da2[k]);
-                atomicAdd(&dwfull[a0 + al + k], dw[k]);
-            }
+        for (int k = 0; k < 8; ++k) {
+            atomicAdd(&dhproj[(long)b * ldh + a0 + k], da2[k]);
+            atomicAdd(&dwfull[(long)b * A + a0 + k], dw[k]);   // per-image rows: <= 16 adders per address (one shared row: 2048)
         }
-        __syncthreads();
-        for (int i = tid; i < C * (na / 4); i += 256) {
-            const int c = i / (na / 4), ch = i % (na / 4);
-            float4* g = reinterpret_cast<float4*>(datt1c + ((long)b * C + c) * A + a0 + ch * 4);
-            const float4 d = *reinterpret_cast<const float4*>(sD + c * 256 + ch * 4);
-            float4 v = *g;
-            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
-            *g = v;
-        }
-        __syncthreads();
     }
 }
 
@@ -599,7 +590,7 @@ int ppv_dec_attend_fwd(const void* att1, const void* encs, const float* hproj, i
 
 // Adjoint of ppv_dec_attend_fwd for one step.  dxh: gradient of the LSTM input rows (gated context at x_off);
 // dalpha_in [bt][P] or null; dhproj [bt][ldh] with its first A columns PRE-ZEROED (att2 part is accumulated, gate part
-// written); dawe_out [bt][E]; dalpha [bt][P] scratch; datt1 [B][P][A] f32 ACCUMULATED; dwfull [A] ACCUMULATED.
+// written); dawe_out [bt][E]; dalpha [bt][P] scratch; datt1 [B][P][A] f32 ACCUMULATED; dwfull [B][A] per-image rows ACCUMULATED.
 int ppv_dec_attend_bwd(const void* att1, const void* encs, const float* hproj, int ldh, const float* wfull, const float* alpha,
                        const float* awe_save, const float* dxh, int ldx, int x_off, const float* dalpha_in, float* dhproj,
                        float* dawe_out, float* dalpha, float* datt1, float* dwfull, int bt, int P, int A, int E,
@@ -678,16 +669,19 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
     return ppv_last_error();
 }
 
-// Adjoint of ppv_decc_attend_fwd.  dfb [bt][C] scratch; datt1c [B][C][A] f32 ACCUMULATED; dhproj first A columns PRE-ZEROED;
-// dwfull ACCUMULATED; dawe_out [bt][E] (kept for the batched beta^T . d awe GEMM); galpha [bt][P] or null.  C*1536 + 8Q <= 150 KB.
+// Adjoint of ppv_decc_attend_fwd.  cell_cls [C][12] (classes a cell belongs to, -1 padded); dfb [bt][C] scratch; datt1c
+// [B][C][A] f32 ACCUMULATED; dhproj first A columns PRE-ZEROED; dwfull [B][A] PER-IMAGE rows ACCUMULATED (sum over b afterwards);
+// dawe_out [bt][E] (kept for the batched
+// beta^T . d awe GEMM); galpha [bt][P] or null.  C*A*2 + (2A+2Q)*4 <= 150 KB.
 int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj, int ldh, const float* wfull, const int* cls_cells,
-                        const float* cls_w, const float* cls_mult, const int* pix_class, const float* alq, const float* awe_save,
-                        const float* dxh, int ldx, int x_off, const float* galpha, float* dhproj, float* dawe_out, float* dfb,
-                        float* datt1c, float* dwfull, int bt, int P, int Q, int C, int A, int E, hipStream_t stream) {
-    if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !alq || !awe_save || !dxh ||
-        !dhproj || !dawe_out || !dfb || !datt1c || !dwfull)
+                        const float* cls_w, const float* cls_mult, const int* pix_class, const int* cell_cls, const float* alq,
+                        const float* awe_save, const float* dxh, int ldx, int x_off, const float* galpha, float* dhproj,
+                        float* dawe_out, float* dfb, float* datt1c, float* dwfull, int bt, int P, int Q, int C, int A, int E,
+                        hipStream_t stream) {
+    if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !cell_cls || !alq || !awe_save ||
+        !dxh || !dhproj || !dawe_out || !dfb || !datt1c || !dwfull)
         return PPV_ERR_NULL;
-    const size_t lds = (size_t)C * 256 * 6 + (size_t)Q * 8;
+    const size_t lds = (size_t)C * A * 2 + (size_t)(2 * A + 2 * Q) * 4;
     if (bt < 1 || A % 8 || E % 8 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
@@ -695,8 +689,8 @@ int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj,
     dec_ctx_bwd_kernel<<<dim3(bt, (C + PS - 1) / PS), 256, E * sizeof(float), stream>>>(
         (const bf16_t*)feat, dxh, ldx, x_off, hproj, ldh, A, awe_save, nullptr, dhproj, dawe_out, dfb, C, E, PS);
     ClassTables tb{cls_cells, cls_w, cls_mult, pix_class};
-    decc_score_bwd_kernel<<<bt, 256, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, alq, dfb, galpha, datt1c, dhproj, dwfull,
-                                                    P, Q, C, A);
+    decc_score_bwd_kernel<<<dim3(bt, (C + 15) / 16), 256, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, cell_cls, alq, dfb,
+                                                                       galpha, datt1c, dhproj, dwfull, P, Q, C, A);
     return ppv_last_error();
 }
 

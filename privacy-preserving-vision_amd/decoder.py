@@ -67,13 +67,18 @@ def _pool_tables(Hc, Wc, Eo, dev):
         cells.append(cs + [-1] * (4 - len(cs)))
         w.append(1.0 / len(cs))
     gamma = [0.0] * (Hc * Wc)
+    cell_cls = [[] for _ in range(Hc * Wc)]
     for q, cs in enumerate(cells):
         for c in cs:
             if c >= 0:
                 gamma[c] += mult[q] * w[q] / len(pix)
+                cell_cls[c].append(q)
+    if max(len(v) for v in cell_cls) > 12:
+        return None
+    cell_cls = [v + [-1] * (12 - len(v)) for v in cell_cls]
     t = lambda v, dt: torch.tensor(v, dtype=dt, device=dev)
     return {"cells": t(cells, torch.int32), "w": t(w, F32), "mult": t(mult, F32), "pix": t(pix, torch.int32), "gamma": t(gamma, F32),
-            "Q": len(classes), "P": len(pix)}
+            "cell_cls": t(cell_cls, torch.int32), "Q": len(classes), "P": len(pix)}
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -192,7 +197,7 @@ class _DecoderFn(torch.autograd.Function):
         DX = torch.zeros((T, B, X), dtype=F32, device=dev)
         DAW = torch.zeros((T, B, E), dtype=F32, device=dev)
         datt = torch.zeros((B, R, 1, A), dtype=F32, device=dev)
-        dwfull = torch.zeros(A, dtype=F32, device=dev)
+        dwfull = torch.zeros((B, A), dtype=F32, device=dev)      # per-image rows: a single shared row serialises the f32 atomics
         scratch = torch.empty((B, R), dtype=F32, device=dev)     # d alpha per pixel (general) / d awe . cell (compact)
         dh_next = torch.zeros((B, D), dtype=F32, device=dev)
         dc_a = torch.zeros((B, D), dtype=F32, device=dev)
@@ -209,7 +214,7 @@ class _DecoderFn(torch.autograd.Function):
             gat = ptr(ga[t]) if ga is not None else None
             if compact:
                 check(lib.ppv_decc_attend_bwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(tables["cells"]), ptr(tables["w"]),
-                                              ptr(tables["mult"]), ptr(tables["pix"]), ptr(ALQ[t]), ptr(AW[t]), ptr(DX[t]), X, M, gat,
+                                              ptr(tables["mult"]), ptr(tables["pix"]), ptr(tables["cell_cls"]), ptr(ALQ[t]), ptr(AW[t]), ptr(DX[t]), X, M, gat,
                                               ptr(DHP[t]), ptr(DAW[t]), ptr(scratch), ptr(datt), ptr(dwfull), bt, P, tables["Q"], R, A, E,
                                               stream_ptr()), "ppv_decc_attend_bwd")
             else:
@@ -250,6 +255,7 @@ class _DecoderFn(torch.autograd.Function):
                     acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
                     check(lib.ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_src), B, R, E, stream_ptr()), "ppv_dec_combine")
                 g_src = g_src.view(ctx.src_shape)
+        dwfull = dwfull.sum(0)
         d_batt = d_b1[:A]
         grads = (d_wenc, d_batt, d_w1[:A], d_batt.clone(), dwfull.view(1, A), torch.zeros(1, dtype=F32, device=dev), d_emb,
                  d_w2[:, :M + E], d_w2[:, M + E:], d_b2, d_b2.clone(), d_w0[:D], d_b0[:D], d_w0[D:], d_b0[D:], d_w1[A:], d_b1[A:],
@@ -314,7 +320,7 @@ class DecoderWithAttention(nn.Module):
                 self._tables[key] = _pool_tables(cells.shape[1], cells.shape[2], encoder_out.shape[1], cells.device)
             tb = self._tables[key]
             R, A = cells.shape[1] * cells.shape[2], self.attention_dim
-            if tb is not None and R * A * 2 + (2 * A + tb["Q"] + R) * 4 <= 150 * 1024 and R * 1536 + 8 * tb["Q"] <= 150 * 1024:
+            if tb is not None and R * A * 2 + (2 * A + tb["Q"] + R) * 4 <= 150 * 1024 and R * A * 2 + (2 * A + 2 * tb["Q"]) * 4 <= 150 * 1024:
                 src, tables = cells, tb
         preds, alphas = _DecoderFn.apply(self, caps, order.contiguous(), dec_len, tables, n_pix, src, *self._plist())
         return preds, caps, dec_len, alphas, order

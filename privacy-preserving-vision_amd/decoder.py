@@ -46,6 +46,24 @@ class Attention(nn.Module):
         self.full_att = nn.Linear(attention_dim, 1)
 
 
+def _numel(shape):
+    n = 1
+    for v in shape:
+        n *= v
+    return n
+
+
+def _carve_zeros(sizes, dev):
+    """One zero-filled f32 allocation carved into named views (each 256-byte aligned: the kernels use 16-byte accesses)."""
+    pad = lambda n: (n + 63) // 64 * 64
+    ws = torch.zeros(sum(pad(_numel(sh)) for _, sh in sizes), dtype=F32, device=dev)
+    out, off = {}, 0
+    for name, sh in sizes:
+        out[name] = ws[off:off + _numel(sh)].view(sh)
+        off += pad(_numel(sh))
+    return out
+
+
 def _pool_tables(Hc, Wc, Eo, dev):
     """Pixel classes of AdaptiveAvgPool2d(Eo) over an Hc x Wc map (torch window rule: [floor(i*n/Eo), ceil((i+1)*n/Eo)) ).
     -> dict with device tensors cells [Q,4] int32 (-1 unused), w [Q], mult [Q], pix_class [P], gamma [C]; None if a pixel
@@ -122,24 +140,18 @@ class _DecoderFn(torch.autograd.Function):
         wfull = w_full.detach().reshape(-1).contiguous()
         hc0 = torch.addmm(b0, mean, w0.t())                      # models.py:150-155
 
-        XH = torch.zeros((T + 1, B, X), dtype=F32, device=dev)
+        # one zero-filled f32 workspace for everything a finished caption leaves untouched (rows >= bt of a step)
+        Q = tables["Q"] if compact else 0
+        sizes = [("XH", (T + 1, B, X)), ("HP", (T, B, A + E)), ("AW", (T, B, E)), ("AL", (T, B, P)), ("G", (T, B, 4 * D)),
+                 ("HS", (T, B, D)), ("ALQ", (T, B, Q)), ("BETA", (T, B, R if compact else 0))]
+        bufs = _carve_zeros(sizes, dev)
+        XH, HP, AW, AL, G, HS, ALQ, BETA = (bufs[k] for k in ("XH", "HP", "AW", "AL", "G", "HS", "ALQ", "BETA"))
         XH[:T, :, :M] = w_emb.detach()[caps[:, :T]].transpose(0, 1)
         XH[0, :, M + E:] = hc0[:, :D]
         C = torch.empty((T + 1, B, D), dtype=F32, device=dev)
         C[0] = hc0[:, D:]
-        HP = torch.zeros((T, B, A + E), dtype=F32, device=dev)
-        AW = torch.zeros((T, B, E), dtype=F32, device=dev)
-        AL = torch.zeros((T, B, P), dtype=F32, device=dev)
-        G = torch.zeros((T, B, 4 * D), dtype=F32, device=dev)
-        HS = torch.zeros((T, B, D), dtype=F32, device=dev)
         z = torch.empty((B, 4 * D), dtype=F32, device=dev)
-        if compact:
-            Q = tables["Q"]
-            ALQ = torch.zeros((T, B, Q), dtype=F32, device=dev)
-            BETA = torch.zeros((T, B, R), dtype=F32, device=dev)
-        else:
-            ebuf = torch.empty((B, P), dtype=F32, device=dev)
-            ALQ = BETA = None
+        ebuf = None if compact else torch.empty((B, P), dtype=F32, device=dev)
         w1t, w2t = w1.t(), w2.t()
         lib = L()
         for t in range(T):
@@ -155,9 +167,7 @@ class _DecoderFn(torch.autograd.Function):
             torch.addmm(b2, XH[t, :bt], w2t, out=z[:bt])
             check(lib.ppv_lstm_cell_fwd(ptr(z), ptr(C[t]), ptr(G[t]), ptr(C[t + 1]), ptr(HS[t]), D, ptr(XH[t + 1, :, M + E:]), X,
                                         bt, D, stream_ptr()), "ppv_lstm_cell_fwd")
-        valid = torch.zeros((T, B, 1), dtype=F32, device=dev)
-        for t in range(T):
-            valid[t, :bts[t]] = 1.0
+        valid = (torch.arange(B, device=dev).view(1, B, 1) < torch.tensor(bts, device=dev).view(T, 1, 1)).to(F32)
         if mod.training and mod.p_drop > 0:                      # models.py:211 nn.Dropout
             keep = 1.0 - mod.p_drop
             dmask = (torch.rand((T, B, D), device=dev) < keep).to(F32) / keep
@@ -192,16 +202,12 @@ class _DecoderFn(torch.autograd.Function):
             dHS = dHS * dmask
         ga = None if g_alphas is None else (g_alphas.transpose(0, 1).float() * valid).contiguous()
 
-        DZ = torch.zeros((T, B, 4 * D), dtype=F32, device=dev)
-        DHP = torch.zeros((T, B, A + E), dtype=F32, device=dev)
-        DX = torch.zeros((T, B, X), dtype=F32, device=dev)
-        DAW = torch.zeros((T, B, E), dtype=F32, device=dev)
-        datt = torch.zeros((B, R, 1, A), dtype=F32, device=dev)
-        dwfull = torch.zeros((B, A), dtype=F32, device=dev)      # per-image rows: a single shared row serialises the f32 atomics
+        sizes = [("DZ", (T, B, 4 * D)), ("DHP", (T, B, A + E)), ("DX", (T, B, X)), ("DAW", (T, B, E)), ("datt", (B, R, 1, A)),
+                 ("dwfull", (B, A)), ("dh_next", (B, D)), ("dc_a", (B, D)), ("dc_b", (B, D))]
+        bufs = _carve_zeros(sizes, dev)
+        DZ, DHP, DX, DAW, datt, dwfull, dh_next, dc_a, dc_b = (bufs[k] for k in ("DZ", "DHP", "DX", "DAW", "datt", "dwfull", "dh_next",
+                                                                                   "dc_a", "dc_b"))   # dwfull: per-image rows
         scratch = torch.empty((B, R), dtype=F32, device=dev)     # d alpha per pixel (general) / d awe . cell (compact)
-        dh_next = torch.zeros((B, D), dtype=F32, device=dev)
-        dc_a = torch.zeros((B, D), dtype=F32, device=dev)
-        dc_b = torch.zeros((B, D), dtype=F32, device=dev)
         dh = torch.empty((B, D), dtype=F32, device=dev)
         lib = L()
         for t in range(T - 1, -1, -1):

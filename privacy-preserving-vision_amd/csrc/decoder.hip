@@ -400,8 +400,8 @@ struct ClassTables {
     const int* pix_class;  // [P]
 };
 
-// grid (bt), 256 threads; LDS: att1c[b] (C*A bf16) | att2 [A] | w_full [A] | e / alpha [Q] | beta [C]
-__global__ __launch_bounds__(256) void decc_score_fwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
+// grid (bt), 512 threads (8 waves: only bt <= 128 workgroups exist, so each one is made as wide as the class loop allows); LDS: att1c[b] (C*A bf16) | att2 [A] | w_full [A] | e / alpha [Q] | beta [C]
+__global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
                                                              int ldh, const float* __restrict__ wfull, ClassTables tb,
                                                              float* __restrict__ alpha_out, float* __restrict__ alq_out,
                                                              float* __restrict__ beta_out, int P, int Q, int C, int A) {
@@ -411,14 +411,14 @@ __global__ __launch_bounds__(256) void decc_score_fwd_kernel(const bf16_t* __res
     float* sW = sA2 + A;
     float* sE = sW + A;
     float* sBeta = sE + Q;
-    __shared__ float s4[4];
+    __shared__ float s8[8];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
-    for (int i = tid; i < C * A / 8; i += 256) reinterpret_cast<uint4*>(sT)[i] = src[i];
-    for (int a = tid; a < A; a += 256) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
-    for (int c = tid; c < C; c += 256) sBeta[c] = 0.f;
+    for (int i = tid; i < C * A / 8; i += 512) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    for (int a = tid; a < A; a += 512) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
+    for (int c = tid; c < C; c += 512) sBeta[c] = 0.f;
     __syncthreads();
-    for (int q = wave; q < Q; q += 4) {
+    for (int q = wave; q < Q; q += 8) {
         const float wq = tb.w[q];
         int cell[4];
 #pragma unroll
@@ -443,17 +443,24 @@ __global__ __launch_bounds__(256) void decc_score_fwd_kernel(const bf16_t* __res
     }
     __syncthreads();
     float m = -3.4e38f;
-    for (int q = tid; q < Q; q += 256) m = fmaxf(m, sE[q]);
-    m = block_max(m, s4);
+    for (int q = tid; q < Q; q += 512) m = fmaxf(m, sE[q]);
+    m = wave_max(m);
+    if (lane == 0) s8[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(fmaxf(s8[0], s8[1]), fmaxf(s8[2], s8[3])), fmaxf(fmaxf(s8[4], s8[5]), fmaxf(s8[6], s8[7])));
+    __syncthreads();
     float z = 0.f;
-    for (int q = tid; q < Q; q += 256) {
+    for (int q = tid; q < Q; q += 512) {
         const float v = __expf(sE[q] - m);
         sE[q] = v;
         z += v * tb.mult[q];
     }
-    z = block_sum(z, s4);
+    z = wave_sum(z);
+    if (lane == 0) s8[wave] = z;
+    __syncthreads();
+    z = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     const float inv = 1.f / z;
-    for (int q = tid; q < Q; q += 256) {
+    for (int q = tid; q < Q; q += 512) {
         const float al = sE[q] * inv;                               // alpha of EVERY pixel of class q
         sE[q] = al;
         alq_out[(long)b * Q + q] = al;
@@ -465,8 +472,8 @@ __global__ __launch_bounds__(256) void decc_score_fwd_kernel(const bf16_t* __res
         }
     }
     __syncthreads();
-    for (int p = tid; p < P; p += 256) alpha_out[(long)b * P + p] = sE[tb.pix_class[p]];
-    for (int c = tid; c < C; c += 256) beta_out[(long)b * C + c] = sBeta[c];
+    for (int p = tid; p < P; p += 512) alpha_out[(long)b * P + p] = sE[tb.pix_class[p]];
+    for (int c = tid; c < C; c += 512) beta_out[(long)b * C + c] = sBeta[c];
 }
 
 // grid (bt, ceil(C / 16)), 256 threads: workgroup y owns 16 cells of image b.  dfb [bt][C] = d awe . feat[b,c,:] (from
@@ -663,7 +670,7 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
     ClassTables tb{cls_cells, cls_w, cls_mult, pix_class};
-    decc_score_fwd_kernel<<<bt, 256, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, alpha_out, alq_out, beta_out, P, Q, C, A);
+    decc_score_fwd_kernel<<<bt, 512, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, alpha_out, alq_out, beta_out, P, Q, C, A);
     dec_ctx_fwd_kernel<false><<<dim3(bt, (E + 255) / 256), 256, (C + 8 * 256) * sizeof(float), stream>>>(
         (const bf16_t*)feat, beta_out, hproj, ldh, A, nullptr, awe_save, xh, ldx, x_off, C, E);
     return ppv_last_error();

@@ -83,9 +83,10 @@ int ppv_zernike_max_order(void);
  *   dgrad:   a = 1, off = -(k-1-pad), div = stride, Wt = [Cin][R][S][Cout] taps flipped.
  * stat_part [stat_rows][2][N]: PRE-ZEROED partial (sum, sum of squares) of the bf16-rounded outputs (train-mode BN;
  * row tiles fold into row tile % stat_rows with f32 atomics; ppv_conv_stat_tiles(M) gives stat_rows) or NULL; addend [M][N] bf16 is added before rounding (residual-gradient accumulation) or NULL;
- * mask_src [M][N] bf16 or NULL: output lanes whose mask_src lane is <= 0 are stored as 0 (the ReLU backward of the tensor
- * the data gradient flows into, torchvision Bottleneck `out = relu(out + identity)`, folded into the store). */
-int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_src,
+ * mask_bits [M*N/8] bytes or NULL (bit k of byte i <-> element 8i+k, written by ppv_bn_act's pos_bits): output lanes whose
+ * bit is clear are stored as 0 (the ReLU backward of the tensor the data gradient flows into, torchvision Bottleneck
+ * `out = relu(out + identity)`, folded into the store at 1/16 of the mask tensor's bytes). */
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
                   const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a,
                   int off, int div, int out_f32, int stat_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
@@ -106,7 +107,7 @@ int ppv_stem_dgrad_scatter(const float* t, float* g, int B, int Ho, int Wo, ppv_
 /* train-mode BatchNorm2d (+ residual, + ReLU), forward and backward */
 int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, int C, ppv_stream_t stream);
-int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, long n, int C,
+int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, void* pos_bits, long n, int C,
                int res_mode, int relu, long res_mod, ppv_stream_t stream);
 int ppv_bn_bwd_blocks(long rows, int C);
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,

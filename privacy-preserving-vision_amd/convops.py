@@ -104,9 +104,10 @@ def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
     return out
 
 
-def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_of=None):
+def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=None):
     """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend);
-    relu_of: the conv input itself when it is a ReLU output -> lanes where it is <= 0 get a zero gradient."""
+    relu_bits: (conv input > 0) bit mask from bn_act(..., want_bits=True) when that input is a ReLU output -> lanes whose bit
+    is clear get a zero gradient."""
     B, Ho, Wo, Cout = g.shape
     Cin, R, S, _ = wd.shape
     H, W = in_hw
@@ -114,7 +115,7 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_of=No
     kind = "conv_gemm<128>" if Cin % 128 == 0 else "conv_gemm<64>"
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
     _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
-        L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(relu_of), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
+        L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(relu_bits), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
                           H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), 0, stream_ptr()), "ppv_conv_gemm"))
     return out
 
@@ -175,13 +176,15 @@ def bn_finalize(stat_part, count, gamma, beta, run_mean, run_var, momentum=0.1, 
     return coef
 
 
-def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False):
-    """y = act(x*scale + shift + res); res_broadcast: res holds one image's worth of elements shared by the batch."""
+def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, want_bits=False):
+    """y = act(x*scale + shift + res); res_broadcast: res holds one image's worth of elements shared by the batch.
+    want_bits: also return the (y > 0) bit mask (uint8, numel / 8 bytes) that conv_dgrad(relu_bits=...) consumes."""
     y = torch.empty_like(x)
+    bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if want_bits else None
     mode = 0 if res is None else (1 if coef_res is None else 2)
-    check(L().ppv_bn_act(ptr(x), ptr(coef), ptr(res), ptr(coef_res), ptr(y), x.numel(), x.shape[-1], mode, int(relu),
+    check(L().ppv_bn_act(ptr(x), ptr(coef), ptr(res), ptr(coef_res), ptr(y), ptr(bits), x.numel(), x.shape[-1], mode, int(relu),
                          res.numel() if (res is not None and res_broadcast) else 0, stream_ptr()), "ppv_bn_act")
-    return y
+    return (y, bits) if want_bits else y
 
 
 def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None):

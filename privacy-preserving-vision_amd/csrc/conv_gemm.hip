@@ -42,10 +42,11 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
     return __builtin_bit_cast(float, (unsigned)h << 16);
 }
 
-// keep the bf16 lanes of v whose mask_src lane is > 0 (ReLU mask of the tensor the gradient flows into)
-__device__ __forceinline__ uint4 relu_mask8(uint4 v, uint4 m) {
-    auto keep = [](unsigned w) { return ((short)(w & 0xffffu) > 0 ? 0xffffu : 0u) | ((int)w > 0xffff ? 0xffff0000u : 0u); };
-    v.x &= keep(m.x); v.y &= keep(m.y); v.z &= keep(m.z); v.w &= keep(m.w);
+// keep the bf16 lanes of v whose bit is set in b (bit k <-> lane k): the ReLU mask of the tensor the gradient flows into,
+// as written by ppv_bn_act's pos_bits
+__device__ __forceinline__ uint4 relu_mask8(uint4 v, unsigned b) {
+    auto keep = [](unsigned two) { return ((two & 1u) ? 0xffffu : 0u) | ((two & 2u) ? 0xffff0000u : 0u); };
+    v.x &= keep(b); v.y &= keep(b >> 2); v.z &= keep(b >> 4); v.w &= keep(b >> 6);
     return v;
 }
 
@@ -59,7 +60,7 @@ __device__ __forceinline__ uint4 relu_mask8(uint4 v, uint4 m) {
 template <int BN, int WM, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                            void* __restrict__ Out, float* __restrict__ stat_part,
-                                                           const bf16_t* __restrict__ addend, const bf16_t* __restrict__ mask_src,
+                                                           const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                            const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                            int tiles_n, int stat_rows) {
     constexpr int BM = 128, BK = 64, WN = 4 / WM;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
         if (idx < BM * CPR && m < g.M)
         {
             uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
-            if (mask_src) v = relu_mask8(v, *reinterpret_cast<const uint4*>(mask_src + m * g.N + n0 + ch * 8));
+            if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
             *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
         }
     }
@@ -256,7 +257,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile(
 template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
-                                                                   const bf16_t* __restrict__ addend, const bf16_t* __restrict__ mask_src,
+                                                                   const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                                    int tiles_n, int stat_rows) {
     constexpr int NT = BM * 2, NWAVE = NT / 64;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                     if (idx < HR * CPR && m < g.M)
                     {
                         uint4 v = *reinterpret_cast<const uint4*>(sOh + row * LDO + ch * 16);
-                        if (mask_src) v = relu_mask8(v, *reinterpret_cast<const uint4*>(mask_src + m * g.N + n0 + ch * 8));
+                        if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
                         *reinterpret_cast<uint4*>(outp + m * g.N + n0 + ch * 8) = v;
                     }
                 }
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         if (idx < BM * CPR && m < g.M)
         {
             uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
-            if (mask_src) v = relu_mask8(v, *reinterpret_cast<const uint4*>(mask_src + m * g.N + n0 + ch * 8));
+            if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
             *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
         }
     }
@@ -610,9 +611,9 @@ int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
 // Generic NHWC bf16 gather-GEMM convolution (see file header).  X [B,Hs,Ws,Cs] bf16, Wt [N][R*S*Cs] bf16,
 // out [B*Ho*Wo][N] bf16 (out_f32 = 0) or f32 (out_f32 = 1: parity tests and the stem data gradient),
 // stat_part [stat_rows][2][N] f32 BN partial sums, PRE-ZEROED by the caller (may be null), addend [M][N] bf16 (may be null),
-// mask_src [M][N] bf16 (may be null): output lanes whose mask_src lane is <= 0 are zeroed (ReLU backward folded into the
-// data-gradient store); zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
-int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_src,
+// mask_bits [M * N / 8] bytes (may be null; bit k of byte i <-> element 8 i + k, as ppv_bn_act's pos_bits writes them): output
+// lanes whose bit is clear are zeroed (ReLU backward folded into the data-gradient store); zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
                   const void* zero_page,
                   int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
                   int out_f32, int stat_rows, hipStream_t stream) {
@@ -627,7 +628,7 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     const bf16_t* x = (const bf16_t*)X;
     const bf16_t* w = (const bf16_t*)Wt;
     const bf16_t* ad = (const bf16_t*)addend;
-    const bf16_t* mk = (const bf16_t*)mask_src;
+    const unsigned char* mk = (const unsigned char*)mask_bits;
     if (mk && out_f32) return PPV_ERR_BAD_SIZE;                 // the mask applies to the bf16 store path only
     const bf16_t* z = (const bf16_t*)zero_page;
 #define PPV_LAUNCH(BN_, WM_, TN_)                                                                                       \

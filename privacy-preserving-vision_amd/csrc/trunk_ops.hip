@@ -71,7 +71,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 template <int RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ x, const float* __restrict__ coef1,
                                                      const bf16_t* __restrict__ r, const float* __restrict__ coef2,
-                                                     bf16_t* __restrict__ y, long n8, int C, long res_mod8) {
+                                                     bf16_t* __restrict__ y, unsigned char* __restrict__ pos_bits, long n8, int C,
+                                                     long res_mod8) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const int c0 = (int)((i * 8) % C);
@@ -90,6 +91,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
         o[k] = RELU ? fmaxf(v, 0.f) : v;
     }
     store8(y + i * 8, o);
+    if (pos_bits) {                                   // bit k = (y[8 i + k] > 0): the ReLU mask at 1/16 of the tensor's bytes
+        unsigned b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b |= (o[k] > 0.f ? 1u : 0u) << k;
+        pos_bits[i] = (unsigned char)b;
+    }
 }
 
 // ----------------------------------------------------------------------------- BN backward
@@ -347,20 +354,22 @@ int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, 
 
 // y = act(x*s1+t1 + res);  res_mode 0 none, 1 identity r, 2 r*s2+t2 (coef2); res_mod > 0: r holds res_mod elements and
 // is broadcast (index modulo), e.g. a per-pixel constant map shared by the batch
-int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, long n, int C, int res_mode,
-               int relu, long res_mod, hipStream_t stream) {
+// pos_bits (n / 8 bytes, may be null): bit k of byte i = (y[8 i + k] > 0), consumed by ppv_conv_gemm's mask_bits
+int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, void* pos_bits, long n, int C,
+               int res_mode, int relu, long res_mod, hipStream_t stream) {
     if (!x || !coef1 || !y || (res_mode && !r) || (res_mode == 2 && !coef2)) return PPV_ERR_NULL;
     if (C % 8 || n % 8) return PPV_ERR_BAD_SIZE;
     const long n8 = n / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
     const bf16_t *xx = (const bf16_t*)x, *rr = (const bf16_t*)r;
     bf16_t* yy = (bf16_t*)y;
-    if (res_mode == 0 && relu) bn_act_kernel<0, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
-    else if (res_mode == 0) bn_act_kernel<0, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
-    else if (res_mode == 1 && relu) bn_act_kernel<1, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
-    else if (res_mode == 1) bn_act_kernel<1, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
-    else if (relu) bn_act_kernel<2, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
-    else bn_act_kernel<2, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, n8, C, res_mod / 8);
+    unsigned char* pb = (unsigned char*)pos_bits;
+    if (res_mode == 0 && relu) bn_act_kernel<0, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
+    else if (res_mode == 0) bn_act_kernel<0, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
+    else if (res_mode == 1 && relu) bn_act_kernel<1, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
+    else if (res_mode == 1) bn_act_kernel<1, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
+    else if (relu) bn_act_kernel<2, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
+    else bn_act_kernel<2, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
     return ppv_last_error();
 }
 

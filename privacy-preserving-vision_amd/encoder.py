@@ -146,6 +146,7 @@ class _TrunkFn(torch.autograd.Function):
         saved["stem"] = (raw0, c0, y0, arg0)
         x = y0
         blocks = []
+        xin_bits = None        # (block input > 0) bit mask; the first block's input is the max-pool output, masked by its own backward
         for blk in enc._blocks:
             xin = x
             r1, r2, r3, rd = blk
@@ -166,12 +167,13 @@ class _TrunkFn(torch.autograd.Function):
                 p = part_for(Bn * H2 * W2, rd.conv.out_channels)
                 xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, p)
                 cd = _bn_coef(rd, p, Bn * H2 * W2)
-                yout = co.bn_act(x3, c3, res=xd, coef_res=cd)
+                yo = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=train)
             else:
                 xd = cd = None
-                yout = co.bn_act(x3, c3, res=xin)
-            blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout))
-            x = yout
+                yo = co.bn_act(x3, c3, res=xin, want_bits=train)
+            yout, ybits = yo if train else (yo, None)
+            blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
+            x, xin_bits = yout, ybits
         out = co.adaptive_pool_fwd(x, enc.enc_image_size)
         if train:
             torch._foreach_add_(enc._nbt, 1)
@@ -230,7 +232,7 @@ class _TrunkFn(torch.autograd.Function):
         # (yout > 0) is applied where that gradient is produced (adaptive-pool backward for the last block, the conv1
         # data-gradient store of the following block otherwise).  bn3 / downsample-bn backward then need neither yout
         # nor a separate masked copy: -2 tensors of the 4C-wide size per block against one extra mask read.
-        last = ctx.blocks[-1][-1]
+        last = ctx.blocks[-1][11]
         g = co.adaptive_pool_bwd(g_out.contiguous(), ctx.last_hw, relu_of=last) if g_out is not None else None
         if g_cells is not None:                              # gradient that arrived on the un-pooled map: mask + bf16 (E == H: 1x1 windows)
             gc = co.adaptive_pool_bwd(g_cells.contiguous(), ctx.last_hw, relu_of=last)
@@ -239,7 +241,7 @@ class _TrunkFn(torch.autograd.Function):
         for blk, sv in zip(reversed(enc._blocks), reversed(ctx.blocks)):
             g_blk_out = g
             r1, r2, r3, rd = blk
-            xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout = sv
+            xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits = sv
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
             gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0)
             gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
@@ -249,9 +251,9 @@ class _TrunkFn(torch.autograd.Function):
             if rd is not None:
                 gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)
-                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_of=xin)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_bits=xin_bits)
             else:
-                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=g, relu_of=xin)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=g, relu_bits=xin_bits)
             if taps is not None:
                 taps.append((g_blk_out, g))
         g_img = None

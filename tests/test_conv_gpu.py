@@ -56,11 +56,12 @@ def test_conv_dgrad(B, H, Cin, Cout, k, stride):
     add = torch.randn(want.shape, generator=torch.Generator().manual_seed(9)).bfloat16()
     got2 = co.conv_dgrad(gd, wd, stride, pad, (H, H), addend=add.cuda())
     assert rel_err(got2.float(), want + add.float()) < 2 ** -8 + 1e-3
-    # ReLU mask of the conv input folded into the store: lanes where relu_of <= 0 (incl. -0.0 and +0.0) are exactly zero
+    # ReLU mask of the conv input folded into the store (1 bit per element): lanes whose bit is clear are exactly zero
     act = torch.relu(torch.randn(want.shape, generator=torch.Generator().manual_seed(11))).bfloat16()
     act.view(-1)[::7] = -0.0
-    got3 = co.conv_dgrad(gd, wd, stride, pad, (H, H), addend=add.cuda(), relu_of=act.cuda())
     keep = (act.float() > 0).cuda()
+    bits = (keep.reshape(-1, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    got3 = co.conv_dgrad(gd, wd, stride, pad, (H, H), addend=add.cuda(), relu_bits=bits)
     assert torch.equal(got3, torch.where(keep, got2, torch.zeros_like(got2)))
-    got4 = co.conv_dgrad(gd, wd, stride, pad, (H, H), relu_of=act.cuda())
+    got4 = co.conv_dgrad(gd, wd, stride, pad, (H, H), relu_bits=bits)
     assert rel_err(got4.float(), want * keep.cpu()) < 2 ** -8 + 1e-3

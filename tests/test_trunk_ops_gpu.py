@@ -83,8 +83,10 @@ def test_batchnorm_train_forward_backward(C, res_mode):
     assert rel_err(rmd, rm) < 1e-4 and rel_err(rvd, rv) < 1e-4
     resd = nhwc(res).cuda().bfloat16() if res_mode else None
     coef2 = torch.stack([g2, b2, g2, g2]).cuda().contiguous() if res_mode == 2 else None
-    yd = co.bn_act(xd, coef, resd, coef2, relu=True)
+    yd, bits = co.bn_act(xd, coef, resd, coef2, relu=True, want_bits=True)
     assert rel_err(yd.float(), nhwc(y.detach())) < BF
+    want_bits = ((yd.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want_bits)                       # bit k of byte i <-> (y[8 i + k] > 0), exactly
     gx, gpre, dg, db = co.bn_bwd(nhwc(gy).cuda().bfloat16(), yd, xd, coef, relu=True, want_gpre=True)
     assert rel_err(gx.float(), nhwc(x.grad)) < 2 * BF
     assert rel_err(dg, gamma.grad) < 5e-3 and rel_err(db, beta.grad) < 5e-3

@@ -10,7 +10,7 @@ for cin, cout, h, cnt in SH:
     NB = max(2, int(600e6 // (B * h * h * (2 * cin + cout) * 2)) + 1)
     gs = [torch.randn(B, h, h, cout, device="cuda").bfloat16() for _ in range(NB)]
     adds = [torch.randn(B, h, h, cin, device="cuda").bfloat16() for _ in range(NB)]
-    acts = [torch.relu(torch.randn(B, h, h, cin, device="cuda")).bfloat16() for _ in range(NB)]
+    acts = [torch.randint(0, 256, (B * h * h * cin // 8,), device="cuda", dtype=torch.uint8) for _ in range(NB)]   # (x > 0) bit masks
     wd = co.weight_layout(torch.randn(cout, cin, 1, 1, device="cuda") * 0.05, 1)
     line = f"dgrad1 {cout:5d} -> {cin:5d} h{h:3d} x{cnt:2d}:"
     for v in variants:
@@ -19,7 +19,7 @@ for cin, cout, h, cnt in SH:
             def run(i):
                 if mode == "plain":
                     return co.conv_dgrad(gs[i], wd, 1, 0, (h, h))
-                return co.conv_dgrad(gs[i], wd, 1, 0, (h, h), addend=adds[i], relu_of=acts[i])
+                return co.conv_dgrad(gs[i], wd, 1, 0, (h, h), addend=adds[i], relu_bits=acts[i])
             for i in range(NB):
                 run(i)
             torch.cuda.synchronize()

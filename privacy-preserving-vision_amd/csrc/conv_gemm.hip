@@ -620,6 +620,7 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
+    if (stat_part && addend) return PPV_ERR_BAD_SIZE;           // the epilogue parks the addend tile where the statistics are folded
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;

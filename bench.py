@@ -62,7 +62,7 @@ class _MeanSquare(torch.autograd.Function):
         return x * (g * (2.0 / x.numel()))
 
 
-def make_step(camera, encoder, batch, device, sync, decoder=None):
+def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=False):
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
     opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True)
@@ -89,7 +89,11 @@ def make_step(camera, encoder, batch, device, sync, decoder=None):
         else:
             # stand-in for CE + attention regulariser: one read of encoder_out forward, one dense gradient backward
             loss_head = _MeanSquare.apply(enc_out)
-        loss_cam = 1 - torch.nn.functional.mse_loss(imgs, sensor)
+        if ssim_loss:                                                             # camera_loss = 'SSIM', train.py:172-173
+            from ppv_amd.ssim import ssim
+            loss_cam = 1 - ssim(imgs, sensor)
+        else:
+            loss_cam = 1 - torch.nn.functional.mse_loss(imgs, sensor)
         loss = 0.4 * loss_head + 6 * loss_cam + 30 * loss_psf
         opt_enc.zero_grad(set_to_none=True)
         opt_cam.zero_grad(set_to_none=True)
@@ -216,6 +220,7 @@ def main():
     ap.add_argument("--decoder", action="store_true",
                     help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
                          "default is the headline Camera+ResNet-101 metric")
+    ap.add_argument("--ssim", action="store_true", help="camera_loss = 'SSIM' (fused SSIM kernels) instead of the default MSE")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -246,7 +251,7 @@ def main():
         torch.manual_seed(3)
         decoder = DecoderWithAttention(attention_dim=512, embed_dim=512, decoder_dim=512, vocab_size=9490, dropout=0.3).to(device)
         decoder.train()
-    step, params = make_step(camera, encoder, args.batch, device, sync, decoder)
+    step, params = make_step(camera, encoder, args.batch, device, sync, decoder, args.ssim)
 
     for _ in range(args.warmup):
         step()

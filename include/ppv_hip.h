@@ -161,6 +161,12 @@ int ppv_alt_corr_bwd(const float* fmap1, const float* fmap2, const float* coords
                      float* d_fmap2, int B, int H1, int W1, int H2, int W2, int C, int r, float scale, int level, int levels,
                      ppv_stream_t stream);
 
+/* ---- SSIM loss, Image_Caption/pytorch_ssim/__init__.py:20-40 (camera_loss = 'SSIM', train.py:172-173): window 11, sigma 1.5,
+ * zero padding; `win` = the 11 normalised 1-D taps (HOST array); forward accumulates per-image sums of the SSIM map */
+int ppv_ssim_fwd(const float* img1, const float* img2, double* sums, const float* win, int B, int C, int H, int W, ppv_stream_t stream);
+int ppv_ssim_bwd(const float* img1, const float* img2, const float* gscale, float* d_img2, const float* win, int B, int C, int H, int W,
+                 ppv_stream_t stream);
+
 /* ---- soft-attention LSTM caption decoder, Image_Caption/models.py:57-218.  encoder_att is hoisted out
  * of the time loop (models.py:83 recomputes it every step) and runs through ppv_conv_gemm; these are the per-step kernels.
  * "sorted" = the batch order after the caption-length sort of models.py:181-183; order[b] = original image index. */

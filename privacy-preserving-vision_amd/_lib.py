@@ -45,6 +45,8 @@ PROTOTYPES = {
     "ppv_upsample2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_concat3_add": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_fan_head": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ppv_ssim_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_ssim_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_dec_prepare": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ppv_dec_attend_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_dec_attend_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

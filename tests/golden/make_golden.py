@@ -287,10 +287,29 @@ def gen_decoder():
     print("decoder loss", loss.item(), "preds", stats(preds), "alphas", stats(alphas), "g_enc", stats(enc.grad))
 
 
+# --------------------------------------------------------------------------- SSIM loss (Image_Caption/pytorch_ssim)
+def gen_ssim():
+    sys.path.insert(0, os.path.join(REF, "Image_Caption"))
+    import pytorch_ssim
+    out = {}
+    for tag, shape in (("a", (2, 3, 64, 64)), ("b", (3, 3, 40, 52))):
+        g = torch.Generator().manual_seed(7)
+        x = torch.rand(shape, generator=g)
+        y = (x + 0.15 * torch.randn(shape, generator=g)).clamp(0, 1)
+        x1, y1 = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        v = pytorch_ssim.SSIM()(x1, y1)                        # window 11, sigma 1.5, size_average=True
+        v.backward()
+        per = pytorch_ssim.ssim(x, y, size_average=False)
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_y": y.numpy(), f"{tag}_ssim": v.item(), f"{tag}_gx": x1.grad.numpy(),
+                    f"{tag}_gy": y1.grad.numpy(), f"{tag}_per_image": per.numpy()})
+        print("ssim", tag, v.item(), per.tolist())
+    np.savez_compressed(os.path.join(HERE, "ssim.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        for w in ("ic", "fd", "corr", "fan", "decoder"):
+        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder}[what]()
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim}[what]()

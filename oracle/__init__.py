@@ -11,9 +11,12 @@ encoder; every function cites the reference file:line it follows.
 
 Parity pin status
 -----------------
-* IC ``OpticsZernike`` / FD ``Camera`` / RAFT ``CorrBlock``: PINNED against
-  golden vectors generated in the build container by importing the reference's
-  own Python (``tests/golden/make_golden.py``; fixtures ``tests/golden/*.npz``).
+* IC ``OpticsZernike`` / FD ``Camera`` (forward and coefficient gradient) / RAFT
+  ``CorrBlock`` and the on-the-fly ``alt_corr`` restatement of ``AlternateCorrBlock`` +
+  ``alt_cuda_corr`` / FAN / ``DecoderWithAttention`` (forward, loss, every gradient) /
+  ``pytorch_ssim``: PINNED against golden vectors generated in the build container by
+  importing the reference's own Python (``tests/golden/make_golden.py``; fixtures
+  ``tests/golden/*.npz``).
 * Third-party arithmetic absent from /root/reference: ``poppy`` 1.0.3
   ``zernike_basis`` and ``cv2.circle`` -- *parity unpinned* (no reference
   fixture stores a basis or a mask); the golden generator feeds the reference

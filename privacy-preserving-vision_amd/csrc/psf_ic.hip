@@ -127,23 +127,36 @@ __global__ __launch_bounds__(256) void zernike_contract_kernel(const float* __re
     reinterpret_cast<float4*>(h)[i] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
 }
 
-// gc_partial[wg][k] = sum_{px in tile} Z[k][px] * gh[px]
+// gc_partial[wave][k] = sum_{px in the wave's 256 pixels} Z[k][px] * gh[px]: one partial row per WAVE (no block barrier in
+// the K loop, four independent 16-byte loads in flight per lane), folded by sum_partials_kernel
 __global__ __launch_bounds__(256) void zernike_grad_kernel(const float* __restrict__ Z, const float* __restrict__ gh,
                                                            double* __restrict__ part, int K, long npx4) {
-    __shared__ double s_red[4];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const bool ok = i < npx4;
     const float4 g = ok ? reinterpret_cast<const float4*>(gh)[i] : make_float4(0, 0, 0, 0);
     const float4* z = reinterpret_cast<const float4*>(Z) + (ok ? i : 0);
-    for (int k = 0; k < K; ++k) {
+    double* row = part + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * K;
+    const int lane = threadIdx.x & 63;
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = z[(long)(k + j) * npx4];
+        double a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = (double)v[j].x * g.x + (double)v[j].y * g.y + (double)v[j].z * g.z + (double)v[j].w * g.w;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += __shfl_xor(a[j], off, 64);
+        if (lane < 4) row[k + lane] = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : a[3];
+    }
+    for (; k < K; ++k) {
         const float4 v = z[(long)k * npx4];
-        double a = ok ? ((double)v.x * g.x + (double)v.y * g.y + (double)v.z * g.z + (double)v.w * g.w) : 0.0;
+        double a = (double)v.x * g.x + (double)v.y * g.y + (double)v.z * g.z + (double)v.w * g.w;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
-        __syncthreads();
-        if (threadIdx.x == 0) part[(long)blockIdx.x * K + k] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-        __syncthreads();
+        if (lane == 0) row[k] = a;
     }
 }
 
@@ -474,7 +487,7 @@ size_t carve(IcWs* w, char* base, int RR, int P, int K) {
     w->sums = (double*)take(8 * 8);
     w->g_n = (double*)take((size_t)P * P * 3 * 8);
     const size_t nwg = (npx / 4 + 255) / 256;
-    w->part = (double*)take(nwg * K * 8);
+    w->part = (double*)take(nwg * 4 * K * 8);
     w->gh = (float*)take(npx * 4);
     return off;
 }
@@ -554,7 +567,7 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
     ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
     const unsigned nwg = (unsigned)((npx4 + 255) / 256);
     zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, w.gh, w.part, K, npx4);
-    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg, K);
+    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg * 4, K);
     return ppv_last_error();
 }
 
@@ -569,14 +582,14 @@ int ppv_zernike_contract(const float* Z, const float* coeffs, float* h, int K, l
 
 // g_coeffs[k] = sum_px Z[k][px] * gh[px]  (adjoint of ppv_zernike_contract); part: scratch of
 // ppv_zernike_grad_scratch_bytes(K, npx)
-size_t ppv_zernike_grad_scratch_bytes(int K, long npx) { return ((size_t)((npx / 4 + 255) / 256)) * K * sizeof(double); }
+size_t ppv_zernike_grad_scratch_bytes(int K, long npx) { return ((size_t)((npx / 4 + 255) / 256)) * 4 * K * sizeof(double); }
 int ppv_zernike_grad(const float* Z, const float* gh, float* g_coeffs, void* part, int K, long npx, hipStream_t stream) {
     if (!Z || !gh || !g_coeffs || !part) return PPV_ERR_NULL;
     if (npx % 4) return PPV_ERR_BAD_SIZE;
     const long npx4 = npx / 4;
     const unsigned nwg = (unsigned)((npx4 + 255) / 256);
     zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, gh, (double*)part, K, npx4);
-    sum_partials_kernel<<<K, 256, 0, stream>>>((const double*)part, g_coeffs, (int)nwg, K);
+    sum_partials_kernel<<<K, 256, 0, stream>>>((const double*)part, g_coeffs, (int)nwg * 4, K);
     return ppv_last_error();
 }
 

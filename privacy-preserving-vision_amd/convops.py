@@ -72,7 +72,9 @@ class WeightLayouts:
             self.dg.append(d)
             recs.append(struct.pack("<QQQiiiii", w.data_ptr(), f.data_ptr(), d.data_ptr(), Cout, Cin, R, S, blk))
             recs[-1] += b"\0" * (48 - len(recs[-1]))
-            blk += (w.numel() + 255) // 256
+            if Cout % 32 or Cin % 32 or R * S > 9:
+                raise ValueError("WeightLayouts: channel counts must be multiples of 32 and the kernel at most 3x3")
+            blk += (Cout // 32) * (Cin // 32)
         self.total_blocks = blk
         import numpy as np
         self.desc = torch.from_numpy(np.frombuffer(b"".join(recs), dtype=np.uint8).copy()).to(dev)

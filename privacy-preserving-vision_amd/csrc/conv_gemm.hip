@@ -580,21 +580,30 @@ __global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const float* _
 // one launch for a whole list of convolutions: desc[i] = {w f32*, fwd bf16*, dgrad bf16*, Cout, Cin, R, S, first block}
 struct WLayoutDesc { const float* w; bf16_t* fwd; bf16_t* dg; int Cout, Cin, R, S, blk0; };
 __global__ __launch_bounds__(256) void weight_layout_multi_kernel(const WLayoutDesc* __restrict__ desc, int ndesc) {
-    // binary search of the descriptor that owns this block
-    int lo = 0, hi = ndesc - 1;
+    // one block = a 32 (n) x 32 (c) x R*S tile through LDS: the torch rows are read as whole 32*R*S-float runs, both bf16
+    // layouts leave as 64-byte runs (the element-per-thread form scattered 2-byte stores with a Cout*2-byte stride)
+    __shared__ bf16_t sT[32][32 * 9 + 2];
+    int lo = 0, hi = ndesc - 1;                                            // binary search of the descriptor that owns this block
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (desc[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const WLayoutDesc d = desc[lo];
-    const long i = (long)(blockIdx.x - d.blk0) * 256 + threadIdx.x;         // index in torch order [n][c][r][s]
-    const long tot = (long)d.Cout * d.Cin * d.R * d.S;
-    if (i >= tot) return;
-    const int s_ = (int)(i % d.S), r = (int)((i / d.S) % d.R), c = (int)((i / ((long)d.S * d.R)) % d.Cin);
-    const int n = (int)(i / ((long)d.S * d.R * d.Cin));
-    const bf16_t v = f2bf(d.w[i]);
-    d.fwd[(((long)n * d.R + r) * d.S + s_) * d.Cin + c] = v;
-    d.dg[(((long)c * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - s_)) * d.Cout + n] = v;
+    const int RS = d.R * d.S, tiles_c = d.Cin / 32, lb = blockIdx.x - d.blk0;
+    const int n0 = (lb / tiles_c) * 32, c0 = (lb % tiles_c) * 32, run = 32 * RS;
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int n = i / run, rem = i % run;
+        sT[n][rem] = f2bf(d.w[((long)(n0 + n) * d.Cin + c0) * RS + rem]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int c = i & 31, rs = (i >> 5) % RS, n = i / run;
+        d.fwd[((long)(n0 + n) * RS + rs) * d.Cin + c0 + c] = sT[n][c * RS + rs];
+    }
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int n = i & 31, rs = (i >> 5) % RS, c = i / run;
+        d.dg[((long)(c0 + c) * RS + (RS - 1 - rs)) * d.Cout + n0 + n] = sT[n][c * RS + rs];
+    }
 }
 
 }  // namespace ppv
@@ -685,8 +694,9 @@ int ppv_conv_stat_tiles(long M) {
     return (int)(t < 32 ? t : 32);
 }
 
-// desc: device array of ndesc records {const float* w; void* fwd; void* dgrad; int Cout, Cin, R, S, blk0} (40 bytes each,
-// blk0 = prefix sum of ceil(numel/256)); total_blocks = sum.  Converts every listed weight to both bf16 layouts.
+// desc: device array of ndesc records {const float* w; void* fwd; void* dgrad; int Cout, Cin, R, S, blk0} (48 bytes each,
+// blk0 = prefix sum of (Cout/32)*(Cin/32)); total_blocks = sum.  Converts every listed weight to both bf16 layouts.
+// Cout % 32 == 0, Cin % 32 == 0, R*S <= 9.
 int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, hipStream_t stream) {
     if (!desc || ndesc < 1) return PPV_ERR_NULL;
     weight_layout_multi_kernel<<<total_blocks, 256, 0, stream>>>((const WLayoutDesc*)desc, ndesc);

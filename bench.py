@@ -158,7 +158,20 @@ def roofline_of_dominant_kernel(step):
             traffic = round(tot_b / tot_n) if tot_n else None
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+    mfma_busy = None
+    mu = os.path.join(ROOT, "profiles", "r01_mfma_util.json")    # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/profile_round.sh)
+    if os.path.exists(mu) and dom == "conv_gemm<128>":
+        try:
+            pk = json.load(open(mu))["per_kernel"]
+            num = den = 0.0
+            for name, v in pk.items():
+                if "conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name:
+                    num += v["mfma_busy_frac"] * v["avg_duration_us"] * v["launches"]
+                    den += v["avg_duration_us"] * v["launches"]
+            mfma_busy = round(num / den, 4) if den else None
+        except Exception:
+            mfma_busy = None
+    return {"bound": "mfma", "kernel": dom, "mfma_busy_frac_pmc": mfma_busy, "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
             "avg_launch_us": round(sec / n * 1e6, 2), "per_kernel": detail}
 

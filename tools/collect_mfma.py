@@ -1,0 +1,24 @@
+"""MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (rocprofv3 --pmc, its own pass; counts cycles summed over the chip's
+1024 SIMDs, MI355X_MICROARCH.md) / (1024 x kernel duration x 2.4 GHz), durations from the --kernel-trace --stats pass.
+
+usage: collect_mfma.py <mfma_counter_collection.csv> <kernel_stats.csv> <out.json>"""
+import csv, json, re, sys, collections
+
+busy = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[1])):
+    if r.get("Counter_Name") == "SQ_VALU_MFMA_BUSY_CYCLES":
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+        busy[k][0] += float(r["Counter_Value"]); busy[k][1] += 1
+dur = {}
+for r in csv.DictReader(open(sys.argv[2])):
+    dur[re.sub(r"\(.*", "", r["Name"]).replace("void ", "")] = float(r["AverageNs"])
+out = {"note": "MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x average kernel duration x 2.4 GHz); PMC pass and "
+               "kernel-trace pass are separate runs of bench.py (B = 128)", "per_kernel": {}}
+for k, (c, n) in sorted(busy.items(), key=lambda kv: -kv[1][0]):
+    if c <= 0 or k not in dur:
+        continue
+    out["per_kernel"][k] = {"launches": n, "mfma_busy_cycles_per_launch": c / n, "avg_duration_us": round(dur[k] / 1e3, 2),
+                            "mfma_busy_frac": round(c / n / (1024 * dur[k] * 2.4), 4)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k, v in out["per_kernel"].items():
+    print(f"{v['mfma_busy_frac']:.3f}  {v['avg_duration_us']:8.1f}us  {k[:80]}")

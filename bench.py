@@ -186,7 +186,7 @@ def cpu_baseline(camera):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))                  # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(cores)
-    B = 2
+    B = 4                                            # bounded sample: ~10-15 s of CPU work on 16 threads
     print(f"[bench] cpu_baseline: oracle on {cores} threads, B={B} ...", file=sys.stderr, flush=True)
     vol = camera.zernike_volume.cpu()
     coeffs = camera._concat().detach().cpu().requires_grad_(True)

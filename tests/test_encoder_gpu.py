@@ -156,3 +156,25 @@ def test_state_dict_keys_are_torchvision_compatible():
     n_tr = sum(p.numel() for p in enc.parameters() if p.requires_grad)
     assert n_all == 42500160 and n_tr == 42274816        # 42.50 M params, 42.27 M trainable
     assert sum(1 for m in enc.modules() if isinstance(m, torch.nn.Conv2d)) == 104
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H", [(1, 256), (3, 224), (5, 192)])
+def test_full_resnet101_odd_batches_and_sizes(B, H):
+    """The full trunk on batch / image sizes other than the benchmark's (7x7, 6x6 and single-image maps, ragged GEMM rows):
+    shapes, finiteness, every trainable parameter and the image receive a gradient; eval mode is deterministic."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder().cuda().train()
+    img = torch.rand(B, 3, H, H, device="cuda", requires_grad=True)
+    out = enc(img)
+    assert out.shape == (B, 36, 36, 2048) and torch.isfinite(out).all()
+    out.square().mean().backward()
+    assert img.grad is not None and torch.isfinite(img.grad).all() and float(img.grad.abs().max()) > 0
+    for n, p in enc.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    enc.eval()
+    with torch.no_grad():
+        a, b = enc(img.detach()), enc(img.detach())
+    assert torch.equal(a, b)

@@ -13,6 +13,7 @@ Rank 0 prints ONE JSON line (contract in the task statement), with `roofline` (t
 live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -77,8 +78,12 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         caps = torch.randint(0, decoder.vocab_size, (batch, 52), generator=gen).to(device)
         caplens = torch.randint(9, 19, (batch, 1), generator=gen).to(device)      # COCO-like lengths incl. <start>/<end>
 
+    opt_stream = torch.cuda.Stream(device=device) if os.environ.get("PPV_OPT_OVERLAP", "1") != "0" else None
+
     def step():
         sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
+        if opt_stream is not None:             # the encoder's (and decoder's) Adam of the previous step ran beside the camera forward
+            torch.cuda.current_stream().wait_stream(opt_stream)
         enc_out = encoder(sensor)
         if decoder is not None:                                                   # train.py:274-282
             scores, caps_sorted, dec_len, alphas, _ = decoder(enc_out, caps, caplens)
@@ -108,18 +113,23 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
                     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
                     assert torch.equal(lo, hi), "gradient differs across ranks after the all-reduce"
         opt_cam.step()
-        grads = [p.grad for p in enc_params]                                      # clip_gradient, train.py:311-316
-        torch._foreach_clamp_min_(grads, -5.0)
-        torch._foreach_clamp_max_(grads, 5.0)
-        opt_enc.step()
-        if decoder is not None:
-            dgr = [p.grad for p in dec_params]
-            if sync is not None:
-                sync.reduce_now(dgr)
-            torch._foreach_clamp_min_(dgr, -5.0)
-            torch._foreach_clamp_max_(dgr, 5.0)
-            opt_dec.step()
         camera.zernike_coeffs_train[1:].data.clamp_(-1, 1)                        # train.py:322-323
+        if decoder is not None and sync is not None:
+            sync.reduce_now([p.grad for p in dec_params])
+        # The encoder / decoder updates touch nothing the next step's camera forward reads: they run on a side stream and the
+        # next encoder forward waits for them (same arithmetic, same order per parameter; PPV_OPT_OVERLAP=0 serialises).
+        if opt_stream is not None:
+            opt_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(opt_stream) if opt_stream is not None else contextlib.nullcontext():
+            grads = [p.grad for p in enc_params]                                  # clip_gradient, train.py:311-316
+            torch._foreach_clamp_min_(grads, -5.0)
+            torch._foreach_clamp_max_(grads, 5.0)
+            opt_enc.step()
+            if decoder is not None:
+                dgr = [p.grad for p in dec_params]
+                torch._foreach_clamp_min_(dgr, -5.0)
+                torch._foreach_clamp_max_(dgr, 5.0)
+                opt_dec.step()
         return loss
 
     return step, enc_params + cam_params

@@ -140,8 +140,18 @@ def roofline_of_dominant_kernel(step):
     import ppv_amd.convops as co
     torch.cuda.synchronize()
     co.PROFILE = []
-    step()
-    torch.cuda.synchronize()
+    # a launch's duration is its roofline input only if it has the device to itself: the instrumented step runs the weight
+    # gradients on the main stream (in the timed steps they overlap the dgrad / BN chain on a side stream)
+    prev = os.environ.get("PPV_WGRAD_SIDE")
+    os.environ["PPV_WGRAD_SIDE"] = "0"
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        if prev is None:
+            os.environ.pop("PPV_WGRAD_SIDE", None)
+        else:
+            os.environ["PPV_WGRAD_SIDE"] = prev
     rec, co.PROFILE = co.PROFILE, None
     agg = {}
     for kind, flops, e0, e1 in rec:
@@ -181,7 +191,8 @@ def roofline_of_dominant_kernel(step):
             mfma_busy = round(num / den, 4) if den else None
         except Exception:
             mfma_busy = None
-    return {"bound": "mfma", "kernel": dom, "mfma_busy_frac_pmc": mfma_busy, "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": dom, "mfma_busy_frac_pmc": mfma_busy,
+            "measured_in": "one extra step with every launch serialised on one stream (kernel alone on the device)", "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
             "avg_launch_us": round(sec / n * 1e6, 2), "per_kernel": detail}
 

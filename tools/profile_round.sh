@@ -5,6 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_round
 mkdir -p $O
+export PPV_WGRAD_SIDE=0   # per-kernel durations and counters are taken with every launch alone on the device
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 echo stats done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch.log 2>&1
@@ -17,5 +18,6 @@ python tools/collect_pmc.py $(find $O/fetch -name "*counter_collection.csv" | he
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python tools/collect_mfma.py $(find $O/mfma -name "*counter_collection.csv" | head -1) $O/kernel_stats.csv $O/mfma_util.json | head -12
 rm -rf $O/fetch $O/write $O/stats $O/mfma
+unset PPV_WGRAD_SIDE
 python bench.py > $O/bench_default.json.log 2>$O/bench_default.err
 tail -1 $O/bench_default.json.log | cut -c1-300

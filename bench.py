@@ -135,6 +135,19 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     return step, enc_params + cam_params
 
 
+def _step_hbm(sec_per_step):
+    """Whole-step HBM view: bytes per step from the committed PMC passes (same workload) over the measured step time."""
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(pmc))
+        gb = d["total_fetch_GB_per_step"] + d["total_write_GB_per_step"]
+    except Exception:
+        return None
+    tbs = gb / 1e3 / sec_per_step
+    return {"GB_per_step_pmc": round(gb, 1), "TB_per_s": round(tbs, 2), "frac_of_8TBps_peak": round(tbs / 8.0, 3),
+            "frac_of_6.3TBps_measured_copy_rate": round(tbs / 6.3, 3)}
+
+
 def roofline_of_dominant_kernel(step):
     """One extra instrumented step: every conv launch is bracketed by HIP events on its own stream."""
     import ppv_amd.convops as co
@@ -320,6 +333,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "trunk_mfma_frac_of_peak": round(value / world * TRUNK_GFLOP_PER_IMG * 1e9 / (PEAK_BF16_DENSE_TFLOPS * 1e12), 4),
             "roofline": roof,
+            "step_hbm": _step_hbm(elapsed / args.steps) if (world == 1 and args.batch == 128 and not args.decoder and not args.ssim) else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(camera)

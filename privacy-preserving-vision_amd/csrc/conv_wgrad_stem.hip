@@ -680,9 +680,14 @@ static void wgrad3_plan(long M, int N, int Cs, long* splits, int* sps) {
 size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
     int TN, sps;
     long splits;
-    int variant = g_wgrad_variant & 0xff;
-    if (variant == 0) variant = (N % 256 == 0) ? 3 : 1;
-    wgrad_plan(M, N, R, S, Cs, variant, &TN, &splits, &sps);
+    // whichever kernel ppv_conv_wgrad picks (tuning hook included): the largest slice count of the candidate plans
+    wgrad_plan(M, N, R, S, Cs, 2, &TN, &splits, &sps);
+    for (int v = 1; v <= 3; v += 2) {
+        if (v == 3 && N % 256) continue;
+        long sp;
+        wgrad_plan(M, N, R, S, Cs, v, &TN, &sp, &sps);
+        if (sp > splits) splits = sp;
+    }
     if (R == 3 && S == 3 && M % 64 == 0) {                       // the fused-tap kernel may be chosen: cover its plan too
         long sp3;
         int sps3;
@@ -705,22 +710,25 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;            // fast_divmod range
     int variant = g_wgrad_variant & 0xff;
     g.xcd_group = (g_wgrad_variant & 0x100) ? 0 : 1;
-    if (variant == 0) {                                        // measured (tools/bench_wgrad.py, cold operands, B = 128):
-        variant = (N % 256 == 0) ? 3 : 1;                      //   256-wide pipelined tiles win where they exist,
+    if (variant == 0) {
+        // Alone on the device the 256-wide three-stage tile (144 KB of LDS) is the fastest 1x1 form (tools/bench_wgrad.py), but
+        // the trunk runs its weight gradients on a side stream beside the data-gradient / BN chain: there a 128-wide TWO-stage
+        // ring (64 KB) that can share a CU with a conv workgroup wins the whole step by 1.9 % (4396 -> 4480 images/s).
+        variant = 6;
         g.xcd_group = (R * S == 1) ? 1 : 0;                    //   XCD grouping pays for 1x1 only
     }
     const long elems = (long)N * R * S * Cs;
     float* slabs = (float*)scratch;
     const bool w_ok = Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && Hs == Ho && Ws == Wo && w_ok && (Ho * Wo) % 64 == 0 &&
-        ((g_wgrad_variant & 0xff) == 0 || (g_wgrad_variant & 0xff) == 4)) {
+        ((g_wgrad_variant & 0xff) == 0 || (g_wgrad_variant & 0xff) == 4 || (g_wgrad_variant & 0xff) == 6)) {
         long sp3;
         int sps3;
         wgrad3_plan(g.M, N, Cs, &sp3, &sps3);
         g.stages_per_split = sps3;
         g.splits = (int)sp3;
         g.slab_elems = elems;
-        constexpr int NS = 3, lds = NS * W3_STAGE;   // a 4th stage (160 KB) measured no faster: the loop is compute-side bound
+        constexpr int NS = 3, lds = NS * W3_STAGE;   // 2 or 4 stages measured no different: the loop is compute-side bound
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
         const int log2W = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
@@ -732,6 +740,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         return ppv_last_error();
     }
     if (variant == 4) variant = (N % 256 == 0) ? 3 : 1;
+    const bool small_ring = variant == 6;                      // TN = 128, two stages (64 KB)
+    if (small_ring) variant = 2;
     int TN, sps;
     long splits;
     wgrad_plan(g.M, N, R, S, Cs, variant, &TN, &splits, &sps);
@@ -753,6 +763,11 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
         conv_wgrad_pipe_kernel<256, 3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+    } else if (small_ring) {
+        constexpr int lds = 2 * 2 * 64 * 256;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        conv_wgrad_pipe_kernel<128, 2><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     } else {
         constexpr int lds = 4 * 2 * 64 * 256;
         static bool attr = false;
@@ -763,8 +778,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     return ppv_last_error();
 }
 
-// tuning / A-B hook: low byte 0 auto, 1 two-stage, 2 pipe TN=128, 3 pipe TN=256, 4 = auto (fused-tap 3x3 allowed; 1-3 force the
-// per-tap kernels); 0x100 disables XCD grouping
+// tuning / A-B hook: low byte 0 auto (= 6), 1 two-stage atomics kernel, 2 pipe TN=128 x 4 stages, 3 pipe TN=256 x 3 stages,
+// 4 = fused-tap 3x3 + (3 | 1), 6 = fused-tap 3x3 + pipe TN=128 x 2 stages; 0x100 disables XCD grouping
 int ppv_wgrad_set_variant(int v) { g_wgrad_variant = v; return PPV_OK; }
 
 // mode 0: forward layout [64][24][8] bf16; mode 1: data-gradient layout [16][4][4][64] bf16

@@ -9,13 +9,16 @@
 //   dgrad   : a = 1,      off = -(k-1-pad),  div = stride, wt = W^T flipped [cin][k-1-r][k-1-s][cout]
 //             (taps whose numerator is not divisible by `div`, or that fall outside, read a zero page)
 //
-// Tiling: 128 (M) x BN (N) x 64 (K) per 256-thread workgroup, 2 x 2 waves, 16 (BN=128) or 8 (BN=64) 16x16
-// accumulators per wave.  A rows are 128-byte channel runs gathered straight into LDS with
-// global_load_lds_dwordx4 (per-lane SOURCE address carries both the gather and the XOR swizzle
-// chunk ^= row & 7, which makes every ds_read_b128 fragment read bank-conflict free); two LDS stages.
-// Epilogue: bf16 rounding, per-channel sum / sum-of-squares of the ROUNDED values (train-mode BatchNorm
-// statistics) via one f32 atomic per channel per wave, tile transposed through LDS and stored
-// as whole 16-byte chunks.
+// Two kernels:
+//   conv_gemm_pipe_kernel<BM, BN, NSTAGE, BK, WG/CU> -- the product path.  NSTAGE LDS stages filled by global_load_lds_dwordx4
+//     (the per-lane SOURCE address carries both the im2col gather and the XOR swizzle that makes every ds_read_b128 fragment
+//     read bank-conflict free), counted s_waitcnt vmcnt + one raw s_barrier per K-step, XCD-aware tile order.  Tile shapes are
+//     picked per problem by ppv_conv_gemm (cold-cache sweep, tools/bench_conv_cold.py): 256x128 BK32 two workgroups per CU
+//     (grids of several rounds), 256x128 BK64 (one round), 128x128 BK64 four stages (layer 4), 128x64 four per CU (layer 1).
+//   conv_gemm_kernel<BN, WM> -- the original 128-row two-stage kernel, kept for N = 16 (stem data gradient) and small grids.
+// Epilogue of both: bf16 rounding; per-channel sum / sum-of-squares of the ROUNDED values (train-mode BatchNorm statistics,
+// SURVEY 8a-18) folded per tile and added with f32 atomics into <= 32 partial rows; optional residual-gradient addend (one
+// rounding of acc + addend) and ReLU bit mask of the destination tensor; the tile goes through LDS and leaves as 16-byte chunks.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include "ppv_common.h"

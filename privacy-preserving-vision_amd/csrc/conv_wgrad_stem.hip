@@ -4,8 +4,11 @@
 //     dW[n][r][s][c] = sum_m G[m][n] * src[b, ho*st + r - pad, wo*st + s - pad, c]
 //   Both operands have the reduction index m as their SLOW memory dimension, so both 64-row tiles are staged
 //   row-major ([m][128 cols], global_load_lds, XOR-swizzled 32-byte blocks) and the MFMA fragments are read
-//   TRANSPOSED with ds_read_b64_tr_b16 -- no register or LDS transpose pass.  One workgroup owns a
-//   128 (n) x 128 (c) tile of one tap and a slice of m; slices combine with f32 atomics into [N][R][S][C].
+//   TRANSPOSED with ds_read_b64_tr_b16 -- no register or LDS transpose pass.  Kernels: conv_wgrad3x3_kernel (stride-1 3x3:
+//   one G stage feeds three taps, X staged once as a halo tile), conv_wgrad_pipe_kernel<TN, NSTAGE> (everything else: one
+//   tap per workgroup; TN = 128 x 2 stages is the default because it shares a CU with a conv workgroup when the weight
+//   gradients run on their side stream), conv_wgrad_kernel (the first, two-stage + f32-atomics form, kept as variant 1).
+//   Each workgroup owns a tile and a slice of m; slices write private f32 slabs that wgrad_to_torch sums into [N][C][R][S].
 //
 // stem forward: K = 7*3*8 = 168 (padded to 192) is built in LDS as an im2col tile from the f32 NCHW sensor image
 //   (each 16-byte chunk = 7 consecutive input columns + one zero), 64 output channels, BN partial statistics fused.

@@ -264,6 +264,17 @@ class OpticsZernike(nn.Module):
                     self.zernike_coeffs_train.data = full[3].clone()
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    # whole-module pickling (the reference checkpoints the objects themselves, Image_Caption/utils.py:387-395): host pointers
+    # into numpy constants are rebuilt on load
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_kdn_p", None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._kdn_p = self._kdn.ctypes.data_as(_lib.ctypes.c_void_p)
+
     def get_Heith_Map(self):
         """Lens.py:129-139."""
         c = self._concat().detach().reshape(-1).contiguous()

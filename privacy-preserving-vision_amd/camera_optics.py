@@ -179,6 +179,15 @@ class Camera(nn.Module):
         self._ws = torch.empty(L.ppv_fd_psf_workspace_bytes(N), dtype=torch.uint8, device=device)
         self._state_token = 0
 
+    def __getstate__(self):                        # whole-module pickling (solver checkpoints / DataParallel replicas)
+        st = dict(self.__dict__)
+        st.pop("_kf_p", None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._kf_p = self._kf.ctypes.data_as(_lib.ctypes.c_void_p)
+
     def get_Heith_Map(self):
         c = torch.cat((self.Zer_no_train, self.Zer_train), 0).detach().reshape(-1).contiguous()
         h = torch.empty((self.N, self.N), dtype=torch.float32, device=self.device)

@@ -289,6 +289,11 @@ class DecoderWithAttention(nn.Module):
         self._tables = {}
         self.init_weights()
 
+    def __getstate__(self):                        # the pooling class tables are device-side caches
+        st = dict(self.__dict__)
+        st["_tables"] = {}
+        return st
+
     def init_weights(self):
         """models.py:121-127."""
         self.embedding.weight.data.uniform_(-0.1, 0.1)

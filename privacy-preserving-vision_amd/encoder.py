@@ -311,6 +311,19 @@ class Encoder(nn.Module):
         self.grad_sync = None      # ppv_amd.dist_sync.GradSync for data-parallel training (bench.py / DDP harness)
         self.fine_tune()
 
+    # whole-module pickling (the reference resumes with `encoder = checkpoint['encoder']`, train.py:145): streams, cached bf16
+    # weight layouts and the per-conv records are runtime state, rebuilt on load
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("_stem", "_blocks", "_wl", "_wgrad_stream", "grad_sync", "_debug_block_grads"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self.grad_sync = None
+        self._index()
+
     def _index(self):
         r = self.resnet
         object.__setattr__(self, "_stem", _ConvRec(r[0], r[1], stem=True))

@@ -268,7 +268,16 @@ def main():
                     help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
                          "default is the headline Camera+ResNet-101 metric")
     ap.add_argument("--ssim", action="store_true", help="camera_loss = 'SSIM' (fused SSIM kernels) instead of the default MSE")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4],
+                    help="BASELINE.json config: 0 = headline metric (default); 2 = camera alone (tools/bench_camera.py); 3 = same as "
+                         "--decoder; 4 = FD camera + FAN + RAFT correlation (tools/bench_fd.py).  2 and 4 print their own JSON line.")
     args = ap.parse_args()
+    if args.config in (2, 4):                                   # single-GPU side configurations: their own measured lines
+        import runpy
+        runpy.run_path(os.path.join(ROOT, "tools", "bench_camera.py" if args.config == 2 else "bench_fd.py"), run_name="__main__")
+        return
+    if args.config == 3:
+        args.decoder = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -142,6 +142,29 @@ __global__ __launch_bounds__(256) void bilinear_up_clamp_kernel(const float* __r
     out[i] = fminf(fmaxf(v, 0.f), 1.f);
 }
 
+// ----------------------------------------------------------------------------- fp32-accurate convolutions on the bf16 MFMA path
+// y = act(x * scale + shift) in f32, written as THREE bf16 channel groups [hi | lo | hi] (hi = bf16(y), lo = bf16(y - hi)), zero
+// padded to Cp channels.  A convolution over that tensor with the weight groups [W_hi | W_hi | W_lo] accumulates
+// y_hi W_hi + y_lo W_hi + y_hi W_lo in the MFMA's f32 accumulators: the product error drops from 2^-9 to about 2^-16
+// relative, which is what the 1e-3 parity bar needs through FAN's ~100 layers (the reference runs the regressor in fp32).
+__global__ __launch_bounds__(256) void bn_act_split3_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                            bf16_t* __restrict__ y, long rows, int C, int Cp, int relu) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Cp) return;
+    const long row = i / Cp;
+    const int c = (int)(i % Cp);
+    float v = 0.f;
+    const int grp = c / C, cc = c % C;
+    if (c < 3 * C) {
+        float t = x[row * C + cc];
+        if (coef) t = t * coef[cc] + coef[C + cc];
+        if (relu) t = fmaxf(t, 0.f);
+        const float hi = __builtin_bit_cast(float, (unsigned)f2bf_f(t) << 16);
+        v = grp == 1 ? t - hi : hi;
+    }
+    y[i] = f2bf_f(v);
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -188,6 +211,16 @@ int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums
     fan_head_sum_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>((const float*)raw, bias, raw_out, sums, M, S * S, ldr, nch, split, nsum);
     const long tot = (long)B * 2 * S * up * S * up;
     bilinear_up_clamp_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(sums, heat, (long)B * 2, S, up);
+    return ppv_last_error();
+}
+
+// x [rows][C] f32 -> y [rows][Cp] bf16 = [hi | lo | hi | 0...] of act(x * coef[0][c] + coef[1][c]) (coef may be null = identity);
+// Cp >= 3 * C (zero padded).  See bn_act_split3_kernel: feeds ppv_conv_gemm with [W_hi | W_hi | W_lo] weights.
+int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, hipStream_t stream) {
+    if (!x || !y) return PPV_ERR_NULL;
+    if (rows < 1 || C < 1 || Cp < 3 * C) return PPV_ERR_BAD_SIZE;
+    const long tot = rows * Cp;
+    ppv::bn_act_split3_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu);
     return ppv_last_error();
 }
 

@@ -92,8 +92,12 @@ def _bn_coef(bn, pad_to=None, extra_shift=None):
 
 
 class FAN(nn.Module):
-    def __init__(self, num_modules=1, end_relu=False, num_landmarks=98, fname_pretrained=None):
+    def __init__(self, num_modules=1, end_relu=False, num_landmarks=98, fname_pretrained=None, *, precision="fp32"):
         super().__init__()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision: 'fp32' (split-bf16 MFMA products, f32 activations: the reference's arithmetic to ~1e-5) or "
+                             "'bf16' (bf16 activations, 3x faster, ~1e-2)")
+        self.precision = precision                    # extra keyword: the reference FAN is fp32 only
         self.num_modules, self.end_relu = num_modules, end_relu
         self.conv1 = CoordConvTh(256, 256, True, False, in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3)
         self.bn1 = nn.BatchNorm2d(64)
@@ -162,6 +166,97 @@ class FAN(nn.Module):
         cache["nl"] = nl
         return cache
 
+    # ------------------------------------------------------------------ fp32-accurate path (precision == "fp32")
+    # Activations stay f32 (NHWC); every convolution runs on the bf16 MFMA kernel over a [hi | lo | hi] channel split of its
+    # input against [W_hi | W_hi | W_lo] weights (csrc/fan.hip bn_act_split3_kernel), BN + ReLU fused into the split.
+    @staticmethod
+    def _w3(w, cout_pad=None):
+        """torch conv weight f32 [Cout,Cin,R,S] -> bf16 GEMM rows over the 3-way split input (Cin3 padded to 64)."""
+        w = w.detach().float()
+        hi = w.bfloat16().float()
+        lo = (w - hi).bfloat16().float()
+        w3 = torch.cat([hi, hi, lo], dim=1)
+        cin3 = (w3.shape[1] + 63) // 64 * 64
+        cout = cout_pad or (w.shape[0] + 63) // 64 * 64
+        return co.weight_layout(_pad_to(w3, (cout, cin3, w.shape[2], w.shape[3])), 0)
+
+    def _block_consts_p(self, blk):
+        c = {"n": (blk.conv1.out_channels, blk.conv2.out_channels, blk.conv3.out_channels),
+             "bn1": _bn_coef(blk.bn1), "bn2": _bn_coef(blk.bn2), "bn3": _bn_coef(blk.bn3),
+             "w1": self._w3(blk.conv1.weight), "w2": self._w3(blk.conv2.weight), "w3": self._w3(blk.conv3.weight)}
+        if blk.downsample is not None:
+            c["bnd"] = _bn_coef(blk.downsample[0])
+            c["wd"] = self._w3(blk.downsample[2].weight)
+        return c
+
+    def _build_cache_p(self, dev):
+        cache = {"dev": dev, "precise": True}
+        cache["stem_w"] = self._w3(self.conv1.conv.weight)                              # [64, 7, 7, 64] (18 real channels)
+        cache["stem_bn"] = _bn_coef(self.bn1, extra_shift=self.conv1.conv.bias.detach())
+        cache["coords256"] = _coord_channels(256, 256).to(dev).contiguous()
+        for name in ("conv2", "conv3", "conv4", "top_m_0"):
+            cache[name] = self._block_consts_p(getattr(self, name))
+        for name, m in self.m0.named_children():
+            if isinstance(m, ConvBlock):
+                cache["m0." + name] = self._block_consts_p(m)
+        wc = self.m0.coordconv.conv.weight.detach().float()                            # [256,259,1,1]
+        cache["cc_w"] = self._w3(wc[:, :256].contiguous())
+        cache["cc_map"] = (torch.einsum("oc,chw->hwo", wc[:, 256:, 0, 0], _coord_channels(64, 64).to(dev))
+                           + self.m0.coordconv.conv.bias.detach().float()).contiguous()   # [64,64,256] f32, bias folded in
+        cache["last_w"] = self._w3(self.conv_last0.weight)
+        cache["end_bn"] = _bn_coef(self.bn_end0, extra_shift=self.conv_last0.bias.detach())
+        cache["l0_w"] = self._w3(self.l0.weight, cout_pad=128)
+        cache["l0_b"] = self.l0.bias.detach().float().contiguous()
+        cache["nl"] = self.l0.out_channels
+        return cache
+
+    @staticmethod
+    def _split3(x, coef, relu):
+        """x [B,H,W,C] f32 -> act(x*scale+shift) as bf16 [B,H,W,pad64(3C)] = [hi | lo | hi]."""
+        B, H, W, C = x.shape
+        cp = (3 * C + 63) // 64 * 64
+        y = torch.empty((B, H, W, cp), dtype=torch.bfloat16, device=x.device)
+        check(_lib.lib().ppv_bn_act_split3(ptr(x), ptr(coef), ptr(y), B * H * W, C, cp, int(relu), stream_ptr()), "ppv_bn_act_split3")
+        return y
+
+    def _conv_p(self, x, coef, w3, n_out, stride=1, pad=0, relu=True):
+        """(BN + ReLU +) convolution, f32 in / f32 out (first n_out channels of the padded GEMM)."""
+        y = co.conv_fwd(self._split3(x.contiguous(), coef, relu), w3, stride, pad, out_f32=True)
+        return y if y.shape[-1] == n_out else y[..., :n_out].contiguous()
+
+    def _convblock_p(self, x, c):
+        n1, n2, n3 = c["n"]
+        o1 = self._conv_p(x, c["bn1"], c["w1"], n1, 1, 1)
+        o2 = self._conv_p(o1, c["bn2"], c["w2"], n2, 1, 1)
+        o3 = self._conv_p(o2, c["bn3"], c["w3"], n3, 1, 1)
+        res = x if "wd" not in c else self._conv_p(x, c["bnd"], c["wd"], n1 + n2 + n3, 1, 0)
+        return torch.cat([o1, o2, o3], dim=-1) + res
+
+    @staticmethod
+    def _avgpool_p(x):
+        B, H, W, C = x.shape
+        return x.view(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+
+    def _hourglass_p(self, level, x, cache):
+        up1 = self._convblock_p(x, cache[f"m0.b1_{level}"])
+        low = self._convblock_p(self._avgpool_p(x), cache[f"m0.b2_{level}"])
+        low = self._hourglass_p(level - 1, low, cache) if level > 1 else self._convblock_p(low, cache["m0.b2_plus_1"])
+        low = self._convblock_p(low, cache[f"m0.b3_{level}"])
+        return up1 + low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)          # nearest x2 (wing.py:70)
+
+    def _trunk_p(self, x6):
+        cache = self._cache
+        x = x6.permute(0, 2, 3, 1).contiguous()                                          # [B,256,256,6] f32
+        x = self._conv_p(x, None, cache["stem_w"], 64, 2, 3, relu=False)                  # CoordConv 7x7/2 (bias folded into bn)
+        x = torch.relu(x * cache["stem_bn"][0] + cache["stem_bn"][1])
+        x = self._avgpool_p(self._convblock_p(x, cache["conv2"]))
+        x = self._convblock_p(self._convblock_p(x, cache["conv3"]), cache["conv4"])
+        h = self._conv_p(x, None, cache["cc_w"], 256, 1, 0, relu=False) + cache["cc_map"]
+        ll = self._convblock_p(self._hourglass_p(4, h, cache), cache["top_m_0"])
+        ll = self._conv_p(ll, None, cache["last_w"], 256, 1, 0, relu=False)
+        ll = torch.relu(ll * cache["end_bn"][0] + cache["end_bn"][1])
+        return co.conv_fwd(self._split3(ll.contiguous(), None, False), cache["l0_w"], 1, 0, out_f32=True)   # [B,64,64,128] f32
+
     def refresh(self):
         """Call after changing parameters in place (the kernel-side constants are cached)."""
         self._cache = None
@@ -198,6 +293,8 @@ class FAN(nn.Module):
 
     def _trunk(self, x6):
         """x6 [B,6,256,256] f32 NCHW (image*0.5+0.5 and the three coordinate channels) -> l0 raw [B,64,64,128] f32."""
+        if self.precision == "fp32":
+            return self._trunk_p(x6)
         cache = self._cache
         L = _lib.lib()
         B = x6.shape[0]
@@ -217,8 +314,9 @@ class FAN(nn.Module):
             raise NotImplementedError("ppv_amd FAN implements the eval-mode forward the reference uses (model.py:298-306)")
         if not x.is_cuda:
             raise RuntimeError("ppv_amd FAN runs on an MI355X (input must be a cuda tensor); no CPU path")
-        if self._cache is None or self._cache["dev"] != x.device:
-            self._cache = self._build_cache(x.device)
+        precise = self.precision == "fp32"
+        if self._cache is None or self._cache["dev"] != x.device or self._cache.get("precise", False) != precise:
+            self._cache = self._build_cache_p(x.device) if precise else self._build_cache(x.device)
 
     @torch.no_grad()
     def get_heatmap(self, x, b_preprocess=True, Privacy=False, delimiter=False):

@@ -52,9 +52,11 @@ def alt_all():
 t_cam = timeit(lambda: cam(x))
 xs_ = cam(x)
 t_fan = timeit(lambda: fan.get_heatmap(xs_, Privacy=True))
+fan16 = FAN(precision="bf16").to(dev).eval()
+t_fan16 = timeit(lambda: fan16.get_heatmap(xs_, Privacy=True))
 t_corr = timeit(corr_all, n=2, w=1)
 t_alt = timeit(alt_all, n=2, w=1)
 print(json.dumps({"config": "FD Camera + FAN + RAFT CorrBlock, B=32 @512x512 (BASELINE.json configs[3]), forward",
-                  "camera_ms": round(t_cam * 1e3, 3), "fan_ms": round(t_fan * 1e3, 3), "corr_32x(volume+20 lookups)_ms": round(t_corr * 1e3, 3),
+                  "camera_ms": round(t_cam * 1e3, 3), "fan_ms": round(t_fan * 1e3, 3), "fan_bf16_mode_ms": round(t_fan16 * 1e3, 3), "corr_32x(volume+20 lookups)_ms": round(t_corr * 1e3, 3),
                   "altcorr_32x(20 on-the-fly lookups)_ms": round(t_alt * 1e3, 3),
                   "images_per_s_camera_fan": round(B / (t_cam + t_fan), 1)}))

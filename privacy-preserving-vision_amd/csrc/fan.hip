@@ -147,6 +147,34 @@ __global__ __launch_bounds__(256) void bilinear_up_clamp_kernel(const float* __r
 // padded to Cp channels.  A convolution over that tensor with the weight groups [W_hi | W_hi | W_lo] accumulates
 // y_hi W_hi + y_lo W_hi + y_hi W_lo in the MFMA's f32 accumulators: the product error drops from 2^-9 to about 2^-16
 // relative, which is what the 1e-3 parity bar needs through FAN's ~100 layers (the reference runs the regressor in fp32).
+// C % 8 == 0: one thread = 8 channels of one row (two float4 loads, three 16-byte stores), pad chunks zero-filled
+__global__ __launch_bounds__(256) void bn_act_split3_vec_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                                bf16_t* __restrict__ y, long rows, int C, int Cp, int relu) {
+    const int cpr = C / 8 + (Cp - 3 * C) / 8;                 // work items per row: data chunks, then pad chunks
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cpr) return;
+    const long row = i / cpr;
+    const int k = (int)(i % cpr);
+    bf16_t* yr = y + row * Cp;
+    if (k >= C / 8) {
+        *reinterpret_cast<uint4*>(yr + 3 * C + (k - C / 8) * 8) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int c0 = k * 8;
+    const float4 u = *reinterpret_cast<const float4*>(x + row * C + c0), v = *reinterpret_cast<const float4*>(x + row * C + c0 + 4);
+    float t[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w}, hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (coef) t[j] = t[j] * coef[c0 + j] + coef[C + c0 + j];
+        if (relu) t[j] = fmaxf(t[j], 0.f);
+        hi[j] = __builtin_bit_cast(float, (unsigned)f2bf_f(t[j]) << 16);
+        lo[j] = t[j] - hi[j];
+    }
+    store8f(yr + c0, hi);
+    store8f(yr + C + c0, lo);
+    store8f(yr + 2 * C + c0, hi);
+}
+
 __global__ __launch_bounds__(256) void bn_act_split3_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                             bf16_t* __restrict__ y, long rows, int C, int Cp, int relu) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -220,7 +248,12 @@ int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int
     if (!x || !y) return PPV_ERR_NULL;
     if (rows < 1 || C < 1 || Cp < 3 * C) return PPV_ERR_BAD_SIZE;
     const long tot = rows * Cp;
-    ppv::bn_act_split3_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu);
+    if (C % 8 == 0 && Cp % 8 == 0) {
+        const long items = rows * (C / 8 + (Cp - 3 * C) / 8);
+        ppv::bn_act_split3_vec_kernel<<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu);
+    } else {
+        ppv::bn_act_split3_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu);
+    }
     return ppv_last_error();
 }
 

@@ -191,7 +191,8 @@ class FAN(nn.Module):
 
     def _build_cache_p(self, dev):
         cache = {"dev": dev, "precise": True}
-        cache["stem_w"] = self._w3(self.conv1.conv.weight)                              # [64, 7, 7, 64] (18 real channels)
+        w1 = self.conv1.conv.weight.detach().float()                                     # [64,6,7,7]: input padded to 8 channels so that
+        cache["stem_w"] = self._w3(_pad_to(w1, (64, 8, 7, 7)))                           # the split runs vectorised -> [64,7,7,64]
         cache["stem_bn"] = _bn_coef(self.bn1, extra_shift=self.conv1.conv.bias.detach())
         cache["coords256"] = _coord_channels(256, 256).to(dev).contiguous()
         for name in ("conv2", "conv3", "conv4", "top_m_0"):
@@ -246,7 +247,7 @@ class FAN(nn.Module):
 
     def _trunk_p(self, x6):
         cache = self._cache
-        x = x6.permute(0, 2, 3, 1).contiguous()                                          # [B,256,256,6] f32
+        x = torch.nn.functional.pad(x6.permute(0, 2, 3, 1), (0, 2)).contiguous()         # [B,256,256,8] f32 (two zero channels)
         x = self._conv_p(x, None, cache["stem_w"], 64, 2, 3, relu=False)                  # CoordConv 7x7/2 (bias folded into bn)
         x = torch.relu(x * cache["stem_bn"][0] + cache["stem_bn"][1])
         x = self._avgpool_p(self._convblock_p(x, cache["conv2"]))

@@ -141,6 +141,8 @@ int ppv_corr_volume_bwd(const float* gcorr, const float* f1, const float* f2, fl
                         int HW, ppv_stream_t stream);
 int ppv_corr_lookup(const float* corr_l, const float* coords, float* out, int B, int H1, int W1, int Hl, int Wl, int r,
                     int level, int nlevels, ppv_stream_t stream);
+int ppv_corr_lookup_all(const float* const* corr_levels, const int* Hl, const int* Wl, int levels, const float* coords, float* out,
+                        int B, int H1, int W1, int r, ppv_stream_t stream);   /* every level in one launch (host arrays) */
 
 /* ---- FAN heat-map regressor forward, eval mode: Face-DeId/core/wing.py:178-260 (glue around ppv_conv_gemm) ------------- */
 int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, int W, ppv_stream_t stream);

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "ppv_corr_lookup_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_avgpool2_bwd_acc": (_I, [_P, _P, _L, _I, _I, _P]),
     "ppv_corr_volume_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ppv_corr_lookup_all": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_corr_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_zernike_contract": (_I, [_P, _P, _P, _I, _L, _P]),
     "ppv_fd_psf_workspace_bytes": (_Z, [_I]),

@@ -107,6 +107,43 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     out[(((long)b * nlevels * ne + (long)level * ne + e) * H1 + h1) * W1 + w1] = v;
 }
 
+// every pyramid level in one launch (grid.y = level): RAFT calls the lookup 20 times per sample, the four per-level
+// launches were launch-rate bound
+struct LookupLevels {
+    const float* corr[8];
+    int Hl[8], Wl[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void corr_lookup_all_kernel(LookupLevels lv, const float* __restrict__ coords,
+                                                              float* __restrict__ out, int B, int H1, int W1, int r) {
+    const int level = blockIdx.y, Hl = lv.Hl[level], Wl = lv.Wl[level];
+    const float* __restrict__ corr = lv.corr[level];
+    const int win = 2 * r + 1, ne = win * win;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long npix = (long)B * H1 * W1;
+    if (i >= npix * ne) return;
+    const long n = i % npix;
+    const int e = (int)(i / npix);
+    const int a = e / win, d = e % win;
+    const int w1 = (int)(n % W1), h1 = (int)((n / W1) % H1), b = (int)(n / ((long)W1 * H1));
+    const float inv = 1.0f / (float)(1 << level);
+    const float cx = coords[(((long)b * 2 + 0) * H1 + h1) * W1 + w1] * inv;
+    const float cy = coords[(((long)b * 2 + 1) * H1 + h1) * W1 + w1] * inv;
+    float x = cx + (float)(a - r);                 // x + dy[a]   (reference quirk)
+    float y = cy + (float)(d - r);                 // y + dx[d]
+    x = ((2.f * x / (float)(Wl - 1) - 1.f) + 1.f) * 0.5f * (float)(Wl - 1);
+    y = ((2.f * y / (float)(Hl - 1) - 1.f) + 1.f) * 0.5f * (float)(Hl - 1);
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float* img = corr + n * (long)Hl * Wl;
+    auto at = [&](int yy, int xx) -> float {
+        return (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? img[(long)yy * Wl + xx] : 0.f;
+    };
+    const float v = at(y0, x0) * wy0 * wx0 + at(y0, x0 + 1) * wy0 * wx1 + at(y0 + 1, x0) * wy1 * wx0 + at(y0 + 1, x0 + 1) * wy1 * wx1;
+    out[(((long)b * lv.n * ne + (long)level * ne + e) * H1 + h1) * W1 + w1] = v;
+}
+
 // ----------------------------------------------------------------------------- backward
 // adjoint of corr_lookup for one level: gcorr_l[n][y][x] += bilinear weights * gout[b][level*ne + e][h1][w1]
 __global__ __launch_bounds__(256) void corr_lookup_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ coords,
@@ -353,6 +390,22 @@ int ppv_corr_lookup(const float* corr_l, const float* coords, float* out, int B,
     if (!corr_l || !coords || !out) return PPV_ERR_NULL;
     const long tot = (long)B * H1 * W1 * (2 * r + 1) * (2 * r + 1);
     ppv::corr_lookup_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(corr_l, coords, out, B, H1, W1, Hl, Wl, r, level, nlevels);
+    return ppv_last_error();
+}
+
+// all levels of the lookup in one launch: corr_levels / Hl / Wl are HOST arrays of `levels` entries (<= 8)
+int ppv_corr_lookup_all(const float* const* corr_levels, const int* Hl, const int* Wl, int levels, const float* coords, float* out,
+                        int B, int H1, int W1, int r, hipStream_t stream) {
+    if (!corr_levels || !Hl || !Wl || !coords || !out) return PPV_ERR_NULL;
+    if (levels < 1 || levels > 8) return PPV_ERR_BAD_SIZE;
+    ppv::LookupLevels lv;
+    lv.n = levels;
+    for (int i = 0; i < levels; ++i) {
+        if (!corr_levels[i]) return PPV_ERR_NULL;
+        lv.corr[i] = corr_levels[i]; lv.Hl[i] = Hl[i]; lv.Wl[i] = Wl[i];
+    }
+    const long tot = (long)B * H1 * W1 * (2 * r + 1) * (2 * r + 1);
+    ppv::corr_lookup_all_kernel<<<dim3((unsigned)((tot + 255) / 256), levels), 256, 0, stream>>>(lv, coords, out, B, H1, W1, r);
     return ppv_last_error();
 }
 

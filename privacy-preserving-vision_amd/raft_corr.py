@@ -61,9 +61,11 @@ class _LookupFn(torch.autograd.Function):
         coords = coords.detach().float().contiguous()
         nl = len(pyr)
         out = torch.empty((B, nl * (2 * r + 1) ** 2, H, W), dtype=torch.float32, device=coords.device)
-        for i, c in enumerate(pyr):
-            check(L.ppv_corr_lookup(ptr(c), ptr(coords), ptr(out), B, H, W, c.shape[-2], c.shape[-1], r, i, nl, stream_ptr()),
-                  "ppv_corr_lookup")
+        import ctypes
+        ptrs = (ctypes.c_void_p * nl)(*[c.data_ptr() for c in pyr])
+        hs = (ctypes.c_int * nl)(*[c.shape[-2] for c in pyr])
+        ws = (ctypes.c_int * nl)(*[c.shape[-1] for c in pyr])
+        check(L.ppv_corr_lookup_all(ptrs, hs, ws, nl, ptr(coords), ptr(out), B, H, W, r, stream_ptr()), "ppv_corr_lookup_all")
         ctx.save_for_backward(coords)
         ctx.meta = (r, shape, [tuple(c.shape) for c in pyr])
         return out

@@ -147,11 +147,11 @@ int ppv_corr_lookup_all(const float* const* corr_levels, const int* Hl, const in
 /* ---- FAN heat-map regressor forward, eval mode: Face-DeId/core/wing.py:178-260 (glue around ppv_conv_gemm) ------------- */
 int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, int W, ppv_stream_t stream);
 int ppv_fan_input(const float* x, const float* coords, float* out, int B, int Hin, int Win, int S, ppv_stream_t stream);
-int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, ppv_stream_t stream);
-int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, ppv_stream_t stream);
+int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, int f32, ppv_stream_t stream);   /* f32: 0 bf16 tensors, 1 f32 */
+int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, int f32, ppv_stream_t stream);
 int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* res, void* out, long M, int n1, int n2,
-                    int n3, int s1, int s2, int s3, ppv_stream_t stream);
-int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, ppv_stream_t stream);
+                    int n3, int s1, int s2, int s3, int f32, ppv_stream_t stream);
+int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, int ldx, ppv_stream_t stream);
 int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr,
                  int nch, int split, int nsum, int up, ppv_stream_t stream);
 

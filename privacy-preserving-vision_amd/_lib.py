@@ -41,10 +41,10 @@ PROTOTYPES = {
     "ppv_zernike_grad": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "ppv_stem_conv6": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_fan_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "ppv_avgpool2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "ppv_upsample2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "ppv_concat3_add": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
-    "ppv_bn_act_split3": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "ppv_avgpool2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_upsample2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_concat3_add": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ppv_bn_act_split3": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "ppv_fan_head": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_ssim_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_ssim_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

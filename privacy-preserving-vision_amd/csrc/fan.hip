@@ -27,6 +27,15 @@ __device__ __forceinline__ void store8f(bf16_t* p, const float (&f)[8]) {
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void store8f(float* p, const float (&f)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
 // out [B,6,S,S] f32: channels 0..2 = bilinear(x [B,3,Hin,Win], align_corners=False) * 0.5 + 0.5, 3..5 = coords [3,S,S]
 __global__ __launch_bounds__(256) void fan_input_kernel(const float* __restrict__ x, const float* __restrict__ coords,
                                                         float* __restrict__ out, int B, int Hin, int Win, int S) {
@@ -47,7 +56,8 @@ __global__ __launch_bounds__(256) void fan_input_kernel(const float* __restrict_
 }
 
 // [B,H,W,C] bf16 -> [B,H/2,W/2,C] bf16
-__global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
                                                             int C) {
     const int Ho = H / 2, Wo = W / 2, c8n = C / 8;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -71,8 +81,9 @@ __global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const bf16_t* __rest
 }
 
 // out [B,H,W,C] = up1 + nearest_x2(low [B,H/2,W/2,C])
-__global__ __launch_bounds__(256) void upsample2_add_kernel(const bf16_t* __restrict__ up1, const bf16_t* __restrict__ low,
-                                                            bf16_t* __restrict__ out, int B, int H, int W, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_add_kernel(const T* __restrict__ up1, const T* __restrict__ low,
+                                                            T* __restrict__ out, int B, int H, int W, int C) {
     const int c8n = C / 8;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)B * H * W * c8n) return;
@@ -87,16 +98,17 @@ __global__ __launch_bounds__(256) void upsample2_add_kernel(const bf16_t* __rest
 }
 
 // out [M][n1+n2+n3] = cat(o1[M][:n1] (stride s1), o2[M][:n2] (stride s2), o3[M][:n3] (stride s3)) + res [M][n1+n2+n3]
-__global__ __launch_bounds__(256) void concat3_add_kernel(const bf16_t* __restrict__ o1, const bf16_t* __restrict__ o2,
-                                                          const bf16_t* __restrict__ o3, const bf16_t* __restrict__ res,
-                                                          bf16_t* __restrict__ out, long M, int n1, int n2, int n3, int s1,
+template <typename T>
+__global__ __launch_bounds__(256) void concat3_add_kernel(const T* __restrict__ o1, const T* __restrict__ o2,
+                                                          const T* __restrict__ o3, const T* __restrict__ res,
+                                                          T* __restrict__ out, long M, int n1, int n2, int n3, int s1,
                                                           int s2, int s3) {
     const int C = n1 + n2 + n3, c8n = C / 8;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * c8n) return;
     const int c0 = (int)(i % c8n) * 8;
     const long m = i / c8n;
-    const bf16_t* src = (c0 < n1) ? o1 + m * s1 + c0 : (c0 < n1 + n2) ? o2 + m * s2 + (c0 - n1) : o3 + m * s3 + (c0 - n1 - n2);
+    const T* src = (c0 < n1) ? o1 + m * s1 + c0 : (c0 < n1 + n2) ? o2 + m * s2 + (c0 - n1) : o3 + m * s3 + (c0 - n1 - n2);
     float a[8], r[8];
     load8f(src, a);
     load8f(res + i * 8, r);
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) void bilinear_up_clamp_kernel(const float* __r
 // relative, which is what the 1e-3 parity bar needs through FAN's ~100 layers (the reference runs the regressor in fp32).
 // C % 8 == 0: one thread = 8 channels of one row (two float4 loads, three 16-byte stores), pad chunks zero-filled
 __global__ __launch_bounds__(256) void bn_act_split3_vec_kernel(const float* __restrict__ x, const float* __restrict__ coef,
-                                                                bf16_t* __restrict__ y, long rows, int C, int Cp, int relu) {
+                                                                bf16_t* __restrict__ y, long rows, int C, int Cp, int relu, int ldx) {
     const int cpr = C / 8 + (Cp - 3 * C) / 8;                 // work items per row: data chunks, then pad chunks
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * cpr) return;
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_act_split3_vec_kernel(const float* __r
         return;
     }
     const int c0 = k * 8;
-    const float4 u = *reinterpret_cast<const float4*>(x + row * C + c0), v = *reinterpret_cast<const float4*>(x + row * C + c0 + 4);
+    const float4 u = *reinterpret_cast<const float4*>(x + row * ldx + c0), v = *reinterpret_cast<const float4*>(x + row * ldx + c0 + 4);
     float t[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w}, hi[8], lo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void bn_act_split3_vec_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void bn_act_split3_kernel(const float* __restrict__ x, const float* __restrict__ coef,
-                                                            bf16_t* __restrict__ y, long rows, int C, int Cp, int relu) {
+                                                            bf16_t* __restrict__ y, long rows, int C, int Cp, int relu, int ldx) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * Cp) return;
     const long row = i / Cp;
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_act_split3_kernel(const float* __restr
     float v = 0.f;
     const int grp = c / C, cc = c % C;
     if (c < 3 * C) {
-        float t = x[row * C + cc];
+        float t = x[row * ldx + cc];
         if (coef) t = t * coef[cc] + coef[C + cc];
         if (relu) t = fmaxf(t, 0.f);
         const float hi = __builtin_bit_cast(float, (unsigned)f2bf_f(t) << 16);
@@ -206,29 +218,34 @@ int ppv_fan_input(const float* x, const float* coords, float* out, int B, int Hi
     return ppv_last_error();
 }
 
-int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, hipStream_t stream) {
+// f32 = 0: bf16 tensors, 1: f32 tensors (fp32-accurate FAN mode)
+int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, int f32, hipStream_t stream) {
     if (!x || !y) return PPV_ERR_NULL;
     if (H % 2 || W % 2 || C % 8) return PPV_ERR_BAD_SIZE;
     const long tot = (long)B * (H / 2) * (W / 2) * (C / 8);
-    avgpool2_nhwc_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    if (f32) avgpool2_nhwc_kernel<float><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const float*)x, (float*)y, B, H, W, C);
+    else avgpool2_nhwc_kernel<bf16_t><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, B, H, W, C);
     return ppv_last_error();
 }
 
-int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, hipStream_t stream) {
+int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, int f32, hipStream_t stream) {
     if (!up1 || !low || !out) return PPV_ERR_NULL;
     if (H % 2 || W % 2 || C % 8) return PPV_ERR_BAD_SIZE;
     const long tot = (long)B * H * W * (C / 8);
-    upsample2_add_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)up1, (const bf16_t*)low, (bf16_t*)out, B, H, W, C);
+    if (f32) upsample2_add_kernel<float><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const float*)up1, (const float*)low, (float*)out, B, H, W, C);
+    else upsample2_add_kernel<bf16_t><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)up1, (const bf16_t*)low, (bf16_t*)out, B, H, W, C);
     return ppv_last_error();
 }
 
 int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* res, void* out, long M, int n1, int n2, int n3,
-                    int s1, int s2, int s3, hipStream_t stream) {
+                    int s1, int s2, int s3, int f32, hipStream_t stream) {
     if (!o1 || !o2 || !o3 || !res || !out) return PPV_ERR_NULL;
     if (n1 % 8 || n2 % 8 || n3 % 8) return PPV_ERR_BAD_SIZE;
     const long tot = M * ((n1 + n2 + n3) / 8);
-    concat3_add_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)o1, (const bf16_t*)o2, (const bf16_t*)o3,
-                                                                         (const bf16_t*)res, (bf16_t*)out, M, n1, n2, n3, s1, s2, s3);
+    if (f32) concat3_add_kernel<float><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const float*)o1, (const float*)o2, (const float*)o3,
+                                                                                         (const float*)res, (float*)out, M, n1, n2, n3, s1, s2, s3);
+    else concat3_add_kernel<bf16_t><<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)o1, (const bf16_t*)o2, (const bf16_t*)o3,
+                                                                                      (const bf16_t*)res, (bf16_t*)out, M, n1, n2, n3, s1, s2, s3);
     return ppv_last_error();
 }
 
@@ -242,17 +259,17 @@ int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums
     return ppv_last_error();
 }
 
-// x [rows][C] f32 -> y [rows][Cp] bf16 = [hi | lo | hi | 0...] of act(x * coef[0][c] + coef[1][c]) (coef may be null = identity);
+// x [rows][ldx] f32 (first C columns used) -> y [rows][Cp] bf16 = [hi | lo | hi | 0...] of act(x * coef[0][c] + coef[1][c]) (coef may be null = identity);
 // Cp >= 3 * C (zero padded).  See bn_act_split3_kernel: feeds ppv_conv_gemm with [W_hi | W_hi | W_lo] weights.
-int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, hipStream_t stream) {
+int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, int ldx, hipStream_t stream) {
     if (!x || !y) return PPV_ERR_NULL;
-    if (rows < 1 || C < 1 || Cp < 3 * C) return PPV_ERR_BAD_SIZE;
+    if (rows < 1 || C < 1 || Cp < 3 * C || ldx < C) return PPV_ERR_BAD_SIZE;
     const long tot = rows * Cp;
-    if (C % 8 == 0 && Cp % 8 == 0) {
+    if (C % 8 == 0 && Cp % 8 == 0 && ldx % 4 == 0) {
         const long items = rows * (C / 8 + (Cp - 3 * C) / 8);
-        ppv::bn_act_split3_vec_kernel<<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu);
+        ppv::bn_act_split3_vec_kernel<<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu, ldx);
     } else {
-        ppv::bn_act_split3_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu);
+        ppv::bn_act_split3_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, coef, (ppv::bf16_t*)y, rows, C, Cp, relu, ldx);
     }
     return ppv_last_error();
 }

@@ -206,57 +206,67 @@ class FAN(nn.Module):
                            + self.m0.coordconv.conv.bias.detach().float()).contiguous()   # [64,64,256] f32, bias folded in
         cache["last_w"] = self._w3(self.conv_last0.weight)
         cache["end_bn"] = _bn_coef(self.bn_end0, extra_shift=self.conv_last0.bias.detach())
+        cache["end_bn_id"] = None
         cache["l0_w"] = self._w3(self.l0.weight, cout_pad=128)
         cache["l0_b"] = self.l0.bias.detach().float().contiguous()
         cache["nl"] = self.l0.out_channels
         return cache
 
     @staticmethod
-    def _split3(x, coef, relu):
-        """x [B,H,W,C] f32 -> act(x*scale+shift) as bf16 [B,H,W,pad64(3C)] = [hi | lo | hi]."""
-        B, H, W, C = x.shape
+    def _split3(x, coef, relu, C=None):
+        """x [B,H,W,ld] f32 (first C channels used) -> act(x*scale+shift) as bf16 [B,H,W,pad64(3C)] = [hi | lo | hi]."""
+        B, H, W, ld = x.shape
+        C = C or ld
         cp = (3 * C + 63) // 64 * 64
         y = torch.empty((B, H, W, cp), dtype=torch.bfloat16, device=x.device)
-        check(_lib.lib().ppv_bn_act_split3(ptr(x), ptr(coef), ptr(y), B * H * W, C, cp, int(relu), stream_ptr()), "ppv_bn_act_split3")
+        check(_lib.lib().ppv_bn_act_split3(ptr(x), ptr(coef), ptr(y), B * H * W, C, cp, int(relu), ld, stream_ptr()), "ppv_bn_act_split3")
         return y
 
-    def _conv_p(self, x, coef, w3, n_out, stride=1, pad=0, relu=True):
-        """(BN + ReLU +) convolution, f32 in / f32 out (first n_out channels of the padded GEMM)."""
-        y = co.conv_fwd(self._split3(x.contiguous(), coef, relu), w3, stride, pad, out_f32=True)
-        return y if y.shape[-1] == n_out else y[..., :n_out].contiguous()
+    def _conv_p(self, x, coef, w3, stride=1, pad=0, relu=True, C=None):
+        """(BN + ReLU +) convolution, f32 in / f32 out; the output keeps the GEMM's 64-padded channel count (callers pass the
+        real count on as ``C`` / a source stride instead of slicing)."""
+        return co.conv_fwd(self._split3(x, coef, relu, C), w3, stride, pad, out_f32=True)
 
     def _convblock_p(self, x, c):
         n1, n2, n3 = c["n"]
-        o1 = self._conv_p(x, c["bn1"], c["w1"], n1, 1, 1)
-        o2 = self._conv_p(o1, c["bn2"], c["w2"], n2, 1, 1)
-        o3 = self._conv_p(o2, c["bn3"], c["w3"], n3, 1, 1)
-        res = x if "wd" not in c else self._conv_p(x, c["bnd"], c["wd"], n1 + n2 + n3, 1, 0)
-        return torch.cat([o1, o2, o3], dim=-1) + res
+        o1 = self._conv_p(x, c["bn1"], c["w1"], 1, 1)
+        o2 = self._conv_p(o1, c["bn2"], c["w2"], 1, 1, C=n1)
+        o3 = self._conv_p(o2, c["bn3"], c["w3"], 1, 1, C=n2)
+        res = x if "wd" not in c else self._conv_p(x, c["bnd"], c["wd"], 1, 0)
+        B, H, W, _ = x.shape
+        out = torch.empty((B, H, W, n1 + n2 + n3), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ppv_concat3_add(ptr(o1), ptr(o2), ptr(o3), ptr(res), ptr(out), B * H * W, n1, n2, n3, o1.shape[-1],
+                                         o2.shape[-1], o3.shape[-1], 1, stream_ptr()), "ppv_concat3_add")
+        return out
 
     @staticmethod
     def _avgpool_p(x):
         B, H, W, C = x.shape
-        return x.view(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+        y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ppv_avgpool2_nhwc(ptr(x), ptr(y), B, H, W, C, 1, stream_ptr()), "ppv_avgpool2_nhwc")
+        return y
 
     def _hourglass_p(self, level, x, cache):
         up1 = self._convblock_p(x, cache[f"m0.b1_{level}"])
         low = self._convblock_p(self._avgpool_p(x), cache[f"m0.b2_{level}"])
         low = self._hourglass_p(level - 1, low, cache) if level > 1 else self._convblock_p(low, cache["m0.b2_plus_1"])
         low = self._convblock_p(low, cache[f"m0.b3_{level}"])
-        return up1 + low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)          # nearest x2 (wing.py:70)
+        B, H, W, C = up1.shape
+        out = torch.empty_like(up1)
+        check(_lib.lib().ppv_upsample2_add(ptr(up1), ptr(low), ptr(out), B, H, W, C, 1, stream_ptr()), "ppv_upsample2_add")   # nearest x2 (wing.py:69)
+        return out
 
     def _trunk_p(self, x6):
         cache = self._cache
         x = torch.nn.functional.pad(x6.permute(0, 2, 3, 1), (0, 2)).contiguous()         # [B,256,256,8] f32 (two zero channels)
-        x = self._conv_p(x, None, cache["stem_w"], 64, 2, 3, relu=False)                  # CoordConv 7x7/2 (bias folded into bn)
+        x = self._conv_p(x, None, cache["stem_w"], 2, 3, relu=False)                      # CoordConv 7x7/2 (bias folded into bn)
         x = torch.relu(x * cache["stem_bn"][0] + cache["stem_bn"][1])
         x = self._avgpool_p(self._convblock_p(x, cache["conv2"]))
         x = self._convblock_p(self._convblock_p(x, cache["conv3"]), cache["conv4"])
-        h = self._conv_p(x, None, cache["cc_w"], 256, 1, 0, relu=False) + cache["cc_map"]
+        h = self._conv_p(x, None, cache["cc_w"], 1, 0, relu=False) + cache["cc_map"]
         ll = self._convblock_p(self._hourglass_p(4, h, cache), cache["top_m_0"])
-        ll = self._conv_p(ll, None, cache["last_w"], 256, 1, 0, relu=False)
-        ll = torch.relu(ll * cache["end_bn"][0] + cache["end_bn"][1])
-        return co.conv_fwd(self._split3(ll.contiguous(), None, False), cache["l0_w"], 1, 0, out_f32=True)   # [B,64,64,128] f32
+        ll = self._conv_p(ll, cache["end_bn_id"], cache["last_w"], 1, 0, relu=False)
+        return self._conv_p(ll, cache["end_bn"], cache["l0_w"], 1, 0, relu=True)          # BN + ReLU fused into the head conv's split
 
     def refresh(self):
         """Call after changing parameters in place (the kernel-side constants are cached)."""
@@ -272,14 +282,14 @@ class FAN(nn.Module):
         res = x if "wd" not in c else co.conv_fwd(co.bn_act(x, c["bnd"]), c["wd"], 1, 0)
         B, H, W, _ = x.shape
         out = torch.empty((B, H, W, n1 + n2 + n3), dtype=torch.bfloat16, device=x.device)
-        check(_lib.lib().ppv_concat3_add(ptr(o1), ptr(o2), ptr(o3), ptr(res), ptr(out), B * H * W, n1, n2, n3, n1, p2, p3,
+        check(_lib.lib().ppv_concat3_add(ptr(o1), ptr(o2), ptr(o3), ptr(res), ptr(out), B * H * W, n1, n2, n3, n1, p2, p3, 0,
                                          stream_ptr()), "ppv_concat3_add")
         return out
 
     def _avgpool(self, x):
         B, H, W, C = x.shape
         y = torch.empty((B, H // 2, W // 2, C), dtype=torch.bfloat16, device=x.device)
-        check(_lib.lib().ppv_avgpool2_nhwc(ptr(x), ptr(y), B, H, W, C, stream_ptr()), "ppv_avgpool2_nhwc")
+        check(_lib.lib().ppv_avgpool2_nhwc(ptr(x), ptr(y), B, H, W, C, 0, stream_ptr()), "ppv_avgpool2_nhwc")
         return y
 
     def _hourglass(self, level, x, cache):
@@ -289,7 +299,7 @@ class FAN(nn.Module):
         low = self._convblock(low, cache[f"m0.b3_{level}"])
         B, H, W, C = up1.shape
         out = torch.empty_like(up1)
-        check(_lib.lib().ppv_upsample2_add(ptr(up1), ptr(low), ptr(out), B, H, W, C, stream_ptr()), "ppv_upsample2_add")
+        check(_lib.lib().ppv_upsample2_add(ptr(up1), ptr(low), ptr(out), B, H, W, C, 0, stream_ptr()), "ppv_upsample2_add")
         return out
 
     def _trunk(self, x6):

@@ -13,6 +13,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
+ABI_VERSION = 2
+
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
 PROTOTYPES = {
     "ppv_abi_version": (_I, []),
@@ -111,6 +113,9 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
+        if L.ppv_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {L.ppv_abi_version()} != {ABI_VERSION} expected by this package "
+                               "(stale build? re-run __graft_entry__.build())")
         _lib = L
     return _lib
 

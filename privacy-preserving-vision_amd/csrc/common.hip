@@ -44,6 +44,6 @@ int ppv_init(void) {
     return PPV_OK;
 }
 
-int ppv_abi_version(void) { return 1; }
+int ppv_abi_version(void) { return 2; }   // 2: mask_bits / pos_bits, decoder, SSIM, alt-corr, split-bf16 entries
 
 }  // extern "C"

@@ -6,11 +6,19 @@ import torch
 import bench
 
 
+WITH_DECODER = "--decoder" in sys.argv
+
+
 def run(steps, batch=32):
     torch.manual_seed(1234)
     dev = torch.device("cuda", 0)
     camera, encoder = bench.build(dev, global_max_sync=False)
-    step, _ = bench.make_step(camera, encoder, batch, dev, None)
+    decoder = None
+    if WITH_DECODER:
+        from ppv_amd.decoder import DecoderWithAttention
+        torch.manual_seed(3)
+        decoder = DecoderWithAttention(attention_dim=512, embed_dim=512, decoder_dim=512, vocab_size=9490, dropout=0.0).to(dev).train()
+    step, _ = bench.make_step(camera, encoder, batch, dev, None, decoder)
     out = []
     for i in range(steps):
         out.append(float(step().detach()))

@@ -37,13 +37,44 @@ F32, BF16 = torch.float32, torch.bfloat16
 
 
 class Attention(nn.Module):
-    """Parameter container with the reference's names (models.py:57-73); the math runs inside _DecoderFn."""
+    """models.py:57-90.  In training the attention runs inside ``_DecoderFn`` (hoisted encoder_att, BPTT); this ``forward`` is the
+    stand-alone single-step form the reference's beam search calls (eval/caption.py:93), inference only."""
 
     def __init__(self, encoder_dim, decoder_dim, attention_dim):
         super().__init__()
         self.encoder_att = nn.Linear(encoder_dim, attention_dim)
         self.decoder_att = nn.Linear(decoder_dim, attention_dim)
         self.full_att = nn.Linear(attention_dim, 1)
+
+    def forward(self, encoder_out, decoder_hidden):
+        """encoder_out [s,P,E] (any strides, e.g. the beam search's expand()), decoder_hidden [s,D] -> (awe [s,E], alpha [s,P])."""
+        if torch.is_grad_enabled() and (encoder_out.requires_grad or decoder_hidden.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("ppv_amd Attention.forward is the inference step (eval/caption.py); training goes through "
+                                      "DecoderWithAttention.forward (run beam search under torch.no_grad())")
+        if not encoder_out.is_cuda:
+            raise RuntimeError("ppv_amd Attention runs on an MI355X (cuda tensors); no CPU path")
+        with torch.no_grad():
+            S, P, E = encoder_out.shape
+            A = self.encoder_att.out_features
+            if E % 128 or A % 128:
+                raise ValueError("ppv_amd decoder: encoder_dim and attention_dim must be multiples of 128 (MFMA GEMM tiles)")
+            dev = encoder_out.device
+            enc = encoder_out.float().contiguous()
+            order = torch.arange(S, device=dev)
+            rows = torch.empty((S, P, 1, E), dtype=BF16, device=dev)
+            mean = torch.zeros((S, E), dtype=F32, device=dev)
+            check(L().ppv_dec_prepare(ptr(enc), ptr(order), ptr(rows), ptr(mean), S, P, E, stream_ptr()), "ppv_dec_prepare")
+            att = co.conv_fwd(rows, co.weight_layout(self.encoder_att.weight.detach().view(A, E, 1, 1), 0), 1, 0)
+            hproj = torch.zeros((S, A + E), dtype=F32, device=dev)        # [att2 + both biases | gate pre-activation (unused: 0)]
+            hproj[:, :A] = torch.addmm(self.decoder_att.bias + self.encoder_att.bias, decoder_hidden.float(), self.decoder_att.weight.t())
+            ebuf = torch.empty((S, P), dtype=F32, device=dev)
+            alpha = torch.empty((S, P), dtype=F32, device=dev)
+            awe = torch.empty((S, E), dtype=F32, device=dev)
+            xh = torch.empty((S, E), dtype=F32, device=dev)                # gated copy (sigmoid(0) * awe), discarded
+            check(L().ppv_dec_attend_fwd(ptr(att), ptr(rows), ptr(hproj), A + E, ptr(self.full_att.weight.detach().reshape(-1).contiguous()),
+                                         ptr(ebuf), ptr(alpha), ptr(awe), ptr(xh), E, 0, S, P, A, E, stream_ptr()), "ppv_dec_attend_fwd")
+            return awe, alpha
 
 
 def _numel(shape):
@@ -306,6 +337,11 @@ class DecoderWithAttention(nn.Module):
     def fine_tune_embeddings(self, fine_tune=True):
         for p in self.embedding.parameters():
             p.requires_grad = fine_tune
+
+    def init_hidden_state(self, encoder_out):
+        """models.py:143-155 (called by the beam search, eval/caption.py:86; the training forward computes it in its prepare pass)."""
+        mean_encoder_out = encoder_out.mean(dim=1)
+        return self.init_h(mean_encoder_out), self.init_c(mean_encoder_out)
 
     def _plist(self):
         a, ds = self.attention, self.decode_step

@@ -183,3 +183,34 @@ def test_encoder_hands_cell_map_to_decoder():
     dec.use_compact = False
     preds2 = dec(enc(img), caps, torch.tensor([[6], [4], [5]], device="cuda"))[0]
     assert _l2(preds2.detach().cpu(), preds.detach().cpu()) < 2e-2
+
+
+@pytest.mark.gpu
+def test_beam_search_entry_points_match_oracle():
+    """The stand-alone calls of the reference's beam search (eval/caption.py:86-102): init_hidden_state, attention(enc, h) on an
+    expand()-ed encoder tensor, f_beta / decode_step / fc -- against the oracle's attend() and init linears."""
+    import ppv_amd.decoder as pd
+    from oracle.decoder import DecoderWithAttention as Ref
+    torch.manual_seed(4)
+    E, A, M, D, V, P, k = 256, 128, 32, 48, 40, 63, 3
+    ref = Ref(A, M, D, V, encoder_dim=E, dropout=0.5).eval()
+    fill_by_name(ref)
+    dec = pd.DecoderWithAttention(A, M, D, V, encoder_dim=E, dropout=0.5).eval()
+    dec.load_state_dict(ref.state_dict())
+    dec = dec.cuda()
+    enc1 = torch.randn(1, P, E)
+    enc = enc1.expand(k, P, E)                                              # stride-0 batch dimension, as the beam search builds it
+    h = torch.randn(k, D)
+    with torch.no_grad():
+        h0, c0 = dec.init_hidden_state(enc.cuda())
+        mean = enc.mean(dim=1)
+        assert rel_err(h0, ref.init_h(mean)) < 1e-5 and rel_err(c0, ref.init_c(mean)) < 1e-5
+        awe, alpha = dec.attention(enc.cuda(), h.cuda())
+        awe_o, alpha_o = ref.attend(enc, h)
+        assert awe.shape == (k, E) and alpha.shape == (k, P)
+        assert _l2(alpha.cpu(), alpha_o) < 1e-2 and _l2(awe.cpu(), awe_o) < 1e-2
+        gate = dec.sigmoid(dec.f_beta(h.cuda()))
+        h1, c1 = dec.decode_step(torch.cat([dec.embedding(torch.tensor([1, 2, 3]).cuda()), gate * awe], dim=1), (h.cuda(), h.cuda()))
+        assert dec.fc(h1).shape == (k, V)
+    with pytest.raises(NotImplementedError):
+        dec.attention(enc.cuda().requires_grad_(True), h.cuda())

@@ -5,6 +5,7 @@
 // BN + ReLU + MaxPool 3x3/2, and the Encoder's AdaptiveAvgPool2d(36) on an 8x8 map (models.py:27,39-40; output is
 // already NHWC so the reference's permute disappears).  All HBM-bound: 16-byte accesses, fp32 math.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ppv_common.h"
 
 namespace ppv {
@@ -101,13 +102,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
 
 // ----------------------------------------------------------------------------- BN backward
 // pass 1: per-channel partial sums of g_pre and g_pre * x, g_pre = g_y * (y > 0) [RELU] ; part [32][2][C] pre-zeroed,
-// block b adds into row b & 31
+// block b adds into row b & fold_mask (31 with the separate coefficient launch, 7 with the fused apply)
 // RELU: 0 none, 1 mask from the stored activation y, 2 mask recomputed as (x*scale + shift > 0) from coef (BN + ReLU
 // without residual: saves reading y; the expression is the forward kernel's, so the mask is bit-identical)
 template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
                                                             const bf16_t* __restrict__ x, const float* __restrict__ coef,
-                                                            float* __restrict__ part, long rows, int C, int rows_per_blk) {
+                                                            float* __restrict__ part, long rows, int C, int rows_per_blk,
+                                                            int fold_mask) {
     __shared__ float s_red[256][17];
     const int tpr = C / 8;                         // threads per row
     const int rpp = 256 / tpr;                     // rows per pass
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
         for (int k = 0; k < 8; ++k) { sc[k] = coef[tc * 8 + k]; sh[k] = coef[C + tc * 8 + k]; }
     }
     if (tr < rpp) {
+#pragma unroll 4
         for (long row = r0 + tr; row < r1; row += rpp) {
             const long o = row * C + tc * 8;
             float g[8], xv[8], yv[8];
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
         const int tcc = c / 8, k = c % 8;
         float v = 0.f;
         for (int rr = 0; rr < rpp; ++rr) v += s_red[rr * tpr + tcc][which * 8 + k];
-        atomicAdd(&part[((long)(blockIdx.x & 31) * 2 + which) * C + c], v);
+        atomicAdd(&part[((long)(blockIdx.x & fold_mask) * 2 + which) * C + c], v);
     }
 }
 
@@ -202,6 +205,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     }
     store8(gx + i * 8, o);
     if (WRITE_GPRE) store8(gpre + i * 8, gp);
+}
+
+// pass 2, coefficients in the prologue: every workgroup sums the 8 folded partial rows for its own channel slice
+// (<= 256 channels, 16 KB of L2-resident f32) and derives kc itself, so the separate coefficient launch and its two
+// kernel boundaries disappear.  grid (row slabs, C / CS), CS = min(C, 256); block = (256 / (CS/8)) rows x CS/8 lanes.
+template <int RELU, bool WRITE_GPRE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                                 const bf16_t* __restrict__ x, const float* __restrict__ part,
+                                                                 const float* __restrict__ coef, double count,
+                                                                 bf16_t* __restrict__ gx, bf16_t* __restrict__ gpre,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 long rows, int C, int rows_per_blk, int fold_rows) {
+    __shared__ float s_k[5][256];
+    const int CS = C < 256 ? C : 256;
+    const int cb = blockIdx.y * CS;
+    if ((int)threadIdx.x < CS) {
+        const int c = cb + threadIdx.x;
+        double a = 0, b = 0;
+#pragma unroll 8
+        for (int t = 0; t < fold_rows; ++t) {
+            a += (double)part[((long)t * 2 + 0) * C + c];
+            b += (double)part[((long)t * 2 + 1) * C + c];
+        }
+        const double scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
+        const double dgam = invstd * (b - mean * a);
+        s_k[0][threadIdx.x] = (float)scale;
+        s_k[1][threadIdx.x] = (float)(-scale * invstd * dgam / count);
+        s_k[2][threadIdx.x] = (float)(-scale * a / count + scale * invstd * mean * dgam / count);
+        s_k[3][threadIdx.x] = (float)scale;
+        s_k[4][threadIdx.x] = coef[C + c];
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[c] = (float)dgam;
+            if (dbeta) dbeta[c] = (float)a;
+        }
+    }
+    __syncthreads();
+    const int tpr = CS / 8, rpp = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    float k0[8], k1[8], k2[8], sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        k0[k] = s_k[0][tc * 8 + k]; k1[k] = s_k[1][tc * 8 + k]; k2[k] = s_k[2][tc * 8 + k];
+        if (RELU == 2) { sc[k] = s_k[3][tc * 8 + k]; sh[k] = s_k[4][tc * 8 + k]; }
+    }
+    const long r0 = (long)blockIdx.x * rows_per_blk;
+    const long r1 = min(rows, r0 + rows_per_blk);
+#pragma unroll 4
+    for (long row = r0 + tr; row < r1; row += rpp) {
+        const long o_ = row * C + cb + tc * 8;
+        float g[8], xv[8], yv[8], o[8], gp[8];
+        load8(gy + o_, g);
+        load8(x + o_, xv);
+        if (RELU == 1) load8(y + o_, yv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (RELU == 2) yv[k] = xv[k] * sc[k] + sh[k];
+            gp[k] = (RELU && !(yv[k] > 0.f)) ? 0.f : g[k];
+            o[k] = k0[k] * gp[k] + k1[k] * xv[k] + k2[k];
+        }
+        store8(gx + o_, o);
+        if (WRITE_GPRE) store8(gpre + o_, gp);
+    }
 }
 
 // ----------------------------------------------------------------------------- stem: BN + ReLU + MaxPool 3x3/2 pad 1
@@ -342,6 +407,11 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const TG* __rest
 
 using namespace ppv;
 
+static int env_int_(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 extern "C" {
 
 int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
@@ -389,19 +459,39 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
                hipStream_t stream) {
     if (!gy || !x || !coef || !gx || !part || !kc || (relu == 1 && !y)) return PPV_ERR_NULL;
     if (C % 64 || C > 2048) return PPV_ERR_BAD_SIZE;
+    static const int fused = env_int_("PPV_BN_BWD_FUSED", 1);
+    const bool fuse = fused && (C == 64 || C == 128 || C % 256 == 0);
     const int rpp = 256 / (C / 8);
-    long rpb = (long)rpp * 16;
+    static const int red_iters = env_int_("PPV_BN_RED_ITERS", 8), fold_rows = env_int_("PPV_BN_FOLD", 8);
+    long rpb = (long)rpp * (fuse ? red_iters : 16);
     long nb = (rows + rpb - 1) / rpb;
-    while (nb > 2048) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
+    while (nb > (fuse ? 1024 : 2048)) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
     const bf16_t *g = (const bf16_t*)gy, *yy = (const bf16_t*)y, *xx = (const bf16_t*)x;
     if (!part_prezeroed) (void)hipMemsetAsync(part, 0, sizeof(float) * 64 * C, stream);
-    if (relu == 2) bn_bwd_reduce_kernel<2><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb);
-    else if (relu) bn_bwd_reduce_kernel<1><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb);
-    else bn_bwd_reduce_kernel<0><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb);
+    const int fold = fuse ? fold_rows - 1 : 31;
+    if (relu == 2) bn_bwd_reduce_kernel<2><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
+    else if (relu) bn_bwd_reduce_kernel<1><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
+    else bn_bwd_reduce_kernel<0><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
+    bf16_t *ox = (bf16_t*)gx, *op = (bf16_t*)gpre;
+    if (fuse) {
+        static const int iters = env_int_("PPV_BN_BWD_ITERS", 8);
+        const int CS = C < 256 ? C : 256;
+        const int arpp = 256 / (CS / 8);
+        const long arpb = (long)arpp * iters;
+        const dim3 grid((unsigned)((rows + arpb - 1) / arpb), (unsigned)(C / CS));
+#define PPV_APPLY(R, G) bn_bwd_apply_fused_kernel<R, G><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, fold_rows)
+        if (relu == 2 && gpre) PPV_APPLY(2, true);
+        else if (relu == 2) PPV_APPLY(2, false);
+        else if (relu && gpre) PPV_APPLY(1, true);
+        else if (relu) PPV_APPLY(1, false);
+        else if (gpre) PPV_APPLY(0, true);
+        else PPV_APPLY(0, false);
+#undef PPV_APPLY
+        return ppv_last_error();
+    }
     bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, 32, count, coef, kc, dgamma, dbeta, C);
     const long n8 = rows * C / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
-    bf16_t *ox = (bf16_t*)gx, *op = (bf16_t*)gpre;
     if (relu == 2 && gpre) bn_bwd_apply_kernel<2, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
     else if (relu == 2) bn_bwd_apply_kernel<2, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
     else if (relu && gpre) bn_bwd_apply_kernel<1, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
 PROTOTYPES = {
@@ -72,6 +72,7 @@ PROTOTYPES = {
     "ppv_fd_psf_workspace_bytes": (_Z, [_I]),
     "ppv_fd_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
     "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
+    "ppv_conv_gemm_red": (_I, [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P]),
     "ppv_weight_layout_multi": (_I, [_P, _I, _I, _P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),

@@ -106,15 +106,28 @@ def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
     return out
 
 
-def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=None):
+RED_ROWS = 8       # partial rows of the BN-backward sums (ppv_conv_gemm_red / ppv_bn_bwd's fused apply)
+
+
+def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=None, red=None):
     """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend);
     relu_bits: (conv input > 0) bit mask from bn_act(..., want_bits=True) when that input is a ReLU output -> lanes whose bit
-    is clear get a zero gradient."""
+    is clear get a zero gradient.  red = (x_raw, part): also take the BN-backward sums of the stored gradient against x_raw
+    (the raw conv output of the BatchNorm this gradient flows into) into the PRE-ZEROED f32 part [>= 16 * Cin];
+    bn_bwd(..., part=part, part_ready=True) then skips its reduce pass."""
     B, Ho, Wo, Cout = g.shape
     Cin, R, S, _ = wd.shape
     H, W = in_hw
     out = torch.empty((B, H, W, Cin), dtype=F32 if out_f32 else BF16, device=g.device)
     kind = "conv_gemm<128>" if Cin % 128 == 0 else "conv_gemm<64>"
+    if red is not None:
+        xr, part = red
+        assert xr.shape == out.shape and xr.dtype == BF16 and not out_f32
+        _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
+            L().ppv_conv_gemm_red(ptr(g), ptr(wd), ptr(out), ptr(part), ptr(xr), ptr(addend), ptr(relu_bits),
+                                  ptr(zero_page(g.device)), B, Ho, Wo, Cout, H, W, Cin, R, S, 1, -(R - 1 - pad), stride,
+                                  RED_ROWS, stream_ptr()), "ppv_conv_gemm_red"))
+        return out
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
     _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
         L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(relu_bits), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
@@ -189,8 +202,9 @@ def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, wan
     return (y, bits) if want_bits else y
 
 
-def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None):
-    """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None).  part: optional PRE-ZEROED f32 [64*C] scratch."""
+def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False):
+    """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None).  part: optional PRE-ZEROED f32 [64*C] scratch;
+    part_ready: part already holds the sums (conv_dgrad(..., red=(x, part)) produced gy)."""
     C = x.shape[-1]
     rows = x.numel() // C
     dev = x.device
@@ -203,7 +217,7 @@ def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None):
         part = torch.empty(64 * C, dtype=F32, device=dev)
     kc = torch.empty(3 * C, dtype=F32, device=dev)
     check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
-                         ptr(kc), rows, C, int(relu), int(prezeroed), stream_ptr()), "ppv_bn_bwd")
+                         ptr(kc), rows, C, int(relu), 2 if part_ready else int(prezeroed), stream_ptr()), "ppv_bn_bwd")
     return gx, gpre, dg, db
 
 

@@ -257,12 +257,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
 // WAR: stage t+NSTAGE-1 overwrites the buffer last read in compute(t-1), which every wave finished before barrier t.
 template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32>
+// RED (data-gradient launches that feed a BatchNorm backward): stat_part receives, instead of the forward statistics, the
+// BN-backward sums of the tile as it is STORED (after addend, rounding and ReLU mask): sum g and sum g * red_x per column,
+// red_x [M][N] bf16 = the raw conv output that BatchNorm normalised.  The separate reduce pass over g and x (2 T) becomes one
+// extra read of x (1 T) in this store loop.
+__device__ __forceinline__ void red_acc8(const uint4 gv, const uint4 xv, float (&ra)[8], float (&rb)[8]) {
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float g0 = __builtin_bit_cast(float, gw[i] << 16), g1 = __builtin_bit_cast(float, gw[i] & 0xffff0000u);
+        const float x0 = __builtin_bit_cast(float, xw[i] << 16), x1 = __builtin_bit_cast(float, xw[i] & 0xffff0000u);
+        ra[2 * i] += g0; ra[2 * i + 1] += g1;
+        rb[2 * i] += g0 * x0; rb[2 * i + 1] += g1 * x1;
+    }
+}
+
+template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
-                                                                   int tiles_n, int stat_rows) {
+                                                                   int tiles_n, int stat_rows, const bf16_t* __restrict__ red_x) {
     constexpr int NT = BM * 2, NWAVE = NT / 64;
     constexpr int ROWB = BK * 2, CH = BK / 8;                             // bytes / 16-byte chunks per staged row
     constexpr int RPI = 1024 / ROWB;                                       // rows per 1-KiB LDS-DMA wave-instruction
@@ -412,6 +427,35 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     char* sO = smem;
     float* sStat = reinterpret_cast<float*>(smem + BM * LDO);
     constexpr int CPR = BN / 8;
+    static_assert(!RED || (CPR == 16 && !OUT_F32), "RED: 128-column bf16 tiles");
+    float ra[8], rb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ra[k] = rb[k] = 0.f;
+    // every thread's chunk column ch = tid % 16 is the same in all its store iterations: fold the four rows of a wave by
+    // shuffles, the waves through LDS (the staging area is free once the caller has passed a barrier), then one atomic per column
+    auto red_finish = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ra[k] += __shfl_xor(ra[k], 16, 64); rb[k] += __shfl_xor(rb[k], 16, 64);
+            ra[k] += __shfl_xor(ra[k], 32, 64); rb[k] += __shfl_xor(rb[k], 32, 64);
+        }
+        float* sRed = reinterpret_cast<float*>(smem);
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sRed[(wave * 2 + 0) * BN + lane * 8 + k] = ra[k];
+                sRed[(wave * 2 + 1) * BN + lane * 8 + k] = rb[k];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += NT) {
+            const int which = t / BN, col = t % BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) v += sRed[(w * 2 + which) * BN + col];
+            atomicAdd(&stat_part[((long)(tile_m % stat_rows) * 2 + which) * g.N + n0 + col], v);
+        }
+    };
     if (addend) {
         // the addend tile comes in as whole 16-byte chunks (coalesced), is parked in LDS behind the output staging
         // area and added fragment-wise in f32: one rounding of (acc + addend), no 2-byte global gathers
@@ -428,6 +472,19 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
             bf16_t* outp = reinterpret_cast<bf16_t*>(Out);
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
+                // the mask bytes of this pass's store loop are requested first: their latency hides behind the addend round trip
+                constexpr int SIT = (HR * CPR + NT - 1) / NT;
+                unsigned char mb[SIT];
+#pragma unroll
+                for (int it = 0; it < SIT; ++it) {
+                    const int idx = it * NT + tid;
+                    const int row = idx / CPR, ch = idx % CPR;
+                    const long m = m0 + pass * HR + row;
+                    mb[it] = 0xff;
+                    if (idx < HR * CPR && m < g.M) {
+                        if (mask_bits) mb[it] = mask_bits[(m * g.N + n0) / 8 + ch];
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < (HR * CPR + NT - 1) / NT; ++it) {
                     const int idx = it * NT + tid;
@@ -455,7 +512,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                                 s2 += v * v;
                                 *reinterpret_cast<bf16_t*>(sOh + rowl * LDO + col * 2) = h;
                             }
-                        if (stat_part) {
+                        if (!RED && stat_part) {
                             s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
                             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
                             if (fq == 0) {
@@ -474,13 +531,16 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                     if (idx < HR * CPR && m < g.M)
                     {
                         uint4 v = *reinterpret_cast<const uint4*>(sOh + row * LDO + ch * 16);
-                        if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
+                        if (mask_bits) v = relu_mask8(v, mb[it]);
+                        if constexpr (RED) red_acc8(v, *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8), ra, rb);
                         *reinterpret_cast<uint4*>(outp + m * g.N + n0 + ch * 8) = v;
                     }
                 }
                 __syncthreads();
             }
-            if (stat_part && tid < 2 * BN) {
+            if constexpr (RED) {
+                red_finish();
+            } else if (stat_part && tid < 2 * BN) {
                 const int which = tid / BN, col = tid % BN;
                 float v = 0.f;
 #pragma unroll
@@ -523,7 +583,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                 s2 += v * v;
                 *reinterpret_cast<bf16_t*>(sO + (wm * WROWS + mi * 16 + fq * 4 + j) * LDO + col * 2) = h;
             }
-        if (stat_part) {
+        if (!RED && stat_part) {
             s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
             if (fq == 0) {
@@ -533,7 +593,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         }
     }
     __syncthreads();
-    if (stat_part && tid < 2 * BN) {
+    if (!RED && stat_part && tid < 2 * BN) {
         const int which = tid / BN, col = tid % BN;
         float v = 0.f;
 #pragma unroll
@@ -550,8 +610,13 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         {
             uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
             if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
+            if constexpr (RED) red_acc8(v, *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8), ra, rb);
             *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
         }
+    }
+    if constexpr (RED) {
+        __syncthreads();                                        // every chunk of the staged tile has been read
+        red_finish();
     }
 }
 
@@ -625,14 +690,15 @@ int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
 // stat_part [stat_rows][2][N] f32 BN partial sums, PRE-ZEROED by the caller (may be null), addend [M][N] bf16 (may be null),
 // mask_bits [M * N / 8] bytes (may be null; bit k of byte i <-> element 8 i + k, as ppv_bn_act's pos_bits writes them): output
 // lanes whose bit is clear are zeroed (ReLU backward folded into the data-gradient store); zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
-int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
-                  const void* zero_page,
-                  int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
-                  int out_f32, int stat_rows, hipStream_t stream) {
+static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
+                          const void* zero_page, const void* red_x_,
+                          int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
+                          int out_f32, int stat_rows, hipStream_t stream) {
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
-    if (stat_part && addend) return PPV_ERR_BAD_SIZE;           // the epilogue parks the addend tile where the statistics are folded
+    if (stat_part && addend && !red_x_) return PPV_ERR_BAD_SIZE; // the epilogue parks the addend tile where the statistics are folded
+    if (red_x_ && (!stat_part || out_f32 || N % 128)) return PPV_ERR_BAD_SIZE;
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
@@ -641,6 +707,7 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
     const bf16_t* x = (const bf16_t*)X;
     const bf16_t* w = (const bf16_t*)Wt;
     const bf16_t* ad = (const bf16_t*)addend;
+    const bf16_t* rx = (const bf16_t*)red_x_;
     const unsigned char* mk = (const unsigned char*)mask_bits;
     if (mk && out_f32) return PPV_ERR_BAD_SIZE;                 // the mask applies to the bf16 store path only
     const bf16_t* z = (const bf16_t*)zero_page;
@@ -649,21 +716,27 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
         if (out_f32) conv_gemm_kernel<BN_, WM_, true><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, mk, z, g, TN_, stat_rows); \
         else conv_gemm_kernel<BN_, WM_, false><<<tiles_m * (TN_), 256, 0, stream>>>(x, w, out, stat_part, ad, mk, z, g, TN_, stat_rows);        \
     } while (0)
-#define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_)                                                                                  \
+#define PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, REDOK_)                                                               \
     do {                                                                                                                \
-        constexpr int lds = NS_ * (BM_ + BN_) * BK_ * 2;                                                                    \
+        constexpr int lds = NS_ * (BM_ + BN_) * BK_ * 2;                                                                \
         const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;                                                      \
-        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false>;                                                          \
-        auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, true>;                                                           \
+        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, false>;                                         \
+        auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, true, false>;                                          \
+        auto kr = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, REDOK_>;                                        \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
             (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
+            (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows);              \
-        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows);                      \
+        if (rx && !(REDOK_)) return PPV_ERR_BAD_SIZE;                                                                   \
+        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx);           \
+        else if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr); \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr);         \
     } while (0)
+#define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, false)
+#define PPV_LAUNCH_PIPE_R(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, true)
     // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages (BK 64),
     // 4 = 256 x 128 x 3 stages of BK 32, two workgroups per CU
     const int CUS = 256;
@@ -679,16 +752,40 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
         else if (t256 >= CUS) v = 3;            // one round: deepest prefetch per workgroup
         else v = 2;                             // the 256-row tile only when it still fills the chip
     }
+    if (rx && (v < 2 || v > 4)) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the three production tiles only
     if (v == 5) PPV_LAUNCH_PIPE(128, 128, 3, 32, 3);      // 16 KB stages, three 4-wave workgroups per CU
-    else if (v == 4) PPV_LAUNCH_PIPE(256, 128, 3, 32, 2); // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
-    else if (v == 3) PPV_LAUNCH_PIPE(256, 128, 3, 64, 1);
-    else if (v == 2) PPV_LAUNCH_PIPE(128, 128, 4, 64, 1);
+    else if (v == 4) PPV_LAUNCH_PIPE_R(256, 128, 3, 32, 2); // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
+    else if (v == 3) PPV_LAUNCH_PIPE_R(256, 128, 3, 64, 1);
+    else if (v == 2) PPV_LAUNCH_PIPE_R(128, 128, 4, 64, 1);
     else if (N == 16) PPV_LAUNCH(16, 4, 1);
     else if (N % 128 == 0) PPV_LAUNCH(128, 2, N / 128);
     else PPV_LAUNCH(64, 2, N / 64);
 #undef PPV_LAUNCH
 #undef PPV_LAUNCH_PIPE
+#undef PPV_LAUNCH_PIPE_R
+#undef PPV_LAUNCH_PIPE_
     return ppv_last_error();
+}
+
+int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
+                  const void* zero_page,
+                  int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
+                  int out_f32, int stat_rows, hipStream_t stream) {
+    return conv_gemm_impl(X, Wt, out, stat_part, addend, mask_bits, zero_page, nullptr, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div,
+                          out_f32, stat_rows, stream);
+}
+
+// Data-gradient launch that also takes the BN-backward sums of the tensor it stores: red_part [red_rows][2][N] f32 (PRE-ZEROED)
+// receives sum g and sum g * red_x per column, g = the stored (addend-added, rounded, masked) output, red_x [M][N] bf16 = the raw
+// convolution output the following BatchNorm normalised.  ppv_bn_bwd(..., part_prezeroed = 2) then skips its reduce pass.
+// bf16 output, N % 128 == 0.
+int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const void* addend,
+                      const void* mask_bits, const void* zero_page,
+                      int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
+                      int red_rows, hipStream_t stream) {
+    if (!red_part || !red_x) return PPV_ERR_NULL;
+    return conv_gemm_impl(X, Wt, out, red_part, addend, mask_bits, zero_page, red_x, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div, 0,
+                          red_rows, stream);
 }
 
 // rows of the BN partial buffer a conv with M output pixels should use

@@ -453,7 +453,8 @@ int ppv_bn_bwd_blocks(long rows, int C) {
 
 // Train-mode BN backward; relu: 0 none, 1 ReLU mask from the stored activation y, 2 mask recomputed from x and coef
 // (BN + ReLU without residual; y may be null).  Writes g_x (bf16), optionally g_pre (bf16, may be
-// null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats (zeroed here); kc: scratch 3*C.
+// null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats; part_prezeroed 0: zeroed here, 1: the caller
+// zeroed it, 2: it already holds the [8][2][C] sums (ppv_conv_gemm_red took them while storing gy; relu must be 0).  kc: scratch 3*C.
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
                hipStream_t stream) {
@@ -467,9 +468,11 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
     long nb = (rows + rpb - 1) / rpb;
     while (nb > (fuse ? 1024 : 2048)) { rpb *= 2; nb = (rows + rpb - 1) / rpb; }
     const bf16_t *g = (const bf16_t*)gy, *yy = (const bf16_t*)y, *xx = (const bf16_t*)x;
+    if (part_prezeroed == 2 && (!fuse || fold_rows != 8)) return PPV_ERR_BAD_SIZE;   // sums already taken by ppv_conv_gemm_red
     if (!part_prezeroed) (void)hipMemsetAsync(part, 0, sizeof(float) * 64 * C, stream);
     const int fold = fuse ? fold_rows - 1 : 31;
-    if (relu == 2) bn_bwd_reduce_kernel<2><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
+    if (part_prezeroed == 2) {}
+    else if (relu == 2) bn_bwd_reduce_kernel<2><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
     else if (relu) bn_bwd_reduce_kernel<1><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
     else bn_bwd_reduce_kernel<0><<<(unsigned)nb, 256, 0, stream>>>(g, yy, xx, coef, part, rows, C, (int)rpb, fold);
     bf16_t *ox = (bf16_t*)gx, *op = (bf16_t*)gpre;

@@ -224,10 +224,10 @@ class _TrunkFn(torch.autograd.Function):
             boff[0] += 64 * C
             return v
 
-        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False):
+        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None):
             trainable = rec.conv.weight.requires_grad
             gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad,
-                                         part=bn_part(xraw.shape[-1]))
+                                         part=bn_part(xraw.shape[-1]) if sums is None else sums, part_ready=sums is not None)
             sync = enc.grad_sync
             if trainable:
                 if side is not None:
@@ -259,12 +259,24 @@ class _TrunkFn(torch.autograd.Function):
             gc = co.adaptive_pool_bwd(g_cells.contiguous(), ctx.last_hw, relu_of=last)
             g = gc if g is None else g.add_(gc)
         taps = getattr(enc, "_debug_block_grads", None)      # tests: per-block (g_out, g_in) taps, last block first
-        for blk, sv in zip(reversed(enc._blocks), reversed(ctx.blocks)):
+        # The conv1 data-gradient launch that stores a block's input gradient also takes the sums bn3-backward of the PREVIOUS
+        # block needs from it (sum g, sum g * x3 per channel): that BN's reduce pass over g and x3 (2 tensors of the 4C-wide
+        # size) becomes one read of x3 in the store loop.  PPV_DGRAD_BNRED=0 keeps the separate pass.
+        fuse_red = _os.environ.get("PPV_DGRAD_BNRED", "1") != "0"
+        order = list(zip(reversed(enc._blocks), reversed(ctx.blocks)))
+        sums3 = None
+        for bi, (blk, sv) in enumerate(order):
             g_blk_out = g
             r1, r2, r3, rd = blk
             xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits = sv
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
-            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0)
+            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0, sums=sums3)
+            red = sums3 = None
+            if fuse_red and bi + 1 < len(order):
+                x3_prev = order[bi + 1][1][7]                # raw conv3 output of the block this gradient flows into
+                if x3_prev.shape[-1] % 128 == 0:
+                    sums3 = bn_part(x3_prev.shape[-1])
+                    red = (x3_prev, sums3)
             gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
             gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)       # mask recomputed from x2 (no residual): y2 not read
             gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
@@ -272,9 +284,9 @@ class _TrunkFn(torch.autograd.Function):
             if rd is not None:
                 gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)
-                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_bits=xin_bits)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_bits=xin_bits, red=red)
             else:
-                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=g, relu_bits=xin_bits)
+                g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=g, relu_bits=xin_bits, red=red)
             if taps is not None:
                 taps.append((g_blk_out, g))
         g_img = None

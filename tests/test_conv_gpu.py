@@ -65,3 +65,40 @@ def test_conv_dgrad(B, H, Cin, Cout, k, stride):
     assert torch.equal(got3, torch.where(keep, got2, torch.zeros_like(got2)))
     got4 = co.conv_dgrad(gd, wd, stride, pad, (H, H), relu_bits=bits)
     assert rel_err(got4.float(), want * keep.cpu()) < 2 ** -8 + 1e-3
+
+
+RED_CASES = [  # (B, H, Cout_of_conv = K of the data gradient, Cin = N columns): the three production tiles + a ragged M
+    (2, 16, 64, 256), (8, 32, 128, 512), (64, 32, 64, 256), (32, 32, 64, 256), (16, 16, 256, 1024), (3, 7, 128, 256),
+]
+
+
+@pytest.mark.parametrize("B,H,Cout,Cin", RED_CASES)
+@pytest.mark.parametrize("with_addend", [True, False])
+def test_dgrad_takes_bn_backward_sums(B, H, Cout, Cin, with_addend):
+    """ppv_conv_gemm_red: the stored tensor is bit-identical to the plain launch; its per-column sums (sum g, sum g * x)
+    equal those of the stored tensor; bn_bwd(part_ready) equals bn_bwd on the same gradient."""
+    import ppv_amd.convops as co
+    gen = torch.Generator().manual_seed(3)
+    g = torch.randn(B, H, H, Cout, generator=gen).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=gen) / Cout ** 0.5).cuda()
+    wd = co.weight_layout(w, 1)
+    add = torch.randn(B, H, H, Cin, generator=gen).bfloat16().cuda() if with_addend else None
+    act = torch.relu(torch.randn(B, H, H, Cin, generator=gen))
+    keep = (act > 0).cuda()
+    bits = (keep.reshape(-1, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    xraw = torch.randn(B, H, H, Cin, generator=gen).bfloat16().cuda()
+    plain = co.conv_dgrad(g, wd, 1, 0, (H, H), addend=add, relu_bits=bits)
+    part = torch.zeros(64 * Cin, device="cuda")
+    fused = co.conv_dgrad(g, wd, 1, 0, (H, H), addend=add, relu_bits=bits, red=(xraw, part))
+    assert torch.equal(plain, fused)
+    sums = part[:co.RED_ROWS * 2 * Cin].view(co.RED_ROWS, 2, Cin).sum(0)
+    gf, xf = plain.float().reshape(-1, Cin), xraw.float().reshape(-1, Cin)
+    assert rel_err(sums[0], gf.sum(0)) < 1e-4
+    assert rel_err(sums[1], (gf * xf).sum(0)) < 1e-4
+    assert part[co.RED_ROWS * 2 * Cin:].abs().max().item() == 0.0
+    coef = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.1,
+                        torch.randn(Cin, generator=gen) * 0.1, torch.rand(Cin, generator=gen) + 0.5]).cuda().contiguous()
+    want = co.bn_bwd(plain, None, xraw, coef, 0)
+    got = co.bn_bwd(fused, None, xraw, coef, 0, part=part, part_ready=True)
+    assert rel_err(got[0].float(), want[0].float()) < 2 ** -7
+    assert rel_err(got[2], want[2]) < 1e-4 and rel_err(got[3], want[3]) < 1e-4

@@ -92,9 +92,11 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
 /* data-gradient launch that also takes the sums the following BatchNorm backward needs (torch's batch_norm_backward reduce):
  * red_part [red_rows][2][N] f32, PRE-ZEROED, receives sum g and sum g * red_x per column, g = the tensor as stored (addend
  * added, rounded to bf16, masked), red_x [M][N] bf16 = the raw convolution output that BatchNorm normalised.  bf16 output,
- * N % 128 == 0; ppv_bn_bwd(..., part_prezeroed = 2) with red_rows = 8 then skips its own reduce pass over g and x. */
-int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const void* addend,
-                      const void* mask_bits, const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N,
+ * N % 128 == 0; ppv_bn_bwd(..., part_prezeroed = 2) with red_rows = 8 then skips its own reduce pass over g and x.
+ * red_coef (NULL, or that BatchNorm's coef rows [scale | shift] when a ReLU without residual follows it; not with addend):
+ * lanes with x * scale + shift <= 0 are stored as 0 and left out of the sums -> ppv_bn_bwd runs with relu = 0. */
+int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const float* red_coef,
+                      const void* addend, const void* mask_bits, const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N,
                       int R, int S, int a, int off, int div, int red_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */

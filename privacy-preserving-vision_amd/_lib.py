@@ -72,7 +72,7 @@ PROTOTYPES = {
     "ppv_fd_psf_workspace_bytes": (_Z, [_I]),
     "ppv_fd_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
     "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
-    "ppv_conv_gemm_red": (_I, [_P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P]),
+    "ppv_conv_gemm_red": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P]),
     "ppv_weight_layout_multi": (_I, [_P, _I, _I, _P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),

@@ -112,19 +112,21 @@ RED_ROWS = 8       # partial rows of the BN-backward sums (ppv_conv_gemm_red / p
 def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=None, red=None):
     """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend);
     relu_bits: (conv input > 0) bit mask from bn_act(..., want_bits=True) when that input is a ReLU output -> lanes whose bit
-    is clear get a zero gradient.  red = (x_raw, part): also take the BN-backward sums of the stored gradient against x_raw
-    (the raw conv output of the BatchNorm this gradient flows into) into the PRE-ZEROED f32 part [>= 16 * Cin];
-    bn_bwd(..., part=part, part_ready=True) then skips its reduce pass."""
+    is clear get a zero gradient.  red = (x_raw, part[, coef]): also take the BN-backward sums of the stored gradient against
+    x_raw (the raw conv output of the BatchNorm this gradient flows into) into the PRE-ZEROED f32 part [>= 16 * Cin];
+    bn_bwd(..., part=part, part_ready=True) then skips its reduce pass.  With coef (that BatchNorm's bn_finalize output, BN +
+    ReLU without residual) the ReLU mask is recomputed from x_raw and applied to the returned gradient: bn_bwd takes relu=0."""
     B, Ho, Wo, Cout = g.shape
     Cin, R, S, _ = wd.shape
     H, W = in_hw
     out = torch.empty((B, H, W, Cin), dtype=F32 if out_f32 else BF16, device=g.device)
     kind = "conv_gemm<128>" if Cin % 128 == 0 else "conv_gemm<64>"
     if red is not None:
-        xr, part = red
+        xr, part = red[0], red[1]
+        rcoef = red[2] if len(red) > 2 else None
         assert xr.shape == out.shape and xr.dtype == BF16 and not out_f32
         _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
-            L().ppv_conv_gemm_red(ptr(g), ptr(wd), ptr(out), ptr(part), ptr(xr), ptr(addend), ptr(relu_bits),
+            L().ppv_conv_gemm_red(ptr(g), ptr(wd), ptr(out), ptr(part), ptr(xr), ptr(rcoef), ptr(addend), ptr(relu_bits),
                                   ptr(zero_page(g.device)), B, Ho, Wo, Cout, H, W, Cin, R, S, 1, -(R - 1 - pad), stride,
                                   RED_ROWS, stream_ptr()), "ppv_conv_gemm_red"))
         return out

@@ -260,7 +260,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile(
 // RED (data-gradient launches that feed a BatchNorm backward): stat_part receives, instead of the forward statistics, the
 // BN-backward sums of the tile as it is STORED (after addend, rounding and ReLU mask): sum g and sum g * red_x per column,
 // red_x [M][N] bf16 = the raw conv output that BatchNorm normalised.  The separate reduce pass over g and x (2 T) becomes one
-// extra read of x (1 T) in this store loop.
+// extra read of x (1 T) in this store loop.  red_coef (BN scale / shift [2][N], may be null): the BatchNorm is followed by a ReLU
+// without residual, so its mask (x * scale + shift > 0, the forward kernel's expression) is recomputed here, applied to the
+// stored gradient and to the sums (single-pass store path only: launches without addend).
+__device__ __forceinline__ uint4 red_mask8(const uint4 gv, const uint4 xv, const float (&sc)[8], const float (&sh)[8]) {
+    unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
+    const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = __builtin_bit_cast(float, xw[i] << 16), x1 = __builtin_bit_cast(float, xw[i] & 0xffff0000u);
+        if (!(__builtin_fmaf(x0, sc[2 * i], sh[2 * i]) > 0.f)) gw[i] &= 0xffff0000u;
+        if (!(__builtin_fmaf(x1, sc[2 * i + 1], sh[2 * i + 1]) > 0.f)) gw[i] &= 0x0000ffffu;
+    }
+    return make_uint4(gw[0], gw[1], gw[2], gw[3]);
+}
 __device__ __forceinline__ void red_acc8(const uint4 gv, const uint4 xv, float (&ra)[8], float (&rb)[8]) {
     const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
@@ -277,7 +290,8 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
-                                                                   int tiles_n, int stat_rows, const bf16_t* __restrict__ red_x) {
+                                                                   int tiles_n, int stat_rows, const bf16_t* __restrict__ red_x,
+                                                                   const float* __restrict__ red_coef) {
     constexpr int NT = BM * 2, NWAVE = NT / 64;
     constexpr int ROWB = BK * 2, CH = BK / 8;                             // bytes / 16-byte chunks per staged row
     constexpr int RPI = 1024 / ROWB;                                       // rows per 1-KiB LDS-DMA wave-instruction
@@ -601,6 +615,16 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         atomicAdd(&stat_part[((long)(tile_m % stat_rows) * 2 + which) * g.N + n0 + col], v);
     }
     bf16_t* out = reinterpret_cast<bf16_t*>(Out);
+    float rsc[8], rsh[8];
+    if constexpr (RED) {
+        if (red_coef) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                rsc[k] = red_coef[n0 + (tid % CPR) * 8 + k];
+                rsh[k] = red_coef[g.N + n0 + (tid % CPR) * 8 + k];
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
         const int idx = it * NT + tid;
@@ -610,7 +634,11 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         {
             uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
             if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
-            if constexpr (RED) red_acc8(v, *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8), ra, rb);
+            if constexpr (RED) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8);
+                if (red_coef) v = red_mask8(v, xv, rsc, rsh);
+                red_acc8(v, xv, ra, rb);
+            }
             *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
         }
     }
@@ -691,14 +719,14 @@ int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
 // mask_bits [M * N / 8] bytes (may be null; bit k of byte i <-> element 8 i + k, as ppv_bn_act's pos_bits writes them): output
 // lanes whose bit is clear are zeroed (ReLU backward folded into the data-gradient store); zero_page: >= 128 zero bytes.  Cs % 64 == 0; N % 64 == 0 or N == 16.
 static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
-                          const void* zero_page, const void* red_x_,
+                          const void* zero_page, const void* red_x_, const float* red_coef,
                           int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
                           int out_f32, int stat_rows, hipStream_t stream) {
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
     if (stat_part && addend && !red_x_) return PPV_ERR_BAD_SIZE; // the epilogue parks the addend tile where the statistics are folded
-    if (red_x_ && (!stat_part || out_f32 || N % 128)) return PPV_ERR_BAD_SIZE;
+    if (red_x_ && (!stat_part || out_f32 || N % 128 || (red_coef && addend))) return PPV_ERR_BAD_SIZE;
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
@@ -731,9 +759,9 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
             attr_set = true;                                                                                            \
         }                                                                                                               \
         if (rx && !(REDOK_)) return PPV_ERR_BAD_SIZE;                                                                   \
-        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx);           \
-        else if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr); \
-        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr);         \
+        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef);           \
+        else if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr); \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr); \
     } while (0)
 #define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, false)
 #define PPV_LAUNCH_PIPE_R(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, true)
@@ -771,20 +799,22 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
                   const void* zero_page,
                   int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
                   int out_f32, int stat_rows, hipStream_t stream) {
-    return conv_gemm_impl(X, Wt, out, stat_part, addend, mask_bits, zero_page, nullptr, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div,
+    return conv_gemm_impl(X, Wt, out, stat_part, addend, mask_bits, zero_page, nullptr, nullptr, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div,
                           out_f32, stat_rows, stream);
 }
 
 // Data-gradient launch that also takes the BN-backward sums of the tensor it stores: red_part [red_rows][2][N] f32 (PRE-ZEROED)
 // receives sum g and sum g * red_x per column, g = the stored (addend-added, rounded, masked) output, red_x [M][N] bf16 = the raw
 // convolution output the following BatchNorm normalised.  ppv_bn_bwd(..., part_prezeroed = 2) then skips its reduce pass.
-// bf16 output, N % 128 == 0.
-int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const void* addend,
-                      const void* mask_bits, const void* zero_page,
+// red_coef (may be null; not together with addend): that BatchNorm's [scale | shift] rows (ppv_bn_finalize's coef) when it is
+// followed by a ReLU without residual: lanes with x * scale + shift <= 0 are stored as 0 and left out of the sums, so the
+// BatchNorm backward runs with relu = 0.  bf16 output, N % 128 == 0.
+int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const float* red_coef,
+                      const void* addend, const void* mask_bits, const void* zero_page,
                       int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
                       int red_rows, hipStream_t stream) {
     if (!red_part || !red_x) return PPV_ERR_NULL;
-    return conv_gemm_impl(X, Wt, out, red_part, addend, mask_bits, zero_page, red_x, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div, 0,
+    return conv_gemm_impl(X, Wt, out, red_part, addend, mask_bits, zero_page, red_x, red_coef, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div, 0,
                           red_rows, stream);
 }
 

@@ -261,8 +261,9 @@ class _TrunkFn(torch.autograd.Function):
         taps = getattr(enc, "_debug_block_grads", None)      # tests: per-block (g_out, g_in) taps, last block first
         # The conv1 data-gradient launch that stores a block's input gradient also takes the sums bn3-backward of the PREVIOUS
         # block needs from it (sum g, sum g * x3 per channel): that BN's reduce pass over g and x3 (2 tensors of the 4C-wide
-        # size) becomes one read of x3 in the store loop.  PPV_DGRAD_BNRED=0 keeps the separate pass.
-        fuse_red = _os.environ.get("PPV_DGRAD_BNRED", "1") != "0"
+        # size) becomes one read of x3 in the store loop.  PPV_DGRAD_BNRED=0 keeps the separate passes, 1 fuses bn3 only.
+        red_level = int(_os.environ.get("PPV_DGRAD_BNRED", "2"))
+        fuse_red, fuse_red12 = red_level >= 1, red_level >= 2
         order = list(zip(reversed(enc._blocks), reversed(ctx.blocks)))
         sums3 = None
         for bi, (blk, sv) in enumerate(order):
@@ -277,10 +278,22 @@ class _TrunkFn(torch.autograd.Function):
                 if x3_prev.shape[-1] % 128 == 0:
                     sums3 = bn_part(x3_prev.shape[-1])
                     red = (x3_prev, sums3)
-            gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
-            gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)       # mask recomputed from x2 (no residual): y2 not read
-            gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
-            gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2)
+            # bn2 / bn1 (BN + ReLU, no residual): the data-gradient launch recomputes the ReLU mask from the raw conv output,
+            # stores the masked gradient and takes the BN-backward sums; 64-column tensors (layer 1) keep the separate pass
+            if fuse_red12 and x2.shape[-1] % 128 == 0:
+                s2 = bn_part(x2.shape[-1])
+                gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid, red=(x2, s2, c2))
+                gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 0, sums=s2)
+            else:
+                gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
+                gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)   # mask recomputed from x2 (no residual): y2 not read
+            if fuse_red12 and x1.shape[-1] % 128 == 0:
+                s1 = bn_part(x1.shape[-1])
+                gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in, red=(x1, s1, c1))
+                gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 0, sums=s1)
+            else:
+                gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
+                gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2)
             if rd is not None:
                 gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)

@@ -102,3 +102,32 @@ def test_dgrad_takes_bn_backward_sums(B, H, Cout, Cin, with_addend):
     got = co.bn_bwd(fused, None, xraw, coef, 0, part=part, part_ready=True)
     assert rel_err(got[0].float(), want[0].float()) < 2 ** -7
     assert rel_err(got[2], want[2]) < 1e-4 and rel_err(got[3], want[3]) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,Cout,Cin,k,stride", [(2, 16, 256, 128, 1, 1), (32, 32, 256, 256, 1, 1), (64, 32, 128, 128, 3, 1),
+                                                    (4, 16, 128, 256, 3, 2), (3, 7, 512, 128, 1, 1)])
+def test_dgrad_relu_recompute_and_sums(B, H, Cout, Cin, k, stride):
+    """red=(x, part, coef): the stored gradient is the plain one with the BN + ReLU mask (x * scale + shift > 0) applied, the
+    sums are those of the stored tensor, and bn_bwd(relu=0, part_ready) equals bn_bwd(relu=2) on the unmasked gradient."""
+    import ppv_amd.convops as co
+    gen = torch.Generator().manual_seed(5)
+    Ho = (H + 2 * ((k - 1) // 2) - k) // stride + 1
+    g = torch.randn(B, Ho, Ho, Cout, generator=gen).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) / (Cout * k * k) ** 0.5).cuda()
+    wd = co.weight_layout(w, 1)
+    xraw = torch.randn(B, H, H, Cin, generator=gen).bfloat16().cuda()
+    coef = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3,
+                        torch.randn(Cin, generator=gen) * 0.1, torch.rand(Cin, generator=gen) + 0.5]).cuda().contiguous()
+    pad = (k - 1) // 2
+    plain = co.conv_dgrad(g, wd, stride, pad, (H, H))
+    part = torch.zeros(64 * Cin, device="cuda")
+    fused = co.conv_dgrad(g, wd, stride, pad, (H, H), red=(xraw, part, coef))
+    keep = torch.addcmul(coef[1], xraw.float(), coef[0]) > 0          # fma, as the kernels compute it
+    assert torch.equal(fused, torch.where(keep, plain, torch.zeros_like(plain)))
+    sums = part[:co.RED_ROWS * 2 * Cin].view(co.RED_ROWS, 2, Cin).sum(0)
+    gf, xf = fused.float().reshape(-1, Cin), xraw.float().reshape(-1, Cin)
+    assert rel_err(sums[0], gf.sum(0)) < 1e-4 and rel_err(sums[1], (gf * xf).sum(0)) < 1e-4
+    want = co.bn_bwd(plain, None, xraw, coef, 2)
+    got = co.bn_bwd(fused, None, xraw, coef, 0, part=part, part_ready=True)
+    assert rel_err(got[0].float(), want[0].float()) < 2 ** -7
+    assert rel_err(got[2], want[2]) < 1e-4 and rel_err(got[3], want[3]) < 1e-4

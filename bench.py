@@ -184,8 +184,9 @@ def roofline_of_dominant_kernel(step):
         try:
             pk = json.load(open(pmc))["per_kernel"]
             tot_b = tot_n = 0.0
-            for name, v in pk.items():          # every instantiation that serves the 128-column class
-                if "conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name:
+            for name, v in pk.items():          # every plain instantiation that serves the 128-column class (the
+                # "+bn_sums" instantiations <..., false, true> are their own class: they also carry a BN-backward reduction)
+                if ("conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name) and name.endswith("false, false>"):
                     tot_b += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches_2steps"]
                     tot_n += v["launches_2steps"]
             traffic = round(tot_b / tot_n) if tot_n else None
@@ -198,7 +199,7 @@ def roofline_of_dominant_kernel(step):
             pk = json.load(open(mu))["per_kernel"]
             num = den = 0.0
             for name, v in pk.items():
-                if "conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name:
+                if ("conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name) and name.endswith("false, false>"):
                     num += v["mfma_busy_frac"] * v["avg_duration_us"] * v["launches"]
                     den += v["avg_duration_us"] * v["launches"]
             mfma_busy = round(num / den, 4) if den else None

@@ -125,7 +125,8 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=
         xr, part = red[0], red[1]
         rcoef = red[2] if len(red) > 2 else None
         assert xr.shape == out.shape and xr.dtype == BF16 and not out_f32
-        _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
+        # its own class in the profile: these launches also do the BatchNorm-backward reduction (a different kernel instantiation)
+        _timed(kind + "+bn_sums", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
             L().ppv_conv_gemm_red(ptr(g), ptr(wd), ptr(out), ptr(part), ptr(xr), ptr(rcoef), ptr(addend), ptr(relu_bits),
                                   ptr(zero_page(g.device)), B, Ho, Wo, Cout, H, W, Cin, R, S, 1, -(R - 1 - pad), stride,
                                   RED_ROWS, stream_ptr()), "ppv_conv_gemm_red"))

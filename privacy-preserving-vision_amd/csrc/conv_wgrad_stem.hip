@@ -16,6 +16,7 @@
 //   16-column conv over 2x2 input super-pixels and run by conv_gemm (N = 16); this file only holds its weight
 //   re-layout and the final scatter to NCHW f32.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ppv_common.h"
 
 namespace ppv {
@@ -619,6 +620,118 @@ __global__ __launch_bounds__(256, CIN == 3 ? 2 : 1) void stem_conv_kernel(const 
     }
 }
 
+// Row-staged form of the 3-channel stem (W/2 % 128 == 0, the 256^2 workload): a tile is 128 consecutive output pixels of ONE
+// output row, so its 7 x 3 input rows are staged once with coalesced float4 loads (f32 -> bf16 LDS rows, 66 x 21 loads per tile
+// instead of 128 x 147 scalar gathers) and the A fragments are read straight from the rows: k-chunk (r, c) of output pixel wo is
+// the 8 consecutive columns 2 wo - 4 .. 2 wo + 3 (a 4-byte aligned 16-byte window; the weights' taps move up one slot, slot 0 = 0).
+// Row pitch 576 B = 144 dwords = 16 mod 64 banks: the four k-groups of a fragment read hit disjoint banks.
+__global__ __launch_bounds__(256, 2) void stem_conv_rows_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wst,
+                                                               bf16_t* __restrict__ out, float* __restrict__ stat_part,
+                                                               int B, int H, int W, int tiles, int stat_rows) {
+    constexpr int NCH = 21, NCHP = 24, KS = 6, LDA = NCHP * 16, ROWB = 576, LDO = 144;
+    extern __shared__ __attribute__((aligned(16))) char stem_smem[];
+    char* sIn = stem_smem;                                      // 21 rows x 576 B
+    char* sW = stem_smem + 12288;                               // 64 x 384 B
+    char* sO = stem_smem + 12288 + 64 * LDA;                    // 128 x 144 B
+    float (*sStat)[2][64] = reinterpret_cast<float (*)[2][64]>(stem_smem + 12288 + 64 * LDA + 128 * LDO);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Ho = H / 2, Wo = W / 2, tpr = Wo / 128;
+    for (int idx = tid; idx < 64 * NCHP; idx += 256) {
+        const int n = idx / NCHP, ch = idx % NCHP;
+        const uint4 u = *reinterpret_cast<const uint4*>(wst + (n * NCHP + ch) * 8);
+        const uint4 v = make_uint4(u.x << 16, (u.x >> 16) | (u.y << 16), (u.y >> 16) | (u.z << 16), (u.z >> 16) | (u.w << 16));
+        *reinterpret_cast<uint4*>(sW + n * LDA + ((ch ^ (n & 7)) * 16)) = v;
+    }
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    // the next tile's input rows are requested before this tile's MFMA phase and land in registers behind it
+    constexpr int NLD = (NCH * 66 + 255) / 256;
+    float4 pf[NLD];
+    auto fetch = [&](int tile) {
+        const int wseg = tile % tpr, bh = tile / tpr;
+        const int b = bh / Ho, ho = bh % Ho;
+        const int wi0 = wseg * 256 - 4;                         // input column of staged element 0
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = k * 256 + tid;
+            const int rc = idx / 66, j = idx % 66;
+            const int r = rc / 3, c = rc % 3;
+            const int hi = 2 * ho - 3 + r, wi = wi0 + 4 * j;
+            pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NCH * 66 && hi >= 0 && hi < H && wi >= 0 && wi < W)
+                pf[k] = *reinterpret_cast<const float4*>(img + (((long)b * 3 + c) * H + hi) * W + wi);
+        }
+    };
+    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = k * 256 + tid;
+            const int rc = idx / 66, j = idx % 66;
+            const unsigned lo = (unsigned)f2bfw(pf[k].x) | ((unsigned)f2bfw(pf[k].y) << 16);
+            const unsigned hi2 = (unsigned)f2bfw(pf[k].z) | ((unsigned)f2bfw(pf[k].w) << 16);
+            if (idx < NCH * 66) *reinterpret_cast<uint2*>(sIn + rc * ROWB + j * 8) = make_uint2(lo, hi2);
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi][0] = acc[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[4], bfr[2];
+            const int chunk = ks * 4 + fq;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                uint4 a = make_uint4(0, 0, 0, 0);
+                if (chunk < NCH) {
+                    const unsigned* pa = reinterpret_cast<const unsigned*>(sIn + chunk * ROWB + (wm * 64 + mi * 16 + fr) * 4);
+                    a = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+                }
+                af[mi] = __builtin_bit_cast(bf16x8, a);
+            }
+            const int wchunk = (chunk ^ (fr & 7)) * 16;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(sW + (wn * 32 + ni * 16 + fr) * LDA + wchunk);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            float s1 = 0.f, s2 = 0.f;
+            const int col = wn * 32 + ni * 16 + fr;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16_t h = f2bfw(acc[mi][ni][j]);
+                    const float v = bf2fw(h);
+                    s1 += v; s2 += v * v;
+                    *reinterpret_cast<bf16_t*>(sO + (wm * 64 + mi * 16 + fq * 4 + j) * LDO + col * 2) = h;
+                }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (fq == 0) { sStat[wm][0][col] = s1; sStat[wm][1][col] = s2; }
+        }
+        __syncthreads();                                        // sO / sStat complete; every wave is done reading sIn
+        if (stat_part && tid < 128) {
+            const int which = tid >> 6, col = tid & 63;
+            atomicAdd(&stat_part[((long)(tile % stat_rows) * 2 + which) * 64 + col], sStat[0][which][col] + sStat[1][which][col]);
+        }
+        const long m0 = (long)tile * 128;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx >> 3, ch = idx & 7;
+            *reinterpret_cast<uint4*>(out + (m0 + row) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+        }
+        // no barrier here: the next tile's sIn writes only race with reads that finished before the barrier above, and its
+        // sO / sStat writes come after its own staging barrier, which every thread reaches after this store loop
+    }
+}
+
 // ============================================================================= stem data gradient helpers
 // torch [64][3][7][7] f32 -> conv_gemm rows [16][4][4][64] bf16: row (ph*2+pw)*3 + c, tap (dy,dx), channel ch:
 //   W[ch][c][ph + 5 - 2 dy][pw + 5 - 2 dx]  (0 outside 0..6; rows 12..15 zero)
@@ -805,6 +918,15 @@ int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part
     constexpr int lds3 = 192 * 24 * 16 + 1024;
     static bool attr3 = false;
     if (!attr3) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3); attr3 = true; }
+    static const int rows_form = getenv("PPV_STEM_ROWS") ? atoi(getenv("PPV_STEM_ROWS")) : 1;
+    if (rows_form && (W / 2) % 128 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {                      // one output row segment per tile: staged input rows, no gathers
+        constexpr int ldsr = 12288 + 64 * 384 + 128 * 144 + 1024;
+        static bool attrr = false;
+        if (!attrr) { (void)hipFuncSetAttribute((const void*)stem_conv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsr); attrr = true; }
+        stem_conv_rows_kernel<<<tiles < 512 ? tiles : 512, 256, ldsr, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles,
+                                                                            stat_rows < 1 ? 1 : stat_rows);
+        return ppv_last_error();
+    }
     stem_conv_kernel<3><<<grid, 256, lds3, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles, stat_rows < 1 ? 1 : stat_rows);
     return ppv_last_error();
 }

@@ -55,6 +55,23 @@ def test_stem_forward_and_data_gradient():
     assert rel_err(gd, x.grad) < 1e-3
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 256), (1, 32, 512)])
+def test_stem_forward_row_staged(B, H, W):
+    """W/2 % 128 == 0 takes the row-staged kernel (one output-row segment per tile): same result as the reference conv on the
+    bf16-rounded operands, statistics included; image borders and the segment seam (W = 512) are inside the case."""
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(1)
+    img = torch.rand(B, 3, H, W, generator=g0)
+    w = r16(torch.randn(64, 3, 7, 7, generator=g0) * 0.1)
+    y = F.conv2d(r16(img), w, stride=2, padding=3)
+    part = torch.zeros(co.stat_tiles(B * (H // 2) * (W // 2)), 2, 64, device="cuda")
+    got = co.stem_conv(img.cuda(), co.stem_weight_layout(w.cuda(), 0), part)
+    assert rel_err(got.float(), nhwc(y)) < BF
+    assert (got.float().cpu() - nhwc(y)).abs().max().item() < 0.05
+    gf = got.float().reshape(-1, 64)
+    assert rel_err(part.sum(0)[0], gf.sum(0)) < 1e-4 and rel_err(part.sum(0)[1], (gf * gf).sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("C,res_mode", [(64, 0), (256, 1), (512, 2), (2048, 1)])
 def test_batchnorm_train_forward_backward(C, res_mode):
     import ppv_amd.convops as co

@@ -113,6 +113,10 @@ int ppv_stem_weight_layout(const float* w, void* out, int mode, ppv_stream_t str
 int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part, int stat_rows, int B, int H,
                   int W, ppv_stream_t stream);
 int ppv_stem_dgrad_scatter(const float* t, float* g, int B, int Ho, int Wo, ppv_stream_t stream);
+/* the whole stem data gradient in one launch (Wo % 128 == 0): g_raw [B,Ho,Wo,64] bf16 -> g_img [B,3,2Ho,2Wo] f32 NCHW;
+ * zero_page: >= 128 zero bytes (source of the out-of-image taps) */
+int ppv_stem_dgrad(const void* g_raw, const void* wsd, float* g_img, const void* zero_page, int B, int Ho, int Wo,
+                   ppv_stream_t stream);
 /* train-mode BatchNorm2d (+ residual, + ReLU), forward and backward */
 int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, int C, ppv_stream_t stream);

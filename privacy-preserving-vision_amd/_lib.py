@@ -83,6 +83,7 @@ PROTOTYPES = {
     "ppv_stem_weight_layout": (_I, [_P, _P, _I, _P]),
     "ppv_stem_conv": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_stem_dgrad_scatter": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ppv_stem_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ppv_bn_finalize": (_I, [_P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P]),
     "ppv_bn_bwd_blocks": (_I, [_L, _I]),

@@ -176,6 +176,10 @@ def stem_conv(img, wst, stat_part=None):
 def stem_dgrad(g_raw, wsd):
     """g_raw [B,Ho,Wo,64] bf16 -> d/d(img) [B,3,2Ho,2Wo] f32 NCHW."""
     B, Ho, Wo, _ = g_raw.shape
+    if Wo % 128 == 0:                      # row-staged single launch (the 256^2 workload)
+        out = torch.empty((B, 3, 2 * Ho, 2 * Wo), dtype=F32, device=g_raw.device)
+        check(L().ppv_stem_dgrad(ptr(g_raw), ptr(wsd), ptr(out), ptr(zero_page(g_raw.device)), B, Ho, Wo, stream_ptr()), "ppv_stem_dgrad")
+        return out
     tmp = torch.empty((B * Ho * Wo, 16), dtype=F32, device=g_raw.device)
     check(L().ppv_conv_gemm(ptr(g_raw), ptr(wsd), ptr(tmp), None, None, None, ptr(zero_page(g_raw.device)), B, Ho, Wo, 64,
                             Ho, Wo, 16, 4, 4, 1, -1, 1, 1, 0, stream_ptr()), "ppv_conv_gemm(stem dgrad)")

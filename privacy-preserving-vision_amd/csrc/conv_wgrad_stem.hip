@@ -661,8 +661,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv_rows_kernel(const float* __r
                 pf[k] = *reinterpret_cast<const float4*>(img + (((long)b * 3 + c) * H + hi) * W + wi);
         }
     };
-    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // XCD-aware tile order: workgroup i runs on XCD i & 7; each XCD walks its own contiguous eighth of the tiles, so the
+    // output rows that share input rows are neighbours in ONE L2 instead of being fetched by eight
+    const int nx = gridDim.x >> 3, per = (tiles + 7) >> 3;
+    const int tile0 = (blockIdx.x & 7) * per + (blockIdx.x >> 3), tile_end = min(tiles, ((int)(blockIdx.x & 7) + 1) * per);
+    if (tile0 < tile_end) fetch(tile0);
+    for (int tile = tile0; tile < tile_end; tile += nx) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int idx = k * 256 + tid;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_rows_kernel(const float* __r
             if (idx < NCH * 66) *reinterpret_cast<uint2*>(sIn + rc * ROWB + j * 8) = make_uint2(lo, hi2);
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        if (tile + nx < tile_end) fetch(tile + nx);
         f32x4 acc[4][2];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[mi][0] = acc[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -758,6 +762,86 @@ __global__ __launch_bounds__(256) void stem_dgrad_scatter_kernel(const float* __
     const int wv = (int)(i % W), hv = (int)((i / W) % H), c = (int)((i / ((long)W * H)) % 3), b = (int)(i / ((long)W * H * 3));
     const int y = hv >> 1, ph = hv & 1, x = wv >> 1, pw = wv & 1;
     g[i] = t[(((long)b * Ho + y) * Wo + x) * 16 + (ph * 2 + pw) * 3 + c];
+}
+
+// Row-staged stem data gradient (Wo % 128 == 0): d/d(img) of the 7x7/2 stem as the same 4x4-tap GEMM on 2x2 super-pixels
+// (M = B*Ho*Wo, N = 16 of which 12 used, K = 16 taps x 64 ch), but a tile is 128 super-pixels of ONE row: the four gradient rows
+// y-1..y+2 it touches are staged once by LDS-DMA (4 x 136 pixels x 128 B, double-buffered: the next tile lands while this one
+// multiplies; 16-byte chunks swizzled c ^ (p & 7) on the SOURCE address so that the four 16-lane groups of a ds_read_b128 each
+// hit 16 disjoint bank slots) instead of 16 gathered taps per pixel (3.8x less L2 -> LDS traffic), the weights' 32 B fragments
+// stay in registers for the whole launch, and the result is written straight in NCHW f32 (six contiguous 1-KB row segments per
+// tile) -- no [M][16] temporary, no scatter launch.  One 8-wave workgroup per CU (2 x 68 KB of staging).
+__global__ __launch_bounds__(512, 1) void stem_dgrad_rows_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ wsd,
+                                                                float* __restrict__ gimg, const bf16_t* __restrict__ zero_page,
+                                                                int B, int Ho, int Wo, int tiles) {
+    constexpr int NP = 136, BUF = 4 * NP * 128, NGRP = 4 * NP / 8, NDMA = (NGRP + 7) / 8;   // 68 one-KiB wave-instructions per tile
+    extern __shared__ __attribute__((aligned(16))) char stem_smem[];
+    float* sOut = reinterpret_cast<float*>(stem_smem + 2 * BUF);           // [6][256] f32
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tpr = Wo / 128, H = 2 * Ho, W = 2 * Wo;
+    bf16x8 wreg[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(wsd + fr * 1024 + ks * 32 + fq * 8);
+    // lane -> (pixel within the 8-pixel group, destination chunk slot); the source chunk is slot ^ (pixel & 7)
+    const int lp = lane >> 3, lc = lane & 7;
+    auto stage = [&](int tile, int buf) {
+        const int xseg = tile % tpr, by = tile / tpr;
+        const int b = by / Ho, y = by % Ho;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int grp = k * 8 + wave;                       // 8-pixel group 0..67 = (dy, 17 groups per row)
+            if (grp >= NGRP) break;                             // wave-uniform
+            const int dy = grp / 17, pix = (grp % 17) * 8 + lp;
+            const int yy = y - 1 + dy, xx = xseg * 128 - 1 + pix;
+            const bf16_t* src = zero_page;
+            if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) src = gx + (((long)b * Ho + yy) * Wo + xx) * 64 + (lc ^ (pix & 7)) * 8;
+            GLDS16W(src, stem_smem + buf * BUF + grp * 1024);
+        }
+    };
+    const int nx = gridDim.x >> 3, per = (tiles + 7) >> 3;      // XCD-aware tile order, as stem_conv_rows_kernel
+    const int tile0 = (blockIdx.x & 7) * per + (blockIdx.x >> 3), tile_end = min(tiles, ((int)(blockIdx.x & 7) + 1) * per);
+    if (tile0 < tile_end) stage(tile0, 0);
+    int cur = 0;
+    for (int tile = tile0; tile < tile_end; tile += nx, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // this tile has landed; the other buffer and sOut are free
+        if (tile + nx < tile_end) stage(tile + nx, cur ^ 1);
+        const char* sA = stem_smem + cur * BUF;
+        // eight waves, 16 super-pixels each (two waves per SIMD cover each other's LDS latency); fragment reads in batches of 8
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            bf16x8 af[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ks = kb * 8 + q;
+                const int tap = ks >> 1, dy = tap >> 2, dx = tap & 3, c8 = (ks & 1) * 4 + fq;
+                const int pix = wave * 16 + fr + dx;
+                af[q] = *reinterpret_cast<const bf16x8*>(sA + ((dy * NP + pix) * 8 + (c8 ^ (pix & 7))) * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q], wreg[kb * 8 + q], acc, 0, 0, 0);
+            // pin the order (the machine scheduler otherwise sinks every read to just before its MFMA: read, wait, multiply)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+        // column n = (ph*2 + pw)*3 + c of super-pixel m -> image row segment (c, ph), column 2 m + pw
+        if (fr < 12) {
+            const int c = fr % 3, pw = (fr / 3) & 1, ph = fr / 6;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sOut[(c * 2 + ph) * 256 + 2 * (wave * 16 + fq * 4 + j) + pw] = acc[j];
+        }
+        __syncthreads();
+        const int xseg = tile % tpr, by = tile / tpr;
+        const int b = by / Ho, y = by % Ho;
+        for (int idx = tid; idx < 6 * 64; idx += 512) {
+            const int seg = idx >> 6, q = idx & 63;
+            const int c = seg >> 1, ph = seg & 1;
+            *reinterpret_cast<float4*>(gimg + (((long)b * 3 + c) * H + 2 * y + ph) * W + xseg * 256 + q * 4) =
+                *reinterpret_cast<const float4*>(sOut + seg * 256 + q * 4);
+        }
+    }
 }
 
 }  // namespace ppv
@@ -923,7 +1007,7 @@ int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part
         constexpr int ldsr = 12288 + 64 * 384 + 128 * 144 + 1024;
         static bool attrr = false;
         if (!attrr) { (void)hipFuncSetAttribute((const void*)stem_conv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsr); attrr = true; }
-        stem_conv_rows_kernel<<<tiles < 512 ? tiles : 512, 256, ldsr, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles,
+        stem_conv_rows_kernel<<<tiles < 512 ? (tiles + 7) / 8 * 8 : 512, 256, ldsr, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles,
                                                                             stat_rows < 1 ? 1 : stat_rows);
         return ppv_last_error();
     }
@@ -943,6 +1027,21 @@ int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, i
     static bool attr6 = false;
     if (!attr6) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6); attr6 = true; }
     stem_conv_kernel<6><<<grid, 256, lds6, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, nullptr, B, H, W, tiles, 1);
+    return ppv_last_error();
+}
+
+// Whole stem data gradient in one launch (row-staged form): g_raw [B,Ho,Wo,64] bf16, wsd from ppv_stem_weight_layout(mode 1),
+// g_img [B,3,2Ho,2Wo] f32 NCHW, zero_page >= 128 zero bytes.  Wo % 128 == 0; other widths use ppv_conv_gemm (N = 16) + ppv_stem_dgrad_scatter.
+int ppv_stem_dgrad(const void* g_raw, const void* wsd, float* g_img, const void* zero_page, int B, int Ho, int Wo,
+                   hipStream_t stream) {
+    if (!g_raw || !wsd || !g_img || !zero_page) return PPV_ERR_NULL;
+    if (Wo % 128) return PPV_ERR_BAD_SIZE;
+    constexpr int lds = 2 * 4 * 136 * 128 + 6 * 256 * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)stem_dgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    const int tiles = B * Ho * (Wo / 128);
+    stem_dgrad_rows_kernel<<<tiles < 256 ? (tiles + 7) / 8 * 8 : 256, 512, lds, stream>>>((const bf16_t*)g_raw, (const bf16_t*)wsd, g_img,
+                                                                                  (const bf16_t*)zero_page, B, Ho, Wo, tiles);
     return ppv_last_error();
 }
 

@@ -70,6 +70,14 @@ def test_stem_forward_row_staged(B, H, W):
     assert (got.float().cpu() - nhwc(y)).abs().max().item() < 0.05
     gf = got.float().reshape(-1, 64)
     assert rel_err(part.sum(0)[0], gf.sum(0)) < 1e-4 and rel_err(part.sum(0)[1], (gf * gf).sum(0)) < 1e-4
+    # data gradient: the row-staged single launch against autograd of the same conv
+    x = r16(img).requires_grad_(True)
+    y2 = F.conv2d(x, w, stride=2, padding=3)
+    g = r16(torch.randn(y2.shape, generator=g0))
+    y2.backward(g)
+    gd = co.stem_dgrad(nhwc(g).cuda().bfloat16(), co.stem_weight_layout(w.cuda(), 1))
+    assert rel_err(gd, x.grad) < 1e-3
+    assert (gd.cpu() - x.grad).abs().max().item() < 1e-2 * x.grad.abs().max().item()
 
 
 @pytest.mark.parametrize("C,res_mode", [(64, 0), (256, 1), (512, 2), (2048, 1)])

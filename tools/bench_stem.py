@@ -18,3 +18,15 @@ for i in range(n):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
 print(f"stem conv B={B} {H}x{H}: {us:.1f} us  ({(B * 3 * H * H * 4 + B * H * H // 4 * 64 * 2) / us / 1e6:.2f} TB/s of compulsory traffic)")
+
+gs = [torch.randn(B, H // 2, H // 2, 64, device="cuda").bfloat16() for _ in range(3)]
+wd = co.stem_weight_layout(torch.randn(64, 3, 7, 7, device="cuda") * 0.1, 1)
+for i in range(3):
+    co.stem_dgrad(gs[i], wd)
+torch.cuda.synchronize()
+e0.record()
+for i in range(n):
+    co.stem_dgrad(gs[i % 3], wd)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / n * 1e3
+print(f"stem dgrad: {us:.1f} us  ({(B * 3 * H * H * 4 + B * H * H // 4 * 64 * 2) / us / 1e6:.2f} TB/s of compulsory traffic)")

@@ -109,6 +109,11 @@ def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
 RED_ROWS = 8       # partial rows of the BN-backward sums (ppv_conv_gemm_red / ppv_bn_bwd's fused apply)
 
 
+def red_supported(rows, C):
+    """Whether conv_dgrad(..., red=...) exists for a gradient of `rows` pixels x C channels (the tiles that carry the sums)."""
+    return C % 128 == 0 or (C % 64 == 0 and rows >= 128 * 1024)
+
+
 def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=None, red=None):
     """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend);
     relu_bits: (conv input > 0) bit mask from bn_act(..., want_bits=True) when that input is a ReLU output -> lanes whose bit

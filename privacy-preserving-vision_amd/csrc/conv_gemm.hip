@@ -441,20 +441,21 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     char* sO = smem;
     float* sStat = reinterpret_cast<float*>(smem + BM * LDO);
     constexpr int CPR = BN / 8;
-    static_assert(!RED || (CPR == 16 && !OUT_F32), "RED: 128-column bf16 tiles");
+    static_assert(!RED || ((CPR == 16 || CPR == 8) && NT % CPR == 0 && !OUT_F32), "RED: 64- or 128-column bf16 tiles");
     float ra[8], rb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) ra[k] = rb[k] = 0.f;
-    // every thread's chunk column ch = tid % 16 is the same in all its store iterations: fold the four rows of a wave by
+    // every thread's chunk column ch = tid % CPR is the same in all its store iterations: fold the rows of a wave by
     // shuffles, the waves through LDS (the staging area is free once the caller has passed a barrier), then one atomic per column
     auto red_finish = [&]() {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+            if (CPR == 8) { ra[k] += __shfl_xor(ra[k], 8, 64); rb[k] += __shfl_xor(rb[k], 8, 64); }
             ra[k] += __shfl_xor(ra[k], 16, 64); rb[k] += __shfl_xor(rb[k], 16, 64);
             ra[k] += __shfl_xor(ra[k], 32, 64); rb[k] += __shfl_xor(rb[k], 32, 64);
         }
         float* sRed = reinterpret_cast<float*>(smem);
-        if (lane < 16) {
+        if (lane < CPR) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 sRed[(wave * 2 + 0) * BN + lane * 8 + k] = ra[k];
@@ -726,7 +727,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
     if (stat_part && addend && !red_x_) return PPV_ERR_BAD_SIZE; // the epilogue parks the addend tile where the statistics are folded
-    if (red_x_ && (!stat_part || out_f32 || N % 128 || (red_coef && addend))) return PPV_ERR_BAD_SIZE;
+    if (red_x_ && (!stat_part || out_f32 || N % 64 || (red_coef && addend))) return PPV_ERR_BAD_SIZE;
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
@@ -770,7 +771,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     const int CUS = 256;
     int v = g_conv_variant;
     if (N != 16 && N % 128 && (v == 0 || v >= 3) && g.M >= 128 * 1024) {
-        PPV_LAUNCH_PIPE(128, 64, 3, 32, 4);     // 64-column layers (layer1): HBM-bound, four small-ring workgroups per CU
+        PPV_LAUNCH_PIPE_R(128, 64, 3, 32, 4);   // 64-column layers (layer1): HBM-bound, four small-ring workgroups per CU
         return ppv_last_error();
     }
     if (N == 16 || N % 128) v = 1;
@@ -808,7 +809,7 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
 // convolution output the following BatchNorm normalised.  ppv_bn_bwd(..., part_prezeroed = 2) then skips its reduce pass.
 // red_coef (may be null; not together with addend): that BatchNorm's [scale | shift] rows (ppv_bn_finalize's coef) when it is
 // followed by a ReLU without residual: lanes with x * scale + shift <= 0 are stored as 0 and left out of the sums, so the
-// BatchNorm backward runs with relu = 0.  bf16 output, N % 128 == 0.
+// BatchNorm backward runs with relu = 0.  bf16 output; N % 128 == 0, or N % 64 == 0 with M >= 128 Ki rows (the 128 x 64 tile).
 int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const float* red_coef,
                       const void* addend, const void* mask_bits, const void* zero_page,
                       int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,

@@ -275,19 +275,19 @@ class _TrunkFn(torch.autograd.Function):
             red = sums3 = None
             if fuse_red and bi + 1 < len(order):
                 x3_prev = order[bi + 1][1][7]                # raw conv3 output of the block this gradient flows into
-                if x3_prev.shape[-1] % 128 == 0:
+                if co.red_supported(x3_prev.numel() // x3_prev.shape[-1], x3_prev.shape[-1]):
                     sums3 = bn_part(x3_prev.shape[-1])
                     red = (x3_prev, sums3)
             # bn2 / bn1 (BN + ReLU, no residual): the data-gradient launch recomputes the ReLU mask from the raw conv output,
-            # stores the masked gradient and takes the BN-backward sums; 64-column tensors (layer 1) keep the separate pass
-            if fuse_red12 and x2.shape[-1] % 128 == 0:
+            # stores the masked gradient and takes the BN-backward sums (64-column tensors only at >= 128 Ki pixels: the 128 x 64 tile)
+            if fuse_red12 and co.red_supported(x2.numel() // x2.shape[-1], x2.shape[-1]):
                 s2 = bn_part(x2.shape[-1])
                 gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid, red=(x2, s2, c2))
                 gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 0, sums=s2)
             else:
                 gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
                 gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)   # mask recomputed from x2 (no residual): y2 not read
-            if fuse_red12 and x1.shape[-1] % 128 == 0:
+            if fuse_red12 and co.red_supported(x1.numel() // x1.shape[-1], x1.shape[-1]):
                 s1 = bn_part(x1.shape[-1])
                 gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in, red=(x1, s1, c1))
                 gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 0, sums=s1)

@@ -105,7 +105,8 @@ def test_dgrad_takes_bn_backward_sums(B, H, Cout, Cin, with_addend):
 
 
 @pytest.mark.parametrize("B,H,Cout,Cin,k,stride", [(2, 16, 256, 128, 1, 1), (32, 32, 256, 256, 1, 1), (64, 32, 128, 128, 3, 1),
-                                                    (4, 16, 128, 256, 3, 2), (3, 7, 512, 128, 1, 1)])
+                                                    (4, 16, 128, 256, 3, 2), (3, 7, 512, 128, 1, 1), (32, 64, 256, 64, 1, 1),
+                                                    (33, 64, 64, 64, 3, 1)])
 def test_dgrad_relu_recompute_and_sums(B, H, Cout, Cin, k, stride):
     """red=(x, part, coef): the stored gradient is the plain one with the BN + ReLU mask (x * scale + shift > 0) applied, the
     sums are those of the stored tensor, and bn_bwd(relu=0, part_ready) equals bn_bwd(relu=2) on the unmasked gradient."""

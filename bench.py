@@ -125,6 +125,8 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
             torch._foreach_clamp_min_(grads, -5.0)
             torch._foreach_clamp_max_(grads, 5.0)
             opt_enc.step()
+            if opt_stream is not None and hasattr(encoder, "prefetch_weight_layouts") and os.environ.get("PPV_WL_PREFETCH", "1") != "0":
+                encoder.prefetch_weight_layouts()      # bf16 GEMM layouts of the updated weights, beside the next camera forward
             if decoder is not None:
                 dgr = [p.grad for p in dec_params]
                 torch._foreach_clamp_min_(dgr, -5.0)

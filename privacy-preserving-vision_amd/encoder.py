@@ -122,7 +122,10 @@ class _TrunkFn(torch.autograd.Function):
 
         enc._step_token += 1
         tok = enc._step_token
-        enc._refresh_weight_layouts()
+        if getattr(enc, "_wl_prefetched", False):    # Encoder.prefetch_weight_layouts() already converted the updated weights
+            object.__setattr__(enc, "_wl_prefetched", False)
+        else:
+            enc._refresh_weight_layouts()
         # one zeroed f32 pool for every conv's BN partial sums of this step ([rows<=32][2][C] each)
         pool = torch.zeros(enc._stat_pool_elems(B, H, W), dtype=torch.float32, device=dev) if train else None
         pool_off = [0]
@@ -340,7 +343,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wgrad_stream", "grad_sync", "_debug_block_grads"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads"):
             st.pop(k, None)
         return st
 
@@ -392,6 +395,14 @@ class Encoder(nn.Module):
                 r.wl, r.wl_idx = wl, i
             object.__setattr__(self, "_wl", wl)
         wl.refresh()
+
+    def prefetch_weight_layouts(self):
+        """Optional: convert the trainable conv weights to their bf16 GEMM layouts NOW, on the current stream, for the next
+        forward (which otherwise does it first thing).  Call it right after ``optimizer.step()`` -- e.g. on the stream the
+        optimizer ran on, beside other work -- and make the stream that runs the forward wait for this one.  Weights changed
+        after this call and before the next forward are not seen by that forward."""
+        self._refresh_weight_layouts()
+        object.__setattr__(self, "_wl_prefetched", True)
 
     def _param_list(self):
         return list(self.resnet.parameters())

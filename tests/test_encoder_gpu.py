@@ -137,6 +137,27 @@ def test_shallow_trunk_end_to_end():
             assert rel_err(b, bo[n]) < 2e-2, n
 
 
+def test_prefetched_weight_layouts_match_the_forwards_own():
+    """Encoder.prefetch_weight_layouts() (bench.py calls it on the optimizer's stream) converts the weights as they are at the
+    call; the next forward uses those layouts and equals a forward that converts them itself."""
+    enc, _ = _pair((1, 1, 1, 1))
+    enc.train()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(7)).cuda()
+    with torch.no_grad():
+        enc(img)                                         # builds the shared layouts
+        for p in enc.parameters():
+            if p.requires_grad and p.dim() == 4:
+                p.mul_(1.25)                             # an "optimizer step"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            enc.prefetch_weight_layouts()
+        torch.cuda.current_stream().wait_stream(side)
+        a = enc(img)
+        b = enc(img)                                     # no prefetch pending: converts on its own
+    assert torch.equal(a, b)
+
+
 def test_eval_mode_uses_running_statistics():
     enc, ref = _pair((1, 1, 1, 1))
     enc.eval(); ref.eval()

@@ -363,8 +363,17 @@ __global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const bf16_t* __
         }
     const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
     TO* o = y + i * 8;
+    if constexpr (sizeof(TO) == 4) {
+        // 1.36 GB at B = 128: streamed out once, far larger than the Infinity Cache -> non-temporal 16-byte stores
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const f32x4_ lo = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+        const f32x4_ hi = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+        __builtin_nontemporal_store(lo, reinterpret_cast<f32x4_*>(o));
+        __builtin_nontemporal_store(hi, reinterpret_cast<f32x4_*>(o) + 1);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (TO)(acc[k] * inv);
+        for (int k = 0; k < 8; ++k) o[k] = (TO)(acc[k] * inv);
+    }
 }
 
 template <typename TG>

@@ -28,7 +28,11 @@ for cin, cout, k, h, wgt in SH:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         tot[v] += ms * wgt
-        line += f"  v{v} {ms*1e3:6.1f}us {fl/ms/1e9:4.0f}TF"
+        # bytes a launch stages through LDS (A re-read per column tile, W per row tile) for the tile the auto rule picks, and HBM-compulsory bytes
+        M_, bm, bn = B * h * h, (128 if v == 2 else 256), (64 if cout % 128 else 128)
+        staged = 2.0 * M_ * cout * cin * k * k * (1.0 / bn + 1.0 / bm)
+        hbm = 2.0 * (M_ * cin + M_ * cout + cout * cin * k * k)
+        line += f"  v{v} {ms*1e3:6.1f}us {fl/ms/1e9:4.0f}TF staged {staged/ms/1e9:5.2f}TB/s hbm {hbm/ms/1e9:5.2f}TB/s"
     print(line)
 co.L().ppv_conv_set_variant(0)
 print("weighted ms/step:", {v: round(t, 3) for v, t in tot.items()})

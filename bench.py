@@ -70,6 +70,8 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     opt_cam = torch.optim.Adam(cam_params, lr=5e-7)
     rank = dist.get_rank() if dist.is_initialized() else 0
     imgs = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(device)
+    # PPV_BENCH_H2D=1: the PCIe-inclusive variant (never `value`): the batch starts in pinned host memory every step
+    imgs_host = imgs.cpu().pin_memory() if os.environ.get("PPV_BENCH_H2D") else None
     if decoder is not None:                                                       # BASELINE.json config 3 / 5
         from torch.nn.utils.rnn import pack_padded_sequence
         dec_params = [p for p in decoder.parameters() if p.requires_grad]
@@ -81,6 +83,9 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     opt_stream = torch.cuda.Stream(device=device) if os.environ.get("PPV_OPT_OVERLAP", "1") != "0" else None
 
     def step():
+        nonlocal imgs
+        if imgs_host is not None:
+            imgs = imgs_host.to(device, non_blocking=True)
         sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
         if opt_stream is not None:             # the encoder's (and decoder's) Adam of the previous step ran beside the camera forward
             torch.cuda.current_stream().wait_stream(opt_stream)

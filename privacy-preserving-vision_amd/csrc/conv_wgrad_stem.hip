@@ -852,12 +852,19 @@ static int g_wgrad_variant = 0;
 
 extern "C" {
 
+// workgroups a weight-gradient launch aims for (split-M slices x tiles); PPV_WGRAD_WGS overrides (A/B: fewer slices = fewer
+// slab bytes and more CUs left to the data-gradient chain the launches overlap with, but longer launches)
+static int wgrad_target_wgs() {
+    static const int t = getenv("PPV_WGRAD_WGS") ? atoi(getenv("PPV_WGRAD_WGS")) : 384;   // 384: -0.6 % step time against 256 under the overlap, 448+ and 192- lose
+    return t < 16 ? 16 : t;
+}
+
 static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN, long* splits, int* sps) {
     const long stages = (M + 63) / 64;
     int tn = (N % 256 == 0 && variant != 2) ? 256 : 128;
     if (variant == 1) tn = 128;
     const int tiles = (N / tn) * (R * S * (Cs / 128));
-    long sp = ((variant == 1 ? 512 : 256) + tiles - 1) / tiles;
+    long sp = ((variant == 1 ? 512 : wgrad_target_wgs()) + tiles - 1) / tiles;
     if (sp > stages / 8) sp = stages / 8;
     if (sp < 1) sp = 1;
     *sps = (int)((stages + sp - 1) / sp);
@@ -869,7 +876,7 @@ static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN
 static void wgrad3_plan(long M, int N, int Cs, long* splits, int* sps) {
     const long stages = M / 64;
     const int tiles = (N / 128) * (Cs / 128) * 3;
-    long sp = (256 + tiles - 1) / tiles;
+    long sp = (wgrad_target_wgs() + tiles - 1) / tiles;
     if (sp > stages / 8) sp = stages / 8;
     if (sp < 1) sp = 1;
     *sps = (int)((stages + sp - 1) / sp);

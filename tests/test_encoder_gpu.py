@@ -158,6 +158,32 @@ def test_prefetched_weight_layouts_match_the_forwards_own():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("fine_tune", [False, True])
+def test_fused_bn_backward_sums_agree_with_the_separate_reduce(fine_tune, monkeypatch):
+    """The data-gradient launches that also take the BatchNorm-backward sums (default) against the separate reduce pass
+    (PPV_DGRAD_BNRED=0): same gradients up to the summation order; also covers the all-frozen trunk (fine_tune(False))."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 2, 1, 1)).cuda().train()
+    enc.fine_tune(fine_tune)
+    img = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run():
+        for p in enc.parameters():
+            p.grad = None
+        x = img.clone().requires_grad_(True)
+        enc(x).square().mean().backward()
+        return x.grad, [p.grad.clone() for p in enc.parameters() if p.requires_grad]
+
+    gx_a, gp_a = run()
+    monkeypatch.setenv("PPV_DGRAD_BNRED", "0")
+    gx_b, gp_b = run()
+    assert len(gp_a) == len(gp_b) == sum(p.requires_grad for p in enc.parameters())
+    assert torch.isfinite(gx_a).all() and rel_err(gx_a, gx_b) < 2e-2
+    for a, b in zip(gp_a, gp_b):
+        assert _cos(a, b) > 0.999
+
+
 def test_eval_mode_uses_running_statistics():
     enc, ref = _pair((1, 1, 1, 1))
     enc.eval(); ref.eval()

@@ -19,6 +19,9 @@
 // Epilogue of both: bf16 rounding; per-channel sum / sum-of-squares of the ROUNDED values (train-mode BatchNorm statistics,
 // SURVEY 8a-18) folded per tile and added with f32 atomics into <= 32 partial rows; optional residual-gradient addend (one
 // rounding of acc + addend) and ReLU bit mask of the destination tensor; the tile goes through LDS and leaves as 16-byte chunks.
+// The RED instantiations of the pipe kernel (ppv_conv_gemm_red: data-gradient launches of the trunk's backward) also take, in that
+// store loop, the sums the following BatchNorm backward needs (sum g, sum g * x per channel; optional recomputed ReLU mask), so
+// that BatchNorm's own reduce pass over the stored tensor disappears.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include "ppv_common.h"

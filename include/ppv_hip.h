@@ -126,6 +126,12 @@ int ppv_bn_bwd_blocks(long rows, int C);
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
                ppv_stream_t stream);
+/* ppv_bn_bwd (relu = 0) that also takes the backward sums of a second BatchNorm fed by the same gradient (the projection
+ * shortcut of a down-sampling bottleneck, raw conv output x2) into part2 [8][2][C], PRE-ZEROED; that BatchNorm's ppv_bn_bwd then
+ * runs with part_prezeroed = 2 */
+int ppv_bn_bwd_sums2(const void* gy, const void* x, const float* coef, double count, void* gx, float* dgamma, float* dbeta,
+                     float* part, float* kc, long rows, int C, int part_prezeroed, const void* x2, float* part2,
+                     ppv_stream_t stream);
 /* stem BN + ReLU + MaxPool 3x3/2 (resnet.1-3) and AdaptiveAvgPool2d(36) (models.py:27,39-40) */
 int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, int B, int H, int W, int C,
                         ppv_stream_t stream);

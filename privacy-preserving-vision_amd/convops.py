@@ -220,9 +220,10 @@ def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, wan
     return (y, bits) if want_bits else y
 
 
-def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False):
+def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False, sums2=None):
     """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None).  part: optional PRE-ZEROED f32 [64*C] scratch;
-    part_ready: part already holds the sums (conv_dgrad(..., red=(x, part)) produced gy)."""
+    part_ready: part already holds the sums (conv_dgrad(..., red=(x, part)) produced gy).  sums2 = (x2, part2): also take the
+    backward sums of a second BatchNorm that the same gy feeds (raw output x2) into the PRE-ZEROED part2."""
     C = x.shape[-1]
     rows = x.numel() // C
     dev = x.device
@@ -234,6 +235,11 @@ def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, p
     if part is None:
         part = torch.empty(64 * C, dtype=F32, device=dev)
     kc = torch.empty(3 * C, dtype=F32, device=dev)
+    if sums2 is not None:               # (x2, part2): the projection shortcut's BN sums ride along (relu 0, no g_pre copy)
+        assert not relu and not want_gpre
+        check(L().ppv_bn_bwd_sums2(ptr(gy), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(dg), ptr(db), ptr(part), ptr(kc), rows, C,
+                                   2 if part_ready else int(prezeroed), ptr(sums2[0]), ptr(sums2[1]), stream_ptr()), "ppv_bn_bwd_sums2")
+        return gx, gpre, dg, db
     check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
                          ptr(kc), rows, C, int(relu), 2 if part_ready else int(prezeroed), stream_ptr()), "ppv_bn_bwd")
     return gx, gpre, dg, db

@@ -210,14 +210,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
 // pass 2, coefficients in the prologue: every workgroup sums the 8 folded partial rows for its own channel slice
 // (<= 256 channels, 16 KB of L2-resident f32) and derives kc itself, so the separate coefficient launch and its two
 // kernel boundaries disappear.  grid (row slabs, C / CS), CS = min(C, 256); block = (256 / (CS/8)) rows x CS/8 lanes.
-template <int RELU, bool WRITE_GPRE>
+// SUMS2: the same gradient also feeds a second BatchNorm (the projection shortcut's, raw output x2): its backward sums (sum g,
+// sum g * x2) are taken here into part2 [8][2][C] (pre-zeroed), one extra read of x2 instead of that BN's own reduce pass.
+template <int RELU, bool WRITE_GPRE, bool SUMS2 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ part,
                                                                  const float* __restrict__ coef, double count,
                                                                  bf16_t* __restrict__ gx, bf16_t* __restrict__ gpre,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                 long rows, int C, int rows_per_blk, int fold_rows) {
+                                                                 long rows, int C, int rows_per_blk, int fold_rows,
+                                                                 const bf16_t* __restrict__ x2, float* __restrict__ part2) {
     __shared__ float s_k[5][256];
+    __shared__ float s_red2[SUMS2 ? 256 : 1][17];
     const int CS = C < 256 ? C : 256;
     const int cb = blockIdx.y * CS;
     if ((int)threadIdx.x < CS) {
@@ -251,6 +255,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     }
     const long r0 = (long)blockIdx.x * rows_per_blk;
     const long r1 = min(rows, r0 + rows_per_blk);
+    float a2[8], b2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a2[k] = b2[k] = 0.f;
 #pragma unroll 4
     for (long row = r0 + tr; row < r1; row += rpp) {
         const long o_ = row * C + cb + tc * 8;
@@ -266,6 +273,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         }
         store8(gx + o_, o);
         if (WRITE_GPRE) store8(gpre + o_, gp);
+        if constexpr (SUMS2) {
+            float x2v[8];
+            load8(x2 + o_, x2v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a2[k] += gp[k]; b2[k] += gp[k] * x2v[k]; }
+        }
+    }
+    if constexpr (SUMS2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s_red2[threadIdx.x][k] = a2[k]; s_red2[threadIdx.x][8 + k] = b2[k]; }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * CS; t += 256) {
+            const int which = t / CS, c = t % CS;
+            float v = 0.f;
+            for (int rr = 0; rr < rpp; ++rr) v += s_red2[rr * tpr + c / 8][which * 8 + c % 8];
+            atomicAdd(&part2[((long)(blockIdx.x & 7) * 2 + which) * C + cb + c], v);
+        }
     }
 }
 
@@ -464,9 +488,9 @@ int ppv_bn_bwd_blocks(long rows, int C) {
 // (BN + ReLU without residual; y may be null).  Writes g_x (bf16), optionally g_pre (bf16, may be
 // null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats; part_prezeroed 0: zeroed here, 1: the caller
 // zeroed it, 2: it already holds the [8][2][C] sums (ppv_conv_gemm_red took them while storing gy; relu must be 0).  kc: scratch 3*C.
-int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
-               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
-               hipStream_t stream) {
+static int bn_bwd_impl(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
+                       float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
+                       const void* x2, float* part2, hipStream_t stream) {
     if (!gy || !x || !coef || !gx || !part || !kc || (relu == 1 && !y)) return PPV_ERR_NULL;
     if (C % 64 || C > 2048) return PPV_ERR_BAD_SIZE;
     static const int fused = env_int_("PPV_BN_BWD_FUSED", 1);
@@ -491,7 +515,12 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
         const int arpp = 256 / (CS / 8);
         const long arpb = (long)arpp * iters;
         const dim3 grid((unsigned)((rows + arpb - 1) / arpb), (unsigned)(C / CS));
-#define PPV_APPLY(R, G) bn_bwd_apply_fused_kernel<R, G><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, fold_rows)
+#define PPV_APPLY(R, G) bn_bwd_apply_fused_kernel<R, G><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, fold_rows, nullptr, nullptr)
+        if (x2) {                                               // projection-shortcut sums ride along (relu 0, no g_pre copy)
+            if (relu || gpre || !part2) return PPV_ERR_BAD_SIZE;
+            bn_bwd_apply_fused_kernel<0, false, true><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C,
+                                                                             (int)arpb, fold_rows, (const bf16_t*)x2, part2);
+        } else
         if (relu == 2 && gpre) PPV_APPLY(2, true);
         else if (relu == 2) PPV_APPLY(2, false);
         else if (relu && gpre) PPV_APPLY(1, true);
@@ -501,6 +530,7 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
 #undef PPV_APPLY
         return ppv_last_error();
     }
+    if (x2) return PPV_ERR_BAD_SIZE;                            // the ride-along sums exist in the fused apply only
     bn_bwd_coef_kernel<<<C / 64, 1024, 0, stream>>>(part, 32, count, coef, kc, dgamma, dbeta, C);
     const long n8 = rows * C / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
@@ -511,6 +541,22 @@ int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, 
     else if (gpre) bn_bwd_apply_kernel<0, true><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
     else bn_bwd_apply_kernel<0, false><<<gb, 256, 0, stream>>>(g, yy, xx, kc, coef, ox, op, n8, C);
     return ppv_last_error();
+}
+
+int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
+               float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
+               hipStream_t stream) {
+    return bn_bwd_impl(gy, y, x, coef, count, gx, gpre, dgamma, dbeta, part, kc, rows, C, relu, part_prezeroed, nullptr, nullptr, stream);
+}
+
+// ppv_bn_bwd (relu = 0, no g_pre copy) that also takes the backward sums of a SECOND BatchNorm fed by the same gradient (the
+// projection shortcut of a down-sampling bottleneck: x2 = its raw conv output) into part2 [8][2][C] (PRE-ZEROED); that BatchNorm's
+// ppv_bn_bwd then runs with part_prezeroed = 2.  C in {64, 128} or C % 256 == 0.
+int ppv_bn_bwd_sums2(const void* gy, const void* x, const float* coef, double count, void* gx, float* dgamma, float* dbeta,
+                     float* part, float* kc, long rows, int C, int part_prezeroed, const void* x2, float* part2,
+                     hipStream_t stream) {
+    if (!x2 || !part2) return PPV_ERR_NULL;
+    return bn_bwd_impl(gy, nullptr, x, coef, count, gx, nullptr, dgamma, dbeta, part, kc, rows, C, 0, part_prezeroed, x2, part2, stream);
 }
 
 int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, int B, int H, int W, int C,

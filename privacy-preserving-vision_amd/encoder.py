@@ -227,10 +227,11 @@ class _TrunkFn(torch.autograd.Function):
             boff[0] += 64 * C
             return v
 
-        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None):
+        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None, sums2=None):
             trainable = rec.conv.weight.requires_grad
             gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad,
-                                         part=bn_part(xraw.shape[-1]) if sums is None else sums, part_ready=sums is not None)
+                                         part=bn_part(xraw.shape[-1]) if sums is None else sums, part_ready=sums is not None,
+                                         sums2=sums2)
             sync = enc.grad_sync
             if trainable:
                 if side is not None:
@@ -264,9 +265,10 @@ class _TrunkFn(torch.autograd.Function):
         taps = getattr(enc, "_debug_block_grads", None)      # tests: per-block (g_out, g_in) taps, last block first
         # The conv1 data-gradient launch that stores a block's input gradient also takes the sums bn3-backward of the PREVIOUS
         # block needs from it (sum g, sum g * x3 per channel): that BN's reduce pass over g and x3 (2 tensors of the 4C-wide
-        # size) becomes one read of x3 in the store loop.  PPV_DGRAD_BNRED=0 keeps the separate passes, 1 fuses bn3 only.
-        red_level = int(_os.environ.get("PPV_DGRAD_BNRED", "2"))
-        fuse_red, fuse_red12 = red_level >= 1, red_level >= 2
+        # size) becomes one read of x3 in the store loop.  PPV_DGRAD_BNRED=0 keeps the separate passes, 1 fuses bn3 only, 2 adds bn1 / bn2,
+        # 3 (default) also the projection shortcuts' sums (taken by bn3's apply pass).
+        red_level = int(_os.environ.get("PPV_DGRAD_BNRED", "3"))
+        fuse_red, fuse_red12, fuse_proj = red_level >= 1, red_level >= 2, red_level >= 3
         order = list(zip(reversed(enc._blocks), reversed(ctx.blocks)))
         sums3 = None
         for bi, (blk, sv) in enumerate(order):
@@ -274,7 +276,9 @@ class _TrunkFn(torch.autograd.Function):
             r1, r2, r3, rd = blk
             xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits = sv
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
-            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0, sums=sums3)
+            # a down-sampling block's projection BatchNorm sees the same gradient as bn3: bn3's apply pass takes its sums too
+            sumsd = bn_part(xd.shape[-1]) if (fuse_proj and rd is not None) else None
+            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0, sums=sums3, sums2=None if sumsd is None else (xd, sumsd))
             red = sums3 = None
             if fuse_red and bi + 1 < len(order):
                 x3_prev = order[bi + 1][1][7]                # raw conv3 output of the block this gradient flows into
@@ -298,7 +302,7 @@ class _TrunkFn(torch.autograd.Function):
                 gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
                 gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2)
             if rd is not None:
-                gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0)
+                gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0, sums=sumsd)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)
                 g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_bits=xin_bits, red=red)
             else:

@@ -152,3 +152,27 @@ def test_adaptive_pool_8_to_36():
     assert rel_err(yd, nhwc(y.detach())) < 1e-6
     gx = co.adaptive_pool_bwd(nhwc(gy).cuda(), (8, 8))
     assert rel_err(gx.float(), nhwc(x.grad)) < BF
+
+
+@pytest.mark.parametrize("C,rows", [(256, 4096), (512, 1000), (2048, 130)])
+def test_bn_backward_takes_a_second_batchnorms_sums(C, rows):
+    """bn_bwd(..., sums2=(x2, part2)): same g_x / dgamma / dbeta as the plain call, and part2 holds sum g and sum g * x2 so that
+    the second BatchNorm's backward (part_ready) equals its own full backward."""
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(C)
+    g = torch.randn(rows, C, generator=g0).bfloat16().cuda()
+    x = torch.randn(rows, C, generator=g0).bfloat16().cuda()
+    x2 = torch.randn(rows, C, generator=g0).bfloat16().cuda()
+    mk = lambda: torch.stack([torch.rand(C, generator=g0) + 0.5, torch.randn(C, generator=g0) * 0.1,
+                              torch.randn(C, generator=g0) * 0.1, torch.rand(C, generator=g0) + 0.5]).cuda().contiguous()
+    coef, coef2 = mk(), mk()
+    want = co.bn_bwd(g, None, x, coef, 0)
+    part2 = torch.zeros(64 * C, device="cuda")
+    got = co.bn_bwd(g, None, x, coef, 0, sums2=(x2, part2))
+    # two runs of the reduce kernel add their f32 atomics in different orders: equal up to that, not bit for bit
+    assert rel_err(got[0].float(), want[0].float()) < 2 ** -9 and rel_err(got[2], want[2]) < 1e-5 and rel_err(got[3], want[3]) < 1e-5
+    sums = part2[:16 * C].view(8, 2, C).sum(0)
+    assert rel_err(sums[0], g.float().sum(0)) < 1e-4 and rel_err(sums[1], (g.float() * x2.float()).sum(0)) < 1e-4
+    want2 = co.bn_bwd(g, None, x2, coef2, 0)
+    got2 = co.bn_bwd(g, None, x2, coef2, 0, part=part2, part_ready=True)
+    assert rel_err(got2[0].float(), want2[0].float()) < 2 ** -7 and rel_err(got2[2], want2[2]) < 1e-4 and rel_err(got2[3], want2[3]) < 1e-4

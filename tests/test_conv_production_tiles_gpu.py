@@ -1,0 +1,202 @@
+"""Oracle parity of the tile variants that carry the B = 128 benchmark (reference: the torchvision bottleneck
+convolutions behind Image_Caption/models.py:17-21).
+
+ppv_conv_gemm picks its tile from the problem size: the small cases of test_conv_gpu.py all land on the 128x128x4-stage or the
+two-stage kernel, while every forward / data-gradient launch of the benchmark runs <256,128,3,32,2> (variant 4),
+<256,128,3,64,1> (variant 3) or <128,64,3,32,4> (64-column layer 1).  Here
+  * every pipelined tile is FORCED (ppv_conv_set_variant) on small problems, and
+  * problems sized like the benchmark's are left to the automatic rule,
+and both are compared with torch CPU fp32 conv2d / its autograd on the same bf16-rounded operands: f32-accumulator output
+1e-3 relative (north_star), bf16 output one more rounding (2^-8), including the residual addend, the ReLU bit mask and the
+fused BatchNorm-backward sums -- against values computed by the oracle, never against another launch of the product.
+The weight gradient is checked the same way at the benchmark's split counts (M = 32 768 rows and up: small-ring 128-wide tile,
+256-wide tile, fused-tap 3x3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF = 2 ** -8 + 1e-3
+
+
+def _mk(B, H, Cin, Cout, k, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, H, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    return x, w
+
+
+def _bits(keep):
+    k = keep.reshape(-1, 8).to(torch.int32).cuda()
+    return (k << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+
+
+class _variant:
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        import ppv_amd.convops as co
+        co.zero_page(torch.device("cuda", 0))
+        co.L().ppv_conv_set_variant(self.v)
+
+    def __exit__(self, *a):
+        import ppv_amd.convops as co
+        co.L().ppv_conv_set_variant(0)
+
+
+def _check_forward(B, H, Cin, Cout, k, stride):
+    import ppv_amd.convops as co
+    x, w = _mk(B, H, Cin, Cout, k)
+    pad = (k - 1) // 2
+    want = F.conv2d(x, w, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    wt = co.weight_layout(w.cuda(), 0)
+    got32 = co.conv_fwd(xd, wt, stride, pad, out_f32=True)
+    assert rel_err(got32, want) < 1e-3
+    part = torch.zeros((co.stat_tiles(want.numel() // Cout), 2, Cout), device="cuda")
+    got = co.conv_fwd(xd, wt, stride, pad, stat_part=part)
+    assert rel_err(got.float(), want) < BF
+    # the statistics are those of the ORACLE's tensor rounded to bf16 (train.py:245 train-mode BN sees the stored tensor)
+    wr = want.bfloat16().float().reshape(-1, Cout)
+    n = wr.shape[0]
+    assert rel_err(part.sum(0)[0] / n, wr.mean(0)) < 2e-3 and rel_err(part.sum(0)[1] / n, (wr * wr).mean(0)) < 2e-3
+    gf = got.float().reshape(-1, Cout)
+    assert rel_err(part.sum(0)[0], gf.sum(0)) < 1e-4 and rel_err(part.sum(0)[1], (gf * gf).sum(0)) < 1e-4
+
+
+def _check_dgrad(B, H, Cin, Cout, k, stride):
+    """data gradient of conv(Cin -> Cout): GEMM with N = Cin columns.  plain, + addend, + bit mask, + BN-backward sums."""
+    import ppv_amd.convops as co
+    x, w = _mk(B, H, Cin, Cout, k)
+    pad = (k - 1) // 2
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).bfloat16().float()
+    y.backward(g)
+    want = x.grad.permute(0, 2, 3, 1).contiguous()
+    gd = g.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    wd = co.weight_layout(w.cuda(), 1)
+    got = co.conv_dgrad(gd, wd, stride, pad, (H, H), out_f32=True)
+    assert rel_err(got, want) < 1e-3
+    gen = torch.Generator().manual_seed(9)
+    add = torch.randn(want.shape, generator=gen).bfloat16()
+    act = torch.relu(torch.randn(want.shape, generator=gen))
+    act.view(-1)[::7] = 0.0
+    keep = act > 0
+    bits = _bits(keep)
+    want_am = (want + add.float()) * keep
+    got_am = co.conv_dgrad(gd, wd, stride, pad, (H, H), addend=add.cuda(), relu_bits=bits)
+    assert rel_err(got_am.float(), want_am) < BF
+    assert not got_am[~keep.cuda()].any()                                   # masked lanes are exact zeros
+    got_m = co.conv_dgrad(gd, wd, stride, pad, (H, H), relu_bits=bits)
+    assert rel_err(got_m.float(), want * keep) < BF
+    rows = want.numel() // Cin
+    if not co.red_supported(rows, Cin):
+        return
+    # fused BN-backward sums, against sums of the ORACLE's gradient: sum g and sum g * x per channel
+    xraw = torch.randn(want.shape, generator=gen).bfloat16()
+    for with_add in (True, False):
+        part = torch.zeros(64 * Cin, device="cuda")
+        fused = co.conv_dgrad(gd, wd, stride, pad, (H, H), addend=add.cuda() if with_add else None, relu_bits=bits,
+                              red=(xraw.cuda(), part))
+        ref = want_am if with_add else want * keep
+        assert rel_err(fused.float(), ref) < BF
+        sums = part[:co.RED_ROWS * 2 * Cin].view(co.RED_ROWS, 2, Cin).sum(0).cpu()
+        rb = ref.bfloat16().float().reshape(-1, Cin)
+        xf = xraw.float().reshape(-1, Cin)
+        # one bf16 rounding per element, random sign: the sums agree to ~2^-9 / sqrt(rows) of the absolute mass
+        tol = 4 * 2 ** -9 / rows ** 0.5 + 1e-4
+        assert ((sums[0] - rb.sum(0)).abs() / rb.abs().sum(0)).max().item() < tol
+        assert ((sums[1] - (rb * xf).sum(0)).abs() / (rb * xf).abs().sum(0)).max().item() < tol
+    # BN + ReLU mask recomputed from the raw conv output (bn1 / bn2 of the trunk)
+    coef = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3,
+                        torch.randn(Cin, generator=gen) * 0.1, torch.rand(Cin, generator=gen) + 0.5]).contiguous()
+    keep2 = (xraw.double() * coef[0].double() + coef[1].double()) > 0        # the sign of the exact value = the sign of the kernel's fmaf
+    part = torch.zeros(64 * Cin, device="cuda")
+    fused = co.conv_dgrad(gd, wd, stride, pad, (H, H), red=(xraw.cuda(), part, coef.cuda()))
+    assert rel_err(fused.float(), want * keep2) < BF
+    assert not fused[~keep2.cuda()].any()
+
+
+FORCED = [  # (B, H, Cin, Cout, k, stride): N % 128 == 0 in both directions, ragged M included
+    (2, 16, 128, 256, 1, 1), (3, 16, 128, 128, 3, 1), (2, 16, 128, 128, 3, 2), (2, 16, 256, 512, 1, 2), (5, 7, 128, 384, 3, 1),
+    (9, 8, 512, 128, 1, 1),
+]
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", FORCED)
+def test_forced_tile_forward(variant, B, H, Cin, Cout, k, stride):
+    with _variant(variant):
+        _check_forward(B, H, Cin, Cout, k, stride)
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", FORCED)
+def test_forced_tile_dgrad(variant, B, H, Cin, Cout, k, stride):
+    with _variant(variant):
+        _check_dgrad(B, H, Cin, Cout, k, stride)
+
+
+# problems that the automatic rule sends to each production tile (t256 = ceil(M / 256) * N / 128):
+AUTO_FWD = [
+    (32, 32, 256, 256, 3, 1),     # M = 32 768, N = 256: t256 = 256  -> <256,128,3,64,1>
+    (64, 32, 128, 512, 1, 1),     # M = 65 536, N = 512: t256 = 1024 -> <256,128,3,32,2>
+    (32, 64, 256, 64, 1, 1),      # M = 131 072, N = 64              -> <128,64,3,32,4>
+    (33, 64, 64, 64, 3, 1),       # ragged M, 64 columns, 3x3        -> <128,64,3,32,4>
+    (16, 32, 256, 512, 1, 2),     # projection shortcut, stride 2: M = 4096, t256 = 64 -> <128,128,4,64,1>
+    (64, 16, 1024, 256, 1, 1),    # M = 16 384, N = 256: t256 = 128  -> <128,128,4,64,1>
+    (128, 16, 256, 1024, 1, 1),   # the layer-3 conv3 shape itself at B = 128: t256 = 1024 -> <256,128,3,32,2>
+]
+AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
+    (32, 32, 256, 256, 3, 1),     # N = 256, M = 32 768 -> <256,128,3,64,1>
+    (64, 32, 512, 128, 1, 1),     # N = 512, M = 65 536 -> <256,128,3,32,2> (conv1 data gradient: addend + mask + sums)
+    (32, 64, 64, 256, 1, 1),      # N = 64, M = 131 072 -> <128,64,3,32,4>
+    (16, 32, 256, 512, 1, 2),     # stride-2 projection data gradient (zero-page taps), N = 256
+    (128, 16, 1024, 256, 1, 1),   # the layer-3 conv1 data gradient at B = 128
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", AUTO_FWD)
+def test_benchmark_sized_forward(B, H, Cin, Cout, k, stride):
+    _check_forward(B, H, Cin, Cout, k, stride)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", AUTO_DGRAD)
+def test_benchmark_sized_dgrad(B, H, Cin, Cout, k, stride):
+    _check_dgrad(B, H, Cin, Cout, k, stride)
+
+
+WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> the benchmark's split counts
+    (32, 32, 256, 1024, 1, 1, 0),   # small-ring 128-wide tile, 1x1 (default under the side-stream overlap)
+    (32, 32, 1024, 256, 1, 1, 0),
+    (32, 32, 256, 256, 3, 1, 0),    # fused-tap 3x3
+    (32, 32, 256, 1024, 1, 1, 3),   # 256-wide three-stage tile
+    (32, 32, 256, 256, 3, 1, 2),    # 3x3 through the one-tap-per-workgroup kernel (128-wide, four stages)
+    (16, 64, 128, 128, 3, 2, 0),    # stride-2 3x3 (first block of a layer): M = 16 384 output pixels
+    (64, 32, 256, 512, 1, 2, 0),    # stride-2 projection
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,variant", WGRAD)
+def test_benchmark_sized_wgrad(B, H, Cin, Cout, k, stride, variant):
+    import ppv_amd.convops as co
+    x, w = _mk(B, H, Cin, Cout, k)
+    pad = (k - 1) // 2
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).bfloat16().float()
+    y.backward(g)
+    co.zero_page(torch.device("cuda", 0))
+    co.L().ppv_wgrad_set_variant(variant)
+    try:
+        got = co.conv_wgrad(g.permute(0, 2, 3, 1).contiguous().cuda().bfloat16(), x.permute(0, 2, 3, 1).contiguous().cuda().bfloat16(),
+                            k, k, stride, pad)
+    finally:
+        co.L().ppv_wgrad_set_variant(0)
+    assert got.shape == w.shape
+    assert rel_err(got, w.grad) < 1e-3

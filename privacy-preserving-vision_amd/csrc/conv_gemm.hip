@@ -22,44 +22,9 @@
 // The RED instantiations of the pipe kernel (ppv_conv_gemm_red: data-gradient launches of the trunk's backward) also take, in that
 // store loop, the sums the following BatchNorm backward needs (sum g, sum g * x per channel; optional recomputed ReLU mask), so
 // that BatchNorm's own reduce pass over the stored tensor disappears.
-#include <hip/hip_runtime.h>
-#include <hip/hip_bf16.h>
-#include "ppv_common.h"
+#include "conv_common.h"
 
 namespace ppv {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;
-
-struct ConvGeom {
-    int B, Hs, Ws, Cs;   // source tensor NHWC
-    int Ho, Wo;          // output pixels per image (GEMM rows m = (b, ho, wo))
-    int N;               // GEMM columns (output channels)
-    int R, S;            // taps
-    int a, off, sh;      // source step, tap offset, log2(div)
-    int flat;            // 1x1, unit step, no offset, same grid: GEMM row m IS source pixel m (no (b, ho, wo) decomposition)
-    long M;              // B * Ho * Wo
-};
-
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    return __builtin_bit_cast(bf16_t, (__bf16)f);
-}
-__device__ __forceinline__ float bf2f(bf16_t h) {
-    return __builtin_bit_cast(float, (unsigned)h << 16);
-}
-
-// keep the bf16 lanes of v whose bit is set in b (bit k <-> lane k): the ReLU mask of the tensor the gradient flows into,
-// as written by ppv_bn_act's pos_bits
-__device__ __forceinline__ uint4 relu_mask8(uint4 v, unsigned b) {
-    auto keep = [](unsigned two) { return ((two & 1u) ? 0xffffu : 0u) | ((two & 2u) ? 0xffff0000u : 0u); };
-    v.x &= keep(b); v.y &= keep(b >> 2); v.z &= keep(b >> 4); v.w &= keep(b >> 6);
-    return v;
-}
-
-#define GLDS16(gptr, lptr)                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                  \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 // stat_part: [stat_rows][2][N] f32 partial (sum, sum of squares) of the bf16-rounded outputs (pre-zeroed; row tiles
 // fold into row tile_m % stat_rows with f32 atomics), or null.
@@ -259,7 +224,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
 //   * incremental (tap, channel) counters instead of per-stage integer divisions.
 // RAW: a stage is read one barrier after every wave's counted wait retired its own loads of that stage.
 // WAR: stage t+NSTAGE-1 overwrites the buffer last read in compute(t-1), which every wave finished before barrier t.
-template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // RED (data-gradient launches that feed a BatchNorm backward): stat_part receives, instead of the forward statistics, the
 // BN-backward sums of the tile as it is STORED (after addend, rounding and ReLU mask): sum g and sum g * red_x per column,
@@ -267,28 +231,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile(
 // extra read of x (1 T) in this store loop.  red_coef (BN scale / shift [2][N], may be null): the BatchNorm is followed by a ReLU
 // without residual, so its mask (x * scale + shift > 0, the forward kernel's expression) is recomputed here, applied to the
 // stored gradient and to the sums (single-pass store path only: launches without addend).
-__device__ __forceinline__ uint4 red_mask8(const uint4 gv, const uint4 xv, const float (&sc)[8], const float (&sh)[8]) {
-    unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
-    const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x0 = __builtin_bit_cast(float, xw[i] << 16), x1 = __builtin_bit_cast(float, xw[i] & 0xffff0000u);
-        if (!(__builtin_fmaf(x0, sc[2 * i], sh[2 * i]) > 0.f)) gw[i] &= 0xffff0000u;
-        if (!(__builtin_fmaf(x1, sc[2 * i + 1], sh[2 * i + 1]) > 0.f)) gw[i] &= 0x0000ffffu;
-    }
-    return make_uint4(gw[0], gw[1], gw[2], gw[3]);
-}
-__device__ __forceinline__ void red_acc8(const uint4 gv, const uint4 xv, float (&ra)[8], float (&rb)[8]) {
-    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float g0 = __builtin_bit_cast(float, gw[i] << 16), g1 = __builtin_bit_cast(float, gw[i] & 0xffff0000u);
-        const float x0 = __builtin_bit_cast(float, xw[i] << 16), x1 = __builtin_bit_cast(float, xw[i] & 0xffff0000u);
-        ra[2 * i] += g0; ra[2 * i + 1] += g1;
-        rb[2 * i] += g0 * x0; rb[2 * i + 1] += g1 * x1;
-    }
-}
-
 template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
@@ -724,11 +666,22 @@ __global__ __launch_bounds__(256) void weight_layout_multi_kernel(const WLayoutD
 using namespace ppv;
 
 static int g_conv_variant = 0;
+#ifdef PPV_STAMPS
+namespace ppv { __device__ unsigned long long* g_stamps = nullptr; }
+#endif
 
 extern "C" {
 
-// tuning / A-B hook: 0 auto, 1 two-stage, 2 = 128x128x4-stage, 3 = 256x128x3-stage
+// tuning / A-B hook: 0 auto, 1 two-stage, 2 = 128x128x4-stage, 3 = 256x128x3-stage, 4 = 256x128 BK32 two per CU, 7 = tiled kernels only
+// (no conv_stream.hip), 8 = conv_stream.hip wherever it can run
 int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
+
+#ifdef PPV_STAMPS
+// diagnostic build: buf = device array of 16 * (largest grid) u64, or null to stop stamping
+int ppv_debug_set_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(ppv::g_stamps), &buf, sizeof(buf)) == hipSuccess ? PPV_OK : PPV_ERR_INIT;
+}
+#endif
 
 // Generic NHWC bf16 gather-GEMM convolution (see file header).  X [B,Hs,Ws,Cs] bf16, Wt [N][R*S*Cs] bf16,
 // out [B*Ho*Wo][N] bf16 (out_f32 = 0) or f32 (out_f32 = 1: parity tests and the stem data gradient),
@@ -749,6 +702,11 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
     g.M = (long)B * Ho * Wo;
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
+    // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
+    if (((g_conv_variant == 0 && addend && !out_f32) || g_conv_variant == 8) && conv1x1_stream_supported(g, Cs, div))
+        return conv1x1_stream_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
+                                     (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
+                                     out_f32, stat_rows, stream);
     const int tiles_m = (int)((g.M + 127) / 128);
     const bf16_t* x = (const bf16_t*)X;
     const bf16_t* w = (const bf16_t*)Wt;
@@ -787,6 +745,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     // 4 = 256 x 128 x 3 stages of BK 32, two workgroups per CU
     const int CUS = 256;
     int v = g_conv_variant;
+    if (v == 7 || v == 8) v = 0;
     if (N != 16 && N % 128 && (v == 0 || v >= 3) && g.M >= 128 * 1024) {
         PPV_LAUNCH_PIPE_R(128, 64, 3, 32, 4);   // 64-column layers (layer1): HBM-bound, four small-ring workgroups per CU
         return ppv_last_error();

@@ -3,7 +3,8 @@ convolutions behind Image_Caption/models.py:17-21).
 
 ppv_conv_gemm picks its tile from the problem size: the small cases of test_conv_gpu.py all land on the 128x128x4-stage or the
 two-stage kernel, while every forward / data-gradient launch of the benchmark runs <256,128,3,32,2> (variant 4),
-<256,128,3,64,1> (variant 3) or <128,64,3,32,4> (64-column layer 1).  Here
+<256,128,3,64,1> (variant 3), <128,64,3,32,4> (64-column layer 1) or the streaming 1x1 kernel of conv_stream.hip (1x1 shapes
+with <= 256 input and >= 2x as many output channels: automatic for the launches with a residual addend, variant 8 everywhere).  Here
   * every pipelined tile is FORCED (ppv_conv_set_variant) on small problems, and
   * problems sized like the benchmark's are left to the automatic rule,
 and both are compared with torch CPU fp32 conv2d / its autograd on the same bf16-rounded operands: f32-accumulator output
@@ -124,18 +125,18 @@ def _check_dgrad(B, H, Cin, Cout, k, stride):
 
 FORCED = [  # (B, H, Cin, Cout, k, stride): N % 128 == 0 in both directions, ragged M included
     (2, 16, 128, 256, 1, 1), (3, 16, 128, 128, 3, 1), (2, 16, 128, 128, 3, 2), (2, 16, 256, 512, 1, 2), (5, 7, 128, 384, 3, 1),
-    (9, 8, 512, 128, 1, 1),
+    (9, 8, 512, 128, 1, 1), (3, 16, 64, 256, 1, 1), (5, 9, 256, 1024, 1, 1),
 ]
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 8])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", FORCED)
 def test_forced_tile_forward(variant, B, H, Cin, Cout, k, stride):
     with _variant(variant):
         _check_forward(B, H, Cin, Cout, k, stride)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 8])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", FORCED)
 def test_forced_tile_dgrad(variant, B, H, Cin, Cout, k, stride):
     with _variant(variant):
@@ -150,25 +151,36 @@ AUTO_FWD = [
     (33, 64, 64, 64, 3, 1),       # ragged M, 64 columns, 3x3        -> <128,64,3,32,4>
     (16, 32, 256, 512, 1, 2),     # projection shortcut, stride 2: M = 4096, t256 = 64 -> <128,128,4,64,1>
     (64, 16, 1024, 256, 1, 1),    # M = 16 384, N = 256: t256 = 128  -> <128,128,4,64,1>
-    (128, 16, 256, 1024, 1, 1),   # the layer-3 conv3 shape itself at B = 128: t256 = 1024 -> <256,128,3,32,2>
+    (128, 16, 256, 1024, 1, 1),   # the layer-3 conv3 shape itself at B = 128 -> conv_stream.hip (K = 256)
+    (32, 64, 64, 256, 1, 1),      # layer-1 conv3 -> conv_stream.hip (K = 64)
+    (32, 64, 256, 512, 1, 2),     # layer-2 projection shortcut (stride 2) -> conv_stream.hip, strided pixel rows
 ]
 AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
     (32, 32, 256, 256, 3, 1),     # N = 256, M = 32 768 -> <256,128,3,64,1>
     (64, 32, 512, 128, 1, 1),     # N = 512, M = 65 536 -> <256,128,3,32,2> (conv1 data gradient: addend + mask + sums)
     (32, 64, 64, 256, 1, 1),      # N = 64, M = 131 072 -> <128,64,3,32,4>
     (16, 32, 256, 512, 1, 2),     # stride-2 projection data gradient (zero-page taps), N = 256
-    (128, 16, 1024, 256, 1, 1),   # the layer-3 conv1 data gradient at B = 128
+    (128, 16, 1024, 256, 1, 1),   # the layer-3 conv1 data gradient at B = 128 -> conv_stream.hip with addend + mask + sums
+    (32, 64, 256, 64, 1, 1),      # layer-1 conv1 data gradient (K = 64 -> 256 columns) -> conv_stream.hip
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 8])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", AUTO_FWD)
-def test_benchmark_sized_forward(B, H, Cin, Cout, k, stride):
-    _check_forward(B, H, Cin, Cout, k, stride)
+def test_benchmark_sized_forward(variant, B, H, Cin, Cout, k, stride):
+    if variant == 8 and (k != 1 or Cin > 256 or Cout < 2 * Cin):
+        pytest.skip("outside conv_stream.hip: variant 8 = variant 0")
+    with _variant(variant):
+        _check_forward(B, H, Cin, Cout, k, stride)
 
 
+@pytest.mark.parametrize("variant", [0, 8])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", AUTO_DGRAD)
-def test_benchmark_sized_dgrad(B, H, Cin, Cout, k, stride):
-    _check_dgrad(B, H, Cin, Cout, k, stride)
+def test_benchmark_sized_dgrad(variant, B, H, Cin, Cout, k, stride):
+    if variant == 8 and (k != 1 or Cout > 256 or Cin < 2 * Cout):
+        pytest.skip("outside conv_stream.hip: variant 8 = variant 0")
+    with _variant(variant):
+        _check_dgrad(B, H, Cin, Cout, k, stride)
 
 
 WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> the benchmark's split counts

@@ -347,13 +347,21 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PPV_FORCE_DIST=1: run the data-parallel machinery (process group, RCCL all-reduce on the side stream, global-max exchange)
+    # even with one rank -- the one-GPU rehearsal of the N-GPU path (tests/test_dist_gpu.py)
+    force_dist = world == 1 and bool(os.environ.get("PPV_FORCE_DIST"))
     if os.environ.get("PPV_FORCE_DEVICE0"):                          # rehearsal: several ranks on one GPU
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("PPV_DIST_BACKEND", "nccl")        # "gloo" only for single-GPU rehearsals
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -361,11 +369,12 @@ def main():
     rank = dist.get_rank() if world > 1 else 0
 
     torch.manual_seed(1234)                      # identical height-map noise stream on every rank -> identical PSF
-    camera, encoder = build(device, global_max_sync=world > 1)
+    camera, encoder = build(device, global_max_sync=world > 1 or force_dist)
     sync = None
-    if world > 1:
+    if world > 1 or force_dist:
         from ppv_amd.dist_sync import GradSync
         sync = GradSync(bucket_mb=32)
+        sync.defer_join = True                   # the step below flush()es before the optimisers: the tail bucket overlaps the camera's backward
         encoder.grad_sync = sync
     decoder = None
     if args.decoder:
@@ -398,7 +407,7 @@ def main():
         line = {
             "metric": "images/sec fwd+bwd, Camera+ResNet-101" + ("+attention decoder" if args.decoder else "") + " @256^2",
             "value": round(value, 1), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "n_gpus": world, "dist": ("rccl all-reduce exercised at world size 1" if force_dist else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "IC OpticsZernike camera (896^2 wave grid, 350 Zernike terms, prueba '3') + ResNet-101 "
                                    "Encoder, fwd+bwd+Adam, 256x256; camera fp32/fp64, trunk bf16 storage + fp32 accumulate; "
@@ -413,7 +422,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(camera)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -153,15 +153,18 @@ def wgrad_scratch_bytes(M, N, R, S, Cs):
     return L().ppv_conv_wgrad_scratch_bytes(M, N, R, S, Cs)
 
 
-def conv_wgrad(g, x, R, S, stride, pad, scratch=None):
+def conv_wgrad(g, x, R, S, stride, pad, scratch=None, out=None):
     """g [B,Ho,Wo,Cout] bf16, x [B,H,W,Cin] bf16 -> dW in torch layout [Cout,Cin,R,S] f32.
-    scratch: optional uint8 buffer of >= wgrad_scratch_bytes(...) (reused across convs; no zeroing needed)."""
+    scratch: optional uint8 buffer of >= wgrad_scratch_bytes(...) (reused across convs; no zeroing needed).
+    out: optional contiguous f32 [Cout,Cin,R,S] destination (e.g. a slice of a flat gradient bucket, dist_sync.GradSync)."""
     B, Ho, Wo, Cout = g.shape
     _, H, W, Cin = x.shape
     need = wgrad_scratch_bytes(B * Ho * Wo, Cout, R, S, Cin)
     if scratch is None or scratch.numel() < need:
         scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
-    out = torch.empty((Cout, Cin, R, S), dtype=F32, device=g.device)
+    if out is None:
+        out = torch.empty((Cout, Cin, R, S), dtype=F32, device=g.device)
+    assert out.shape == (Cout, Cin, R, S) and out.dtype == F32 and out.is_contiguous()
     _timed("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
         L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(out), ptr(scratch), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S,
                            stride, pad, stream_ptr()), "ppv_conv_wgrad"), nbytes=(g.numel() + x.numel()) * 2.0 + out.numel() * 4.0)
@@ -220,7 +223,7 @@ def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, wan
     return (y, bits) if want_bits else y
 
 
-def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False, sums2=None):
+def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False, sums2=None, out_affine=None):
     """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None).  part: optional PRE-ZEROED f32 [64*C] scratch;
     part_ready: part already holds the sums (conv_dgrad(..., red=(x, part)) produced gy).  sums2 = (x2, part2): also take the
     backward sums of a second BatchNorm that the same gy feeds (raw output x2) into the PRE-ZEROED part2."""
@@ -231,6 +234,8 @@ def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, p
     gpre = torch.empty_like(x) if want_gpre else None
     dg = torch.empty(C, dtype=F32, device=dev) if want_affine else None
     db = torch.empty(C, dtype=F32, device=dev) if want_affine else None
+    if want_affine and out_affine is not None:          # (d gamma, d beta) destinations, e.g. slices of a flat gradient bucket
+        dg, db = out_affine
     prezeroed = part is not None
     if part is None:
         part = torch.empty(64 * C, dtype=F32, device=dev)

@@ -1,7 +1,21 @@
 """Data-parallel gradient averaging for the Camera + Encoder step: one process per GPU,
-``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on MI355X; ``gloo`` in CPU tests), gradients bucketed in the
-order backward produces them (reverse layer order) and all-reduced on a side HIP stream while the rest of backward
-runs.  The reference has no distributed code; this is the build's own layer."""
+``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on MI355X; ``gloo`` in CPU tests), gradients all-reduced on a
+side HIP stream while the rest of backward runs.  The reference has no distributed code; this is the build's own layer.
+
+Two ways in:
+
+* ``attach(params)`` (what ``ppv_amd.encoder.Encoder`` does when a ``GradSync`` is assigned to ``encoder.grad_sync``): the
+  gradients of ``params`` -- listed in the order backward produces them -- live in persistent, PRE-FLATTENED f32 buckets.
+  Backward's kernels write straight into a parameter's slice (``grad_view``), the trunk sets ``param.grad`` to that slice
+  itself and hands autograd nothing, and a bucket is all-reduced in place the moment its last slice is ``mark_ready``:
+  no ``torch.cat`` / ``copy_`` round trip (2 x 170 MB per step before), and no tensor that is being all-reduced ever goes
+  through autograd's AccumulateGrad (which may add to or clone it on the main stream while the side stream reduces it).
+* ``push(grad)``: loose tensors (tests, foreign modules); bucketed by bytes, flattened with one ``cat`` per bucket.
+
+Stream contract: every all-reduce runs on ``self.stream`` behind the events of the gradients it covers.  The trunk's backward
+ends with ``join()`` (current stream waits for the side stream), so ``param.grad`` is final for whatever is enqueued after
+``backward()`` -- safe by construction.  A harness that wants the tail bucket to overlap what follows backward (bench.py: the
+camera's own backward) sets ``defer_join = True`` and calls ``flush()`` before the optimiser step."""
 import torch
 import torch.distributed as dist
 
@@ -12,10 +26,67 @@ class GradSync:
         self.world = dist.get_world_size(process_group)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.stream = None
-        self._bucket, self._size, self._events = [], 0, []
+        self.defer_join = False
         self.launched = 0
+        # loose tensors
+        self._bucket, self._size, self._events = [], 0, []
+        # pre-flattened buckets
+        self._flat = []            # one f32 tensor per bucket
+        self._slot = {}            # id(param) -> (bucket, offset, numel)
+        self._pending = []         # per bucket: slices not yet marked ready this step
+        self._count = []           # per bucket: number of slices
+        self._bevents = []         # per bucket: events of the slices marked ready
+        self._params = []
 
-    # -- called by Encoder backward as each gradient tensor becomes final
+    # ------------------------------------------------------------------ pre-flattened buckets
+    def attach(self, params):
+        """params: the parameters whose gradients this object owns, in the order backward finishes them."""
+        params = [p for p in params if p.requires_grad]
+        if [id(p) for p in params] == [id(p) for p in self._params] and self._flat and self._flat[0].device == params[0].device:
+            return
+        self._params = params
+        self._flat, self._slot, self._count = [], {}, []
+        cur, off = [], 0
+        groups = []
+        for p in params:
+            n = p.numel()
+            cur.append((p, off, n))
+            off += (n + 3) // 4 * 4                                   # 16-byte aligned slices
+            if off * 4 >= self.bucket_bytes:
+                groups.append((cur, off))
+                cur, off = [], 0
+        if cur:
+            groups.append((cur, off))
+        for b, (items, total) in enumerate(groups):
+            self._flat.append(torch.zeros(total, dtype=torch.float32, device=params[0].device))
+            self._count.append(len(items))
+            for p, o, n in items:
+                self._slot[id(p)] = (b, o, n)
+        self._pending = [c for c in self._count]
+        self._bevents = [[] for _ in self._count]
+
+    def grad_view(self, p):
+        """The slice of the flat bucket that IS this parameter's gradient (None: not attached)."""
+        s = self._slot.get(id(p))
+        if s is None:
+            return None
+        b, o, n = s
+        return self._flat[b][o:o + n].view(p.shape)
+
+    def mark_ready(self, p):
+        """The slice of ``p`` has been written on the CURRENT stream; the bucket is reduced when all its slices are."""
+        b = self._slot[id(p)][0]
+        if self._flat[b].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._bevents[b].append(ev)
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._pending[b] = self._count[b]
+            events, self._bevents[b] = self._bevents[b], []
+            self._reduce_on_side(self._flat[b], events, [])
+
+    # ------------------------------------------------------------------ loose tensors
     def push(self, grad):
         if grad is None:
             return
@@ -33,39 +104,63 @@ class GradSync:
         events, self._events = self._events, []
         if not grads:
             return
+        if len(grads) == 1:
+            self._reduce_on_side(grads[0].reshape(-1), events, grads)
+            return
+        self._reduce_on_side(None, events, grads)
+
+    def _reduce_on_side(self, flat, events, scatter_to):
         self.launched += 1
-        if grads[0].is_cuda:
+        ref = flat if flat is not None else scatter_to[0]
+
+        def run():
+            buf = flat if flat is not None else torch.cat([g.reshape(-1) for g in scatter_to])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.mul_(1.0 / self.world)
+            if flat is None:
+                off = 0
+                for g in scatter_to:
+                    g.copy_(buf[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+
+        if ref.is_cuda:
             if self.stream is None:
-                self.stream = torch.cuda.Stream(device=grads[0].device)
+                self.stream = torch.cuda.Stream(device=ref.device)
             for ev in events:                        # every gradient of this bucket, on its producing stream
                 self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                self._reduce(grads)
-                for g in grads:
+                run()
+                for g in scatter_to:
                     g.record_stream(self.stream)
         else:
-            self._reduce(grads)
+            run()
 
-    def _reduce(self, grads):
-        flat = torch.cat([g.reshape(-1) for g in grads]) if len(grads) > 1 else grads[0].reshape(-1)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
-        if len(grads) > 1:
-            off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
-
+    # ------------------------------------------------------------------ joins
     def launch_pending(self):
-        """Start the all-reduce of the last, partly filled bucket (called when the producer has no more gradients)."""
+        """Start the all-reduce of the last, partly filled bucket of loose tensors."""
         self._launch()
 
-    def flush(self):
-        """Launch what is left and make the current stream wait for every outstanding all-reduce.  MUST run between
-        ``backward()`` and the optimiser step (bench.py does; a training script calls ``encoder.grad_sync.flush()``)."""
-        self._launch()
+    def join(self):
+        """Current stream waits for every all-reduce issued so far."""
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+
+    def end_of_backward(self):
+        """Called by the trunk when it has no more gradients: tail bucket out; join unless the harness deferred it."""
+        self._launch()
+        for b, c in enumerate(self._count):          # a bucket some of whose slices never came (frozen mid-way): reduce what there is
+            if self._pending[b] != c:
+                self._pending[b] = c
+                events, self._bevents[b] = self._bevents[b], []
+                self._reduce_on_side(self._flat[b], events, [])
+        if not self.defer_join:
+            self.join()
+
+    def flush(self):
+        """Launch what is left and make the current stream wait for every outstanding all-reduce.  With ``defer_join`` this MUST
+        run between ``backward()`` and the optimiser step (bench.py does)."""
+        self._launch()
+        self.join()
 
     def reduce_now(self, tensors):
         """Blocking-order average of a few small tensors (lens coefficients) on the current stream."""

@@ -227,30 +227,56 @@ class _TrunkFn(torch.autograd.Function):
             boff[0] += 64 * C
             return v
 
+        # Data-parallel runs (enc.grad_sync): the trainable gradients live in pre-flattened buckets (dist_sync.GradSync.attach);
+        # the kernels below write straight into a parameter's slice, the trunk sets param.grad to that slice itself and returns
+        # nothing for it to autograd, and a bucket is all-reduced (side stream) as soon as its last slice is written.  With
+        # gradients already accumulated in .grad (zero_grad(set_to_none=False), micro-batching) the slices cannot become the
+        # gradient: plain tensors are produced, averaged on the current stream at the end, and returned to autograd.
+        sync = enc.grad_sync
+        bucketed = False
+        if sync is not None:
+            order = []
+            for blk_ in reversed(enc._blocks):
+                for rec_ in (blk_[2], blk_[1], blk_[0], blk_[3]):
+                    if rec_ is not None:
+                        order += [rec_.bn.weight, rec_.bn.bias, rec_.conv.weight]
+            order = [p_ for p_ in order if p_.requires_grad]
+            bucketed = all(p_.grad is None for p_ in order)
+            if bucketed:
+                sync.attach(order)
+        loose = []                                            # gradients to average on the current stream (non-bucketed sync)
+
+        def deliver(p, t):
+            if bucketed:
+                p.grad = t                                    # t IS the bucket slice
+                sync.mark_ready(p)
+            else:
+                grads[p] = t
+                if sync is not None:
+                    loose.append(t)
+
         def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None, sums2=None):
             trainable = rec.conv.weight.requires_grad
-            gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=rec.bn.weight.requires_grad,
+            affine = rec.bn.weight.requires_grad
+            oa = (sync.grad_view(rec.bn.weight).view(-1), sync.grad_view(rec.bn.bias).view(-1)) if (bucketed and affine) else None
+            gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=affine,
                                          part=bn_part(xraw.shape[-1]) if sums is None else sums, part_ready=sums is not None,
-                                         sums2=sums2)
-            sync = enc.grad_sync
+                                         sums2=sums2, out_affine=oa)
             if trainable:
+                w = rec.conv.weight
+                dst = sync.grad_view(w) if bucketed else None
                 if side is not None:
                     ev = torch.cuda.Event(); ev.record()
                     with torch.cuda.stream(side):
                         side.wait_event(ev)
-                        grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch)
+                        dw = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst)
                         gx.record_stream(side); xin.record_stream(side)
-                        if sync is not None:
-                            sync.push(grads[rec.conv.weight])
+                        deliver(w, dw)
                 else:
-                    grads[rec.conv.weight] = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch)
-                    if sync is not None:
-                        sync.push(grads[rec.conv.weight])
-            if rec.bn.weight.requires_grad:
-                grads[rec.bn.weight], grads[rec.bn.bias] = dg, db
-                if sync is not None:
-                    sync.push(dg)
-                    sync.push(db)
+                    deliver(w, co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst))
+            if affine:
+                deliver(rec.bn.weight, dg)
+                deliver(rec.bn.bias, db)
             return gx, gpre
 
         # Gradients between blocks travel PRE-MASKED by the ReLU of the tensor they belong to: the mask of a block's output
@@ -320,12 +346,16 @@ class _TrunkFn(torch.autograd.Function):
             gx0, _, dg, db = co.bn_bwd(gpre0, None, raw0, c0, False, want_affine=st.bn.weight.requires_grad, part=bn_part(64))
             if st.bn.weight.requires_grad:
                 grads[st.bn.weight], grads[st.bn.bias] = dg, db
+                if sync is not None:
+                    loose += [dg, db]
             if needs_img:
                 g_img = co.stem_dgrad(gx0, st.wd(tok))
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-        if enc.grad_sync is not None:
-            enc.grad_sync.launch_pending()       # the tail bucket starts now; the caller flush()es before optimizer.step()
+        if sync is not None:
+            if loose:
+                sync.reduce_now(loose)           # accumulation mode: averaged in stream order, then handed to autograd
+            sync.end_of_backward()               # tail bucket out; joins the all-reduce stream unless the harness defers it (flush())
         return (None, g_img) + tuple(grads.get(p) for p in enc._param_list())
 
 

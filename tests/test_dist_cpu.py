@@ -40,6 +40,19 @@ def _worker(rank, world, port, ret):
         sync.push(g)
     sync.flush()
     ok = all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(local, full)) and sync.launched >= 2
+    # the pre-flattened path: gradients written into bucket slices, reduced in place when a bucket's last slice is marked
+    ps = [torch.nn.Parameter(t.clone()) for t in w]
+    sync2 = GradSync(bucket_mb=0.01)
+    sync2.attach(list(reversed(ps)))
+    local2 = grads_for(data[rank * 4:(rank + 1) * 4])
+    for p, g in reversed(list(zip(ps, local2))):
+        v = sync2.grad_view(p)
+        v.copy_(g)
+        p.grad = v
+        sync2.mark_ready(p)
+    sync2.end_of_backward()
+    ok = ok and sync2.launched >= 2 and all(torch.allclose(p.grad, b, rtol=1e-5, atol=1e-6) for p, b in zip(ps, full))
+    ok = ok and all(p.grad.data_ptr() == sync2.grad_view(p).data_ptr() for p in ps)
     m = torch.tensor([float(rank + 1)])
     dist.all_reduce(m, op=dist.ReduceOp.MAX)         # the scalar exchange of Lens.py:312 (global_max_sync)
     ret[rank] = bool(ok and m.item() == world)

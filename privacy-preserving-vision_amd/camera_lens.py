@@ -306,6 +306,14 @@ class OpticsZernike(nn.Module):
             noise = noise.contiguous()
         use_m1 = prueba in ("1", "3")
         use_m2 = prueba in ("2", "3")
+        if use_m1 or use_m2:
+            # the kernels index the masks as [patch, patch, 3] through raw pointers: a hard-wired 256^2 mask (Lens.py:111-127) with
+            # another patch size would be read with the wrong stride -- the reference fails on the broadcast there, so do we
+            P = self.patch_size
+            for m in ((self.mask_1,) if use_m1 else ()) + ((self.mask_2,) if use_m2 else ()):
+                if tuple(m.shape) != (P, P, 3) or m.dtype != torch.float64 or m.device != self.device:
+                    raise ValueError(f"prueba={prueba!r} needs mask_1 / mask_2 of shape ({P}, {P}, 3) float64 on {self.device}; got "
+                                     f"{tuple(m.shape)} {m.dtype} (the reference's masks are hard-wired to 256 x 256, Lens.py:111-127)")
         psf_n, psf_m, loss = _IcPsfFn.apply(coeffs, noise, self, use_m1, use_m2)
         psf = psf_m if use_m2 else psf_n
         sensor_img = _IcSensorFn.apply(input_img.to(torch.float32), psf, self)

@@ -48,10 +48,13 @@ class Attention(nn.Module):
 
     def forward(self, encoder_out, decoder_hidden):
         """encoder_out [s,P,E] (any strides, e.g. the beam search's expand()), decoder_hidden [s,D] -> (awe [s,E], alpha [s,P])."""
-        if torch.is_grad_enabled() and (encoder_out.requires_grad or decoder_hidden.requires_grad
-                                        or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("ppv_amd Attention.forward is the inference step (eval/caption.py); training goes through "
-                                      "DecoderWithAttention.forward (run beam search under torch.no_grad())")
+        # The reference's beam-search scripts call this outside torch.no_grad() (eval/caption.py:93, eval_total.py:121): the step
+        # runs under an internal no_grad and returns detached tensors (training goes through DecoderWithAttention.forward).
+        if torch.is_grad_enabled() and (encoder_out.requires_grad or decoder_hidden.requires_grad) and not getattr(self, "_warned", False):
+            import warnings
+            warnings.warn("ppv_amd Attention.forward is the inference step: its outputs carry no autograd history "
+                          "(training goes through DecoderWithAttention.forward)")
+            self._warned = True
         if not encoder_out.is_cuda:
             raise RuntimeError("ppv_amd Attention runs on an MI355X (cuda tensors); no CPU path")
         with torch.no_grad():

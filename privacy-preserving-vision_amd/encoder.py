@@ -79,9 +79,10 @@ class _ConvRec:
                 self._wt = co.weight_layout(w.detach(), 0)
                 self._ver_t = token
             return self._wt
-        if self._wt is None or self._ver_t != w._version or self._wt.device != w.device:
+        key = (w._version, w.data_ptr())             # `.data = ...` swaps the storage without a version bump
+        if self._wt is None or self._ver_t != key or self._wt.device != w.device:
             self._wt = co.stem_weight_layout(w.detach(), 0) if self.stem else co.weight_layout(w.detach(), 0)
-            self._ver_t = w._version
+            self._ver_t = key
         return self._wt
 
     def wd(self, token=0):
@@ -93,17 +94,22 @@ class _ConvRec:
                 self._wd = co.weight_layout(w.detach(), 1)
                 self._ver_d = token
             return self._wd
-        if self._wd is None or self._ver_d != w._version or self._wd.device != w.device:
+        key = (w._version, w.data_ptr())
+        if self._wd is None or self._ver_d != key or self._wd.device != w.device:
             self._wd = co.stem_weight_layout(w.detach(), 1) if self.stem else co.weight_layout(w.detach(), 1)
-            self._ver_d = w._version
+            self._ver_d = key
         return self._wd
+
+    def invalidate(self):
+        self._wt = self._wd = None
 
 
 def _bn_coef(rec, stat_part, count):
     bn = rec.bn
     if bn.training:
-        return co.bn_finalize(stat_part, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                              bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+        # momentum=None is torch's cumulative moving average: factor 1 / (batches seen, this one included)
+        mom = bn.momentum if bn.momentum is not None else 1.0 / (int(bn.num_batches_tracked) + 1)
+        return co.bn_finalize(stat_part, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, mom, bn.eps)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight.detach() * invstd
     return torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
@@ -116,6 +122,10 @@ class _TrunkFn(torch.autograd.Function):
     def forward(ctx, enc, images, *params):
         images = images.contiguous().float()
         B, _, H, W = images.shape
+        if H % 32 or W % 32:
+            # stem /2, max-pool /2, three stride-2 blocks: the kernels' tile geometry (and the BatchNorm sample counts) assume
+            # every stage halves exactly; torchvision would floor odd sizes (the reference only feeds 256 x 256, datasets.py:46)
+            raise ValueError(f"ppv_amd Encoder: image height and width must be multiples of 32, got {H} x {W}")
         dev = images.device
         train = enc.resnet[1].training
         saved = {}
@@ -429,6 +439,25 @@ class Encoder(nn.Module):
                 r.wl, r.wl_idx = wl, i
             object.__setattr__(self, "_wl", wl)
         wl.refresh()
+
+    def invalidate_weight_cache(self):
+        """Drop the cached bf16 layouts of the FROZEN convolutions (stem, layer1, everything under fine_tune(False)).  They are
+        keyed on the parameter's version counter and storage pointer, which in-place writes through ``p.data`` (EMA, weight
+        surgery) do not change; train() / eval() / load_state_dict() call this, call it yourself after such a write."""
+        self._stem.invalidate()
+        for blk in self._blocks:
+            for r in blk:
+                if r is not None:
+                    r.invalidate()
+
+    def train(self, mode=True):
+        self.invalidate_weight_cache()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weight_cache()
+        return out
 
     def prefetch_weight_layouts(self):
         """Optional: convert the trainable conv weights to their bf16 GEMM layouts NOW, on the current stream, for the next

@@ -225,3 +225,52 @@ def test_full_resnet101_odd_batches_and_sizes(B, H):
     with torch.no_grad():
         a, b = enc(img.detach()), enc(img.detach())
     assert torch.equal(a, b)
+
+
+def test_sizes_that_do_not_halve_exactly_are_refused():
+    """r1 advisor: 200 x 200 silently mis-scaled the BatchNorm statistics (floor-divided stage sizes against the convs' true
+    output sizes).  The reference only feeds 256 x 256 (datasets.py:46); other sizes must be multiples of 32 or raise."""
+    from ppv_amd.encoder import Encoder
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    with pytest.raises(ValueError, match="multiples of 32"):
+        enc(torch.rand(1, 3, 200, 200, device="cuda"))
+    assert enc(torch.rand(1, 3, 96, 160, device="cuda")).shape == (1, 36, 36, 2048)
+
+
+def test_frozen_weight_layouts_follow_data_writes_after_invalidate():
+    """Frozen convs cache their bf16 layouts; a write through ``.data`` (EMA, weight surgery) bumps no version counter:
+    invalidate_weight_cache() (also called by train() / eval() / load_state_dict()) makes the next forward see it."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().eval()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        a = enc(img)
+        enc.resnet[4][0].conv1.weight.data.mul_(0.5)             # layer1: frozen
+        enc.invalidate_weight_cache()
+        b = enc(img)
+        enc.resnet[4][0].conv1.weight.data.mul_(2.0)
+        enc.eval()                                               # eval() / train() refresh too
+        c = enc(img)
+    assert not torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_momentum_none_is_the_cumulative_average():
+    from ppv_amd.encoder import Encoder
+    from oracle.resnet import Encoder as OEncoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    ref = OEncoder(layers=(1, 1, 1, 1))
+    ref.load_state_dict({k: v.detach().cpu() for k, v in enc.state_dict().items()})
+    ref.train()
+    for m in list(enc.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = None
+    for s in range(3):
+        img = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(10 + s))
+        with torch.no_grad():
+            enc(img.cuda())
+            ref(img)
+    a, b = enc.resnet[1].running_mean.cpu(), ref.resnet[1].running_mean                  # stem BN: not yet touched by trunk chaos
+    assert ((a - b).abs().max() / b.abs().max()).item() < 2e-2
+    assert int(enc.resnet[1].num_batches_tracked) == 3

@@ -481,6 +481,82 @@ class Encoder(nn.Module):
         out._ppv_cells = cells             # the 8x8 map behind the up-sampled output (consumed by ppv_amd.decoder, ignored otherwise)
         return out
 
+    # ------------------------------------------------------------------ fp32-accurate forward (parity instrument, not the product path)
+    @torch.no_grad()
+    def forward_fp32_accurate(self, images, taps=None):
+        """The same trunk with f32 activations end to end, for parity against the UN-ROUNDED fp32 reference (north_star:
+        "conv activations within 1e-3 rel fp32"; the product stores bf16 activations, which a 101-layer train-mode-BN network at
+        random initialisation amplifies far beyond that, see tests/test_encoder_fp32_gpu.py).
+
+        Every convolution still runs on the hand-written MFMA kernel, as three bf16 products accumulated in f32:
+        [x_hi | x_lo | x_hi] x [W_hi | W_hi | W_lo] (ppv_bn_act_split3 fuses BatchNorm + ReLU + the split, as in ppv_amd.fan);
+        the product error drops from 2^-9 to about 2^-16.  Batch statistics, the residual add and the pools are f32 torch
+        element-wise ops on the device (train-mode BatchNorm: biased variance of the batch, models.py:31-41 / train.py:245;
+        running statistics are NOT updated).  Forward only.  ``taps``: optional list that receives every block's output
+        [B,H,W,C] f32 (stem pool output first)."""
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+        if not images.is_cuda:
+            raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
+        x = images.float().permute(0, 2, 3, 1).contiguous()                                  # NHWC f32
+        train = self.resnet[1].training
+
+        def w3(w):
+            w = w.detach().float()
+            hi = w.bfloat16().float()
+            lo = (w - hi).bfloat16().float()
+            w3_ = torch.cat([hi, hi, lo], dim=1)
+            cin3 = (w3_.shape[1] + 63) // 64 * 64
+            if cin3 != w3_.shape[1]:
+                w3_ = torch.nn.functional.pad(w3_, (0, 0, 0, 0, 0, cin3 - w3_.shape[1]))
+            return co.weight_layout(w3_.contiguous(), 0)
+
+        def split3(t, coef, relu):
+            B_, H_, W_, C_ = t.shape
+            cp = (3 * C_ + 63) // 64 * 64
+            y = torch.empty((B_, H_, W_, cp), dtype=torch.bfloat16, device=t.device)
+            check(_lib.lib().ppv_bn_act_split3(ptr(t), ptr(coef), ptr(y), B_ * H_ * W_, C_, cp, int(relu), C_, stream_ptr()),
+                  "ppv_bn_act_split3")
+            return y
+
+        def coef_of(bn, t):
+            if train:
+                mean = t.mean(dim=(0, 1, 2), dtype=torch.float64)
+                var = (t.double() - mean).square().mean(dim=(0, 1, 2))
+            else:
+                mean, var = bn.running_mean.double(), bn.running_var.double()
+            scale = bn.weight.detach().double() / torch.sqrt(var + bn.eps)
+            return torch.stack([scale, bn.bias.detach().double() - mean * scale]).float().contiguous()
+
+        def conv(t, coef, relu, rec):
+            """act(bn(t)) -> conv, f32 in / f32 out"""
+            return co.conv_fwd(split3(t, coef, relu), w3(rec.conv.weight), rec.stride, rec.pad, out_f32=True)
+
+        st = self._stem
+        x = torch.nn.functional.pad(x, (0, 5))                                               # 3 -> 8 channels (vector split)
+        raw = co.conv_fwd(split3(x, None, False), w3(torch.nn.functional.pad(st.conv.weight.detach(), (0, 0, 0, 0, 0, 5))), 2, 3,
+                          out_f32=True)
+        c = coef_of(st.bn, raw)
+        y = torch.relu(raw * c[0] + c[1])
+        y = torch.nn.functional.max_pool2d(y.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        if taps is not None:
+            taps.append(y)
+        for r1, r2, r3, rd in self._blocks:
+            x1 = conv(y, None, False, r1)
+            x2 = conv(x1, coef_of(r1.bn, x1), True, r2)
+            x3 = conv(x2, coef_of(r2.bn, x2), True, r3)
+            c3 = coef_of(r3.bn, x3)
+            if rd is not None:
+                xd = conv(y, None, False, rd)
+                cd = coef_of(rd.bn, xd)
+                idn = xd * cd[0] + cd[1]
+            else:
+                idn = y
+            y = torch.relu(x3 * c3[0] + c3[1] + idn)
+            if taps is not None:
+                taps.append(y)
+        return torch.nn.functional.adaptive_avg_pool2d(y.permute(0, 3, 1, 2), self.enc_image_size).permute(0, 2, 3, 1).contiguous()
+
     def fine_tune(self, fine_tune=True):
         """models.py:43-54: freeze everything, then un-freeze children [5:] (layer2..4)."""
         for p in self.resnet.parameters():

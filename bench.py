@@ -190,21 +190,50 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     return step, enc_params + cam_params
 
 
+def _latest_profile(suffix):
+    """profiles/rNN<suffix> of the highest round that has one (the PMC passes cannot run inside this process: they are collected
+    by tools/profile_round.sh on the same workload and committed)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)):
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def _step_hbm(sec_per_step):
     """Whole-step HBM view: bytes per step from the committed PMC passes (same workload) over the measured step time."""
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pmc = _latest_profile("_pmc_traffic.json")
     try:
         d = json.load(open(pmc))
         gb = d["total_fetch_GB_per_step"] + d["total_write_GB_per_step"]
     except Exception:
         return None
     tbs = gb / 1e3 / sec_per_step
-    return {"GB_per_step_pmc": round(gb, 1), "TB_per_s": round(tbs, 2), "frac_of_8TBps_peak": round(tbs / 8.0, 3),
-            "frac_of_6.3TBps_measured_copy_rate": round(tbs / 6.3, 3)}
+    return {"GB_per_step_pmc": round(gb, 1), "pmc_file": os.path.basename(pmc), "TB_per_s": round(tbs, 2),
+            "frac_of_8TBps_peak": round(tbs / 8.0, 3), "frac_of_6.3TBps_measured_copy_rate": round(tbs / 6.3, 3)}
+
+
+# launch class (ppv_amd.convops labels) -> the kernel instantiations that serve it, as they are named in the rocprofv3 summaries
+def _class_kernels(kind):
+    tiled128 = lambda n: "conv_gemm_pipe_kernel<" in n and "conv_gemm_pipe_kernel<128, 64" not in n
+    tiled64 = lambda n: "conv_gemm_pipe_kernel<128, 64" in n or "conv_gemm_kernel<64" in n
+    return {
+        "conv_gemm<128>": lambda n: tiled128(n) and n.endswith("false, false>"),
+        "conv_gemm<128>+bn_sums": lambda n: tiled128(n) and n.endswith("false, true>"),
+        "conv_gemm<64>": lambda n: tiled64(n) and n.endswith("false, false>"),
+        "conv_gemm<64>+bn_sums": lambda n: tiled64(n) and n.endswith("false, true>"),
+        "conv1x1_stream": lambda n: "conv1x1_stream_kernel" in n,
+        "conv1x1_stream+bn_sums": lambda n: "conv1x1_stream_kernel" in n,
+        "conv_wgrad": lambda n: "conv_wgrad" in n or "wgrad_to_torch" in n,
+    }.get(kind, lambda n: False)
 
 
 def roofline_of_dominant_kernel(step):
-    """One extra instrumented step: every conv launch is bracketed by HIP events on its own stream."""
+    """One extra instrumented step: every conv launch is bracketed by HIP events on its own stream.  The DOMINANT class is the one
+    with the most device time (not the most flops: that picks the fastest kernels)."""
     import ppv_amd.convops as co
     torch.cuda.synchronize()
     co.PROFILE = []
@@ -228,47 +257,49 @@ def roofline_of_dominant_kernel(step):
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
         a[3] += nbytes
-    dom = max(agg, key=lambda k: agg[k][0])
+    dom = max(agg, key=lambda k: agg[k][1])
     fl, sec, n, by = agg[dom]
     achieved = fl / sec / 1e12
-    detail = {k: {"launches": v[2], "tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3),
-                  "compulsory_TBps": round(v[3] / v[1] / 1e12, 2)} for k, v in agg.items()}
+    detail = {k: {"launches": v[2], "tflops": round(v[0] / v[1] / 1e12, 1), "frac_of_peak": round(v[0] / v[1] / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
+                  "ms": round(v[1] * 1e3, 3), "compulsory_TBps": round(v[3] / v[1] / 1e12, 2)} for k, v in agg.items()}
+    all_fl, all_sec = sum(v[0] for v in agg.values()), sum(v[1] for v in agg.values())
     # the class's own roofline: arithmetic intensity against compulsory bytes (every operand and result once)
     ai = fl / by if by else None
     attainable = min(PEAK_BF16_DENSE_TFLOPS, ai * 8.0) if ai else None          # 8 TB/s HBM3E
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # HBM bytes per launch and MFMA-busy fraction of the dominant class from the latest committed PMC passes (rocprofv3 --pmc,
     # separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md); PMC cannot be collected inside this process
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc) and dom == "conv_gemm<128>":
-        try:
-            pk = json.load(open(pmc))["per_kernel"]
-            tot_b = tot_n = 0.0
-            for name, v in pk.items():          # every plain instantiation that serves the 128-column class (the
-                # "+bn_sums" instantiations <..., false, true> are their own class: they also carry a BN-backward reduction)
-                if ("conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name) and name.endswith("false, false>"):
-                    tot_b += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches_2steps"]
-                    tot_n += v["launches_2steps"]
-            traffic = round(tot_b / tot_n) if tot_n else None
-        except Exception:
-            traffic = None
-    mfma_busy = None
-    mu = os.path.join(ROOT, "profiles", "r01_mfma_util.json")    # SQ_VALU_MFMA_BUSY_CYCLES pass (tools/profile_round.sh)
-    if os.path.exists(mu) and dom == "conv_gemm<128>":
-        try:
-            pk = json.load(open(mu))["per_kernel"]
-            num = den = 0.0
-            for name, v in pk.items():
-                if ("conv_gemm_pipe_kernel<256, 128" in name or "conv_gemm_pipe_kernel<128, 128" in name) and name.endswith("false, false>"):
-                    num += v["mfma_busy_frac"] * v["avg_duration_us"] * v["launches"]
-                    den += v["avg_duration_us"] * v["launches"]
-            mfma_busy = round(num / den, 4) if den else None
-        except Exception:
-            mfma_busy = None
-    return {"bound": "mfma", "kernel": dom, "mfma_busy_frac_pmc": mfma_busy,
+    match = _class_kernels(dom)
+    traffic = mfma_busy = None
+    pmc_file, mu_file = _latest_profile("_pmc_traffic.json"), _latest_profile("_mfma_util.json")
+    try:
+        pk = json.load(open(pmc_file))["per_kernel"]
+        tot_b = tot_n = 0.0
+        for name, v in pk.items():
+            if match(name):
+                tot_b += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches_2steps"]
+                tot_n += v["launches_2steps"]
+        if dom == "conv_wgrad" and tot_n:                       # its slab-reduce launches belong to the same conv_wgrad() call
+            tot_n = sum(v["launches_2steps"] for name, v in pk.items() if match(name) and "wgrad_to_torch" not in name)
+        traffic = round(tot_b / tot_n) if tot_n else None
+    except Exception:
+        traffic = None
+    try:
+        pk = json.load(open(mu_file))["per_kernel"]
+        num = den = 0.0
+        for name, v in pk.items():
+            if match(name):
+                num += v["mfma_busy_frac"] * v["avg_duration_us"] * v["launches"]
+                den += v["avg_duration_us"] * v["launches"]
+        mfma_busy = round(num / den, 4) if den else None
+    except Exception:
+        mfma_busy = None
+    return {"bound": "mfma", "kernel": dom, "chosen_by": "largest share of device time among the MFMA launch classes",
+            "mfma_busy_frac_pmc": mfma_busy, "pmc_files": [os.path.basename(f) for f in (pmc_file, mu_file) if f],
             "measured_in": "one extra step with every launch serialised on one stream (kernel alone on the device)", "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
             "avg_launch_us": round(sec / n * 1e6, 2),
+            "all_mfma_kernels": {"tflops": round(all_fl / all_sec / 1e12, 1), "frac_of_peak": round(all_fl / all_sec / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
+                                 "ms_per_step": round(all_sec * 1e3, 3), "algorithmic_TFLOP_per_step": round(all_fl / 1e12, 3)},
             "hbm_view": None if not by else {"compulsory_bytes_per_launch": round(by / n), "achieved_TBps": round(by / sec / 1e12, 2),
                                              "frac_of_8TBps": round(by / sec / 8e12, 3), "flop_per_byte": round(ai, 1),
                                              "attainable_TFLOPs_at_this_intensity": round(attainable, 1),

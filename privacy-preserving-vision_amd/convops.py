@@ -116,6 +116,12 @@ def red_supported(rows, C):
     return C % 128 == 0 or (C % 64 == 0 and rows >= 128 * 1024)
 
 
+def _stream_kernel(K, N, R, S, div, addend, out_f32):
+    """Mirror of ppv_conv_gemm's automatic rule (csrc/conv_gemm.hip / conv_stream.hip): which launches the streaming 1x1 kernel
+    takes -- only used to label launches for bench.py's per-class roofline."""
+    return R == 1 and S == 1 and div == 1 and K in (64, 128, 256) and N % 64 == 0 and N >= 2 * K and addend is not None and not out_f32
+
+
 def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=None, red=None):
     """g [B,Ho,Wo,Cout] bf16, wd [Cin,R,S,Cout] bf16 (flipped) -> grad wrt the conv input [B,H,W,Cin] (+ addend);
     relu_bits: (conv input > 0) bit mask from bn_act(..., want_bits=True) when that input is a ReLU output -> lanes whose bit
@@ -128,6 +134,8 @@ def conv_dgrad(g, wd, stride, pad, in_hw, addend=None, out_f32=False, relu_bits=
     H, W = in_hw
     out = torch.empty((B, H, W, Cin), dtype=F32 if out_f32 else BF16, device=g.device)
     kind = "conv_gemm<128>" if Cin % 128 == 0 else "conv_gemm<64>"
+    if _stream_kernel(Cout, Cin, R, S, stride, addend, out_f32):
+        kind = "conv1x1_stream"
     if red is not None:
         xr, part = red[0], red[1]
         rcoef = red[2] if len(red) > 2 else None

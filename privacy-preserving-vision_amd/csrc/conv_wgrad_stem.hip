@@ -331,6 +331,224 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
             }
 }
 
+// ----------------------------------------------------------------------------- streamed weight gradient (one tap per workgroup)
+// conv_wgrad_pipe_kernel<128, 2> keeps ONE 32-KB stage in flight per workgroup: with ~2 us from request to landing under load it
+// is latency-bound (tools/bench_wgrad.py: 53 us for the layer-3 1x1 shapes against 14 us of HBM time and 16 us of L2 -> LDS fill),
+// and deeper rings of the same form did not help because every stage costs all waves a vmcnt wait and a barrier.  Here the roles
+// are split as in conv_stream.hip: 4 loader waves keep a ring of NSLOT 32-row stages full (global_load_lds, run-ahead bounded only
+// by free slots), NCW consumer waves (64 n x 64 c each) read transposed fragments and issue MFMAs; progress travels in per-wave
+// LDS words, there is no barrier in the m loop, so the consumers never wait for a request they did not issue.
+// MEASURED (tools/bench_wgrad.py, tools/wgrad_timeline.py, B = 128): NOT faster, kept as variant 7 only.  The stamps show stages
+// landing every 1.6 us per CU whatever the flight depth (2 stages or 5): 24 KB per 1.6 us = 15 GB/s per CU, i.e. the CU's LDS-DMA
+// path takes ~65 ns per 1-KB global_load_lds instruction from HBM-resident rows, and four loader waves do not add up (the guide's
+// one-loader figure is 25 GB/s).  At 256 workgroups the layer-3 1x1 shapes take 69 us against 65-70 us for the pipelined kernel,
+// and in the whole step (weight gradients beside the data-gradient chain) the 147-KB ring that keeps a CU to itself costs 4-8 %
+// (4769 / 4552 images/s at 256 / 384 workgroups against 4963 with the 64-KB two-stage ring).
+constexpr int WS_NLW = 4;
+typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef PPV_STAMPS   // diagnostic build (csrc/build_stamps.sh, tools/wgrad_timeline.py): phase stamps of consumer wave 0 and loader wave 0
+extern __device__ unsigned long long* g_stamps;
+#define WS_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define WS_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WS_STAMP_FLUSH(base, who) do { if (g_stamps && threadIdx.x == (who)) { for (int i_ = 0; i_ < 8; ++i_) g_stamps[(long)blockIdx.x * 16 + (base) + i_] = stamp_[i_]; } } while (0)
+#else
+#define WS_STAMP_DECL do { } while (0)
+#define WS_STAMP(i) do { } while (0)
+#define WS_STAMP_FLUSH(base, who) do { } while (0)
+#endif
+
+template <int TN>
+__global__ __launch_bounds__((TN / 32 + WS_NLW) * 64, (TN / 32 + WS_NLW) / 4) void conv_wgrad_stream_kernel(
+    const bf16_t* __restrict__ G, const bf16_t* __restrict__ X, float* __restrict__ dW, const bf16_t* __restrict__ zero_page, WgradGeom g) {
+    constexpr int NCW = TN / 32, NH = TN / 128;                           // consumer waves (wn 0..TN/64-1, wc 0..1); 128-column halves of G
+    constexpr int HALF = 32 * 256;                                        // one [32 m][128] bf16 tile
+    constexpr int STAGE = (NH + 1) * HALF;                                // G halves, then the X tile
+    constexpr int NSLOT = TN == 256 ? 6 : 8;                              // 144 KB / 128 KB of ring
+    constexpr int NI = (NH + 1) * 8, LI = NI / WS_NLW;                    // 1-KB LDS-DMA instructions per stage / per loader wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile unsigned* sLanded = reinterpret_cast<volatile unsigned*>(smem + NSLOT * STAGE);   // [4] stages each loader wave has landed
+    volatile unsigned* sDone = sLanded + 4;                                                      // [NCW] stages each consumer has read
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctiles = g.Cs / 128;
+    const int tiles_y = g.R * g.S * ctiles, tiles = (g.N / TN) * tiles_y;
+    int zslice, tl;
+    if (g.xcd_group) {                                                    // every tile of one m-slice on the same XCD (G / X rows from its L2)
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        zslice = (idx / tiles) * 8 + xcd;
+        tl = idx % tiles;
+    } else {
+        zslice = blockIdx.x / tiles;
+        tl = blockIdx.x % tiles;
+    }
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % (g.N / TN)) * TN, by = tl / (g.N / TN);
+    const int tap = by / ctiles, c0 = (by % ctiles) * 128;
+    const int r = tap / g.S, s = tap % g.S;
+    const long m_begin = (long)zslice * g.stages_per_split * 32;          // stages of 32 rows here
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 32);
+    const int nst = (int)((m_end - m_begin + 31) / 32);
+    if (nst <= 0) return;
+    WS_STAMP_DECL;
+    WS_STAMP(0);
+    if (tid < 4 + NCW) sLanded[tid] = 0;
+    __syncthreads();
+
+    if (wave >= NCW) {
+        // ------------------------------------------------------------ loader waves
+        const int lw = wave - NCW;
+        const int rli = lane >> 4, lch = lane & 15;
+        const int HoWo = g.Ho * g.Wo;
+        const float rcp_howo = 1.0f / (float)HoWo, rcp_wo = 1.0f / (float)g.Wo;
+        const long zdG = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(G);
+        const long zdX = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+        const bool flat = g.R == 1 && g.S == 1 && g.st == 1 && g.pad == 0;
+        // Event loop: issue stages as far ahead as the ring has free slots (up to NSLOT - 1 stages = 120 KB in flight per CU: what
+        // it takes to cover 2-3 us of loaded HBM latency at the 40-70 GB/s a CU can take in), publish a stage when its requests
+        // have landed (counted vmcnt: stages land in issue order).  The first version published stage t - 1 right after issuing
+        // stage t, which capped the flight depth at two stages: 1.5 us per stage instead of 0.35.
+        auto wait_oldest = [&](int younger) {                                // all but the `younger` youngest stages' requests done
+            switch (younger) {
+                case 0: wg_wait_vmcnt_le<0>(); break;
+                case 1: wg_wait_vmcnt_le<LI>(); break;
+                case 2: wg_wait_vmcnt_le<2 * LI>(); break;
+                case 3: wg_wait_vmcnt_le<3 * LI>(); break;
+                case 4: wg_wait_vmcnt_le<4 * LI>(); break;
+                case 5: wg_wait_vmcnt_le<5 * LI>(); break;
+                case 6: wg_wait_vmcnt_le<6 * LI>(); break;
+                default: wg_wait_vmcnt_le<7 * LI>(); break;
+            }
+        };
+        static_assert(7 * LI < 64, "vmcnt is a 6-bit counter");
+        auto consumed = [&]() {
+            const ws_u32x4 a = *reinterpret_cast<volatile const ws_u32x4*>(sDone);
+            unsigned lo = min(min(a.x, a.y), min(a.z, a.w));
+            if (NCW == 8) {
+                const ws_u32x4 b = *reinterpret_cast<volatile const ws_u32x4*>(sDone + 4);
+                lo = min(lo, min(min(b.x, b.y), min(b.z, b.w)));
+            }
+            return (int)__builtin_amdgcn_readfirstlane(lo);
+        };
+        int issued = 0, published = 0, done = 0, slot = 0;
+        while (published < nst) {
+            if (issued < nst && issued >= done + NSLOT) done = consumed();   // ring looks full: refresh the consumers' progress
+            if (issued < nst && issued < done + NSLOT && issued - published < 8) {
+                asm volatile("" ::: "memory");
+                char* sb = smem + slot * STAGE;
+                const long mb = m_begin + (long)issued * 32;
+#pragma unroll
+                for (int i = 0; i < LI; ++i) {
+                    const int q = i * WS_NLW + lw;                          // instruction 0 .. NI-1: tile q / 8, rows (q % 8) * 4 ..
+                    const int tile = q >> 3, row = (q & 7) * 4 + rli;
+                    const long m = mb + row;
+                    const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+                    if (tile < NH) {
+                        const long off = (m < m_end) ? (m * g.N + n0 + tile * 128 + gch * 8) * 2 : zdG;
+                        GLDS16W(reinterpret_cast<const char*>(G) + off, sb + tile * HALF + (q & 7) * 1024);
+                    } else {
+                        long off = zdX;
+                        if (m < m_end) {
+                            if (flat) {
+                                off = (m * g.Cs + c0 + gch * 8) * 2;
+                            } else {
+                                int b, rem, ho, wo;
+                                fast_divmod((int)m, HoWo, rcp_howo, b, rem);
+                                fast_divmod(rem, g.Wo, rcp_wo, ho, wo);
+                                const int hs = ho * g.st + r - g.pad, ws = wo * g.st + s - g.pad;
+                                if (((unsigned)hs < (unsigned)g.Hs) & ((unsigned)ws < (unsigned)g.Ws))
+                                    off = ((((long)b * g.Hs + hs) * g.Ws + ws) * g.Cs + c0 + gch * 8) * 2;
+                            }
+                        }
+                        GLDS16W(reinterpret_cast<const char*>(X) + off, sb + NH * HALF + (q & 7) * 1024);
+                    }
+                }
+                slot = slot + 1 == NSLOT ? 0 : slot + 1;
+                ++issued;
+                if (issued == 1) WS_STAMP(1);
+                if (issued == 5) WS_STAMP(2);
+                continue;
+            }
+            if (published < issued) {                                        // nothing to issue right now: retire the oldest stage in flight
+                wait_oldest(issued - published - 1);
+                ++published;
+                if (lane == 0) sLanded[lw] = (unsigned)published;
+                if (published == 1) WS_STAMP(3);
+                if (published == 5) WS_STAMP(4);
+                if (published == 13) WS_STAMP(5);
+            } else {
+                __builtin_amdgcn_s_sleep(2);                                 // ring full, everything landed: the consumers are behind
+            }
+        }
+        WS_STAMP(7);
+        WS_STAMP_FLUSH(8, NCW * 64);
+        return;
+    }
+    // ---------------------------------------------------------------- consumer waves
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave >> 1, wc = wave & 1;                              // 64-column group of n, of c
+    unsigned landed = 0;
+    auto wait_landed = [&](int j) {                                       // stage j has landed (all four loader waves)
+        while (landed <= (unsigned)j) {
+            const ws_u32x4 a = *reinterpret_cast<volatile const ws_u32x4*>(sLanded);
+            landed = __builtin_amdgcn_readfirstlane(min(min(a.x, a.y), min(a.z, a.w)));
+            if (landed <= (unsigned)j) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    // one stage = one K = 32 MFMA step per wave: reads, wait, release the slot, 16 MFMAs.  No software pipelining inside a wave
+    // (the second fragment set does not fit the 168-VGPR budget of three waves per SIMD: it spilled, and scratch accesses sit in
+    // the vmcnt queue): the two consumer waves of a SIMD are not in lockstep, one's reads fly under the other's MFMAs.
+    int slot = 0;
+    for (int j = 0; j < nst; ++j) {
+        wait_landed(j);
+        if (j == 0) WS_STAMP(1);
+        if (j == 1) WS_STAMP(2);
+        if (j == 5) WS_STAMP(3);
+        if (j == 13) WS_STAMP(4);
+        const char* tg = smem + slot * STAGE + (wn >> 1) * HALF;
+        const char* tx = smem + slot * STAGE + NH * HALF;
+        s16x4 alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) tr_issue(alo[mi], ahi[mi], tg, 0, (wn & 1) * 4 + mi, lane);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) tr_issue(blo[ni], bhi[ni], tx, 0, wc * 4 + ni, lane);
+        tr_wait_all();                                                      // fragments of stage j are in registers
+        if (lane == 0) sDone[wave] = (unsigned)(j + 1);
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[mi], ahi[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bfr[ni] = tr_pack(blo[ni], bhi[ni]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);   // D[c][n]
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    }
+    WS_STAMP(5);
+    // operands swapped (x fragment in the A position): a lane's four accumulator registers are four consecutive c of one n, i.e.
+    // 16 contiguous bytes of the slab -- 16 dwordx4 stores per lane instead of 64 dword stores (the slab write of a workgroup was
+    // 128 KB of 4-byte stores: ~15 us of store issue)
+    const int fr = lane & 15, fq = lane >> 4;
+    const long wrow = (long)g.R * g.S * g.Cs;
+    float* dst = dW + (long)zslice * g.slab_elems;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + mi * 16 + fr;
+            const int c = c0 + wc * 64 + ni * 16 + fq * 4;
+            *reinterpret_cast<f32x4*>(&dst[(long)n * wrow + (long)tap * g.Cs + c]) = acc[mi][ni];
+        }
+    WS_STAMP(7);
+    WS_STAMP_FLUSH(0, 0);
+}
+
 // ----------------------------------------------------------------------------- 3x3 / stride 1 / pad 1 wgrad, taps fused
 // conv_wgrad_pipe_kernel re-reads the G rows of an m-slice once per (tap, c-tile): 18 times for the layer-3 3x3 convs, and
 // its 9 taps fetch 9 shifted copies of the same X rows -- the kernel ran at the L2->LDS rate (453 MB per launch).  Here one
@@ -883,6 +1101,19 @@ static void wgrad3_plan(long M, int N, int Cs, long* splits, int* sps) {
     *splits = (stages + *sps - 1) / *sps;
 }
 
+// m-slices of the streamed kernel (32-row stages)
+static void wgrad_stream_plan(long M, int N, int R, int S, int Cs, int* TN, long* splits, int* sps) {
+    const long stages = (M + 31) / 32;
+    const int tn = (N % 256 == 0) ? 256 : 128;
+    const int tiles = (N / tn) * (R * S * (Cs / 128));
+    long sp = (wgrad_target_wgs() + tiles - 1) / tiles;
+    if (sp > stages / 16) sp = stages / 16;
+    if (sp < 1) sp = 1;
+    *sps = (int)((stages + sp - 1) / sp);
+    *splits = (stages + *sps - 1) / *sps;
+    *TN = tn;
+}
+
 // bytes of f32 scratch ppv_conv_wgrad needs (per-slice slabs of the [N][R][S][Cs] gradient)
 size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
     int TN, sps;
@@ -900,6 +1131,12 @@ size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
         int sps3;
         wgrad3_plan(M, N, Cs, &sp3, &sps3);
         if (sp3 > splits) splits = sp3;
+    }
+    {
+        long sps_;
+        int tn_, st_;
+        wgrad_stream_plan(M, N, R, S, Cs, &tn_, &sps_, &st_);
+        if (sps_ > splits) splits = sps_;
     }
     return (size_t)splits * N * R * S * Cs * sizeof(float);
 }
@@ -946,6 +1183,30 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
         return ppv_last_error();
     }
+    if ((g_wgrad_variant & 0xff) == 7) {   // streamed kernel: loader / consumer waves, deep ring (opt-in: see its header comment)
+        int TN, sps;
+        long splits;
+        wgrad_stream_plan(g.M, N, R, S, Cs, &TN, &splits, &sps);
+        g.stages_per_split = sps;
+        g.splits = (int)splits;
+        g.slab_elems = elems;
+        g.xcd_group = (R * S == 1 && !(g_wgrad_variant & 0x100)) ? 1 : 0;
+        const int tiles = (N / TN) * (R * S * (Cs / 128));
+        const unsigned grid = g.xcd_group ? (unsigned)(8 * ((splits + 7) / 8) * tiles) : (unsigned)(splits * tiles);
+        if (TN == 256) {
+            constexpr int lds = 6 * 3 * 32 * 256 + 64;
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_stream_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+            conv_wgrad_stream_kernel<256><<<grid, 768, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        } else {
+            constexpr int lds = 8 * 2 * 32 * 256 + 64;
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_stream_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+            conv_wgrad_stream_kernel<128><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        }
+        wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)splits);
+        return ppv_last_error();
+    }
     if (variant == 4) variant = (N % 256 == 0) ? 3 : 1;
     const bool small_ring = variant == 6;                      // TN = 128, two stages (64 KB)
     if (small_ring) variant = 2;
@@ -985,7 +1246,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     return ppv_last_error();
 }
 
-// tuning / A-B hook: low byte 0 auto (= 6), 1 two-stage atomics kernel, 2 pipe TN=128 x 4 stages, 3 pipe TN=256 x 3 stages,
+// tuning / A-B hook: low byte 0 auto (= 6), 7 streamed kernel (conv_wgrad_stream_kernel) for everything but the fused-tap 3x3, 1 two-stage atomics kernel, 2 pipe TN=128 x 4 stages, 3 pipe TN=256 x 3 stages,
 // 4 = fused-tap 3x3 + (3 | 1), 6 = fused-tap 3x3 + pipe TN=128 x 2 stages; 0x100 disables XCD grouping
 int ppv_wgrad_set_variant(int v) { g_wgrad_variant = v; return PPV_OK; }
 

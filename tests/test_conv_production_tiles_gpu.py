@@ -191,6 +191,9 @@ WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> th
     (32, 32, 256, 256, 3, 1, 2),    # 3x3 through the one-tap-per-workgroup kernel (128-wide, four stages)
     (16, 64, 128, 128, 3, 2, 0),    # stride-2 3x3 (first block of a layer): M = 16 384 output pixels
     (64, 32, 256, 512, 1, 2, 0),    # stride-2 projection
+    (32, 32, 256, 1024, 1, 1, 7),   # streamed kernel (loader / consumer waves), 256-wide
+    (32, 32, 1024, 128, 1, 1, 7),   # streamed kernel, 128-wide
+    (16, 64, 128, 128, 3, 2, 7),    # streamed kernel, strided taps with padding
 ]
 
 

@@ -42,6 +42,10 @@ int ppv_otf_build(const void* psf, int psf_is_f64, long sc, long sy, long sx, in
                   void* otfT, void* workspace, ppv_stream_t stream);
 int ppv_fftconv_fwd(const float* img, const void* otfT, float* out, void* signs, float* partial_max,
                     void* workspace, int B, int C, int N, int mode, int conj_otf, ppv_stream_t stream);
+/* the same on the data set's uint8 pixels, decoded as x / 255 inside the row transform (Image_Caption/datasets.py:46
+ * `imgs / 255.`; HDF5 uint8 [N,3,256,256], utils.py:94-150): the f32 copy of the batch never exists */
+int ppv_fftconv_fwd_u8(const unsigned char* img, const void* otfT, float* out, void* signs, float* partial_max,
+                       void* workspace, int B, int C, int N, int mode, int conj_otf, ppv_stream_t stream);
 int ppv_fftconv_partials_per_image(int C, int N, int mode);
 /* normalisation: Lens.py:312 (one group = whole batch) / Optics.py:128 (one group per image) */
 int ppv_group_max(const float* partial, float* out, int groups, int per_group, ppv_stream_t stream);
@@ -54,6 +58,11 @@ int ppv_fftconv_ic_bwd(const float* img, const float* g_sensor, const float* sen
                        const float* maxv, const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64,
                        long sc, long sy, long sx, float* g_img, void* workspace, int B, int C, int N,
                        ppv_stream_t stream);
+/* uint8 pixels (datasets.py:46): no gradient w.r.t. the image, g_img must be NULL */
+int ppv_fftconv_ic_bwd_u8(const unsigned char* img, const float* g_sensor, const float* sensor, const void* signs,
+                          const float* maxv, const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64,
+                          long sc, long sy, long sx, float* g_img, void* workspace, int B, int C, int N,
+                          ppv_stream_t stream);
 
 /* ---- IC PSF generation: Image_Caption/Camera/Lens.py:158-274 (+ Utils.py:80-109,192-248,328-413) ---------
  * Z [K][RR][RR] f32 basis, coeffs [K] f32, noise [RR*RR] f32 U[0,1) (Utils.py:403), sph [RR][RR][3] c64

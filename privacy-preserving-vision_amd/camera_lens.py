@@ -108,9 +108,10 @@ class _IcSensorFn(torch.autograd.Function):
         g_img = torch.empty_like(img) if need_img else None
         ws = torch.empty(L.ppv_fftconv_bwd_workspace_bytes(B, C, N), dtype=torch.uint8, device=dev)
         sc, sy, sx = (1, P * 3, 3)       # [1,P,P,3] viewed as [C][P][P]
-        check(L.ppv_fftconv_ic_bwd(ptr(img), ptr(g), ptr(sensor), ptr(signs), ptr(m), ptr(dotcnt), ptr(otf),
-                                   ptr(g_psf), int(dtype == torch.float64), sc, sy, sx, ptr(g_img), ptr(ws),
-                                   B, C, N, stream_ptr()), "ppv_fftconv_ic_bwd")
+        bwd = L.ppv_fftconv_ic_bwd_u8 if img.dtype == torch.uint8 else L.ppv_fftconv_ic_bwd     # uint8 pixels: no image gradient
+        check(bwd(ptr(img), ptr(g), ptr(sensor), ptr(signs), ptr(m), ptr(dotcnt), ptr(otf),
+                  ptr(g_psf), int(dtype == torch.float64), sc, sy, sx, ptr(g_img), ptr(ws),
+                  B, C, N, stream_ptr()), "ppv_fftconv_ic_bwd")
         return g_img, g_psf, None
 
 
@@ -316,7 +317,9 @@ class OpticsZernike(nn.Module):
                                      f"{tuple(m.shape)} {m.dtype} (the reference's masks are hard-wired to 256 x 256, Lens.py:111-127)")
         psf_n, psf_m, loss = _IcPsfFn.apply(coeffs, noise, self, use_m1, use_m2)
         psf = psf_m if use_m2 else psf_n
-        sensor_img = _IcSensorFn.apply(input_img.to(torch.float32), psf, self)
+        # uint8 input = the data set's raw pixels (HDF5 uint8, utils.py:94-150): decoded as x / 255 inside the first FFT kernel
+        # (datasets.py:46 `imgs / 255.`), forward and backward; anything else is taken as float32 in [0, 1] like the reference
+        sensor_img = _IcSensorFn.apply(input_img if input_img.dtype == torch.uint8 else input_img.to(torch.float32), psf, self)
         np.random.uniform(low=0.001, high=0.02)                               # Lens.py:295 (RNG stream parity; value unused)
         return sensor_img, psf, coeffs, (loss if use_m1 else None)
 

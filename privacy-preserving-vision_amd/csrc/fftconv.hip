@@ -24,10 +24,13 @@
 namespace ppv {
 
 // ----------------------------------------------------------------------------- rows forward
-template <int R>
-__global__ __launch_bounds__(256) void rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out,
+// TIN = float, or unsigned char: the data set's uint8 pixels, decoded here as x / 255 (reference Image_Caption/datasets.py:46
+// `imgs / 255.`): the f32 copy of the batch (4x the bytes) never exists
+template <int R, typename TIN = float>
+__global__ __launch_bounds__(256) void rows_r2c_kernel(const TIN* __restrict__ in, float2* __restrict__ out,
                                                        const float2* __restrict__ twg, int planes, int H, int W,
                                                        int ppw) {
+    constexpr float DEC = sizeof(TIN) == 1 ? 1.0f / 255.0f : 1.0f;
     constexpr int N = 64 * R, NH = N / 2;
     __shared__ float2 s_tw[N];
     __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
@@ -43,14 +46,14 @@ __global__ __launch_bounds__(256) void rows_r2c_kernel(const float* __restrict__
         const int plane = (int)(pair / ppp), j = (int)(pair % ppp);
         const int r0 = 2 * j;
         const bool has_b = (r0 + 1) < H;
-        const float* pa = in + ((long)plane * H + r0) * W;
-        const float* pb = pa + W;
+        const TIN* pa = in + ((long)plane * H + r0) * W;
+        const TIN* pb = pa + W;
         float2 u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int n = lane + 64 * r;
-            const float a = (n < W) ? pa[n] : 0.f;
-            const float b = (has_b && n < W) ? pb[n] : 0.f;
+            const float a = (n < W) ? (float)pa[n] * DEC : 0.f;
+            const float b = (has_b && n < W) ? (float)pb[n] * DEC : 0.f;
             u[r] = make_float2(a, b);
         }
         fft_wave<R>(u, s_scr[wave], s_tw, lane);
@@ -621,8 +624,8 @@ int otf_build_t(const void* psf, int psf_is_f64, long sc, long sy, long sx, int 
     return ppv_last_error();
 }
 
-template <int R>
-int fftconv_fwd_t(const float* img, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
+template <int R, typename TIN = float>
+int fftconv_fwd_t(const TIN* img, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
                   int B, int C, int mode, int conj_otf, hipStream_t stream) {
     constexpr int N = 64 * R;
     const float2* tw = (const float2*)ppv_twiddles_f32(N);
@@ -635,7 +638,7 @@ int fftconv_fwd_t(const float* img, const void* otfT, float* out, void* signs, f
     const long pairs = (long)planes * (H / 2);
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
     const float scale = 1.0f / ((float)N * (float)N);
-    rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(img, S1, tw, planes, H, H, ppw);
+    rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, S1, tw, planes, H, H, ppw);
     cols_mul_kernel<R><<<dim3(N / 32, planes), 512, 0, stream>>>(S1, S2, (const float2*)otfT, tw, C, H, 0, H, conj_otf,
                                                                 scale);
     if (mode == 0)
@@ -646,8 +649,8 @@ int fftconv_fwd_t(const float* img, const void* otfT, float* out, void* signs, f
     return ppv_last_error();
 }
 
-template <int R>
-int fftconv_bwd_t(const float* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
+template <int R, typename TIN = float>
+int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
                   const double* dotcnt, const void* otfT, void* g_psf, int is_f64, long sc, long sy, long sx,
                   float* g_img, void* workspace, int B, int C, hipStream_t stream) {
     constexpr int N = 64 * R, NH = N / 2, P = NH;
@@ -671,7 +674,7 @@ int fftconv_bwd_t(const float* img, const float* g_sensor, const float* sensor, 
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
     rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(gr, SG, tw, planes, P, P, ppw);
     if (g_psf) {
-        rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(img, SX, tw, planes, P, P, ppw);
+        rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, SX, tw, planes, P, P, ppw);
         cols_corr_acc_kernel<R><<<dim3(N / 32, C, (B + bchunk - 1) / bchunk), 512, 0, stream>>>(SX, SG, part, tw, B, C, P, P,
                                                                                            bchunk);
         cols_inv_from_T_kernel<R><<<(unsigned)((C * NH + 3) / 4), 256, 0, stream>>>(part, S2, tw, C, (B + bchunk - 1) / bchunk,
@@ -763,6 +766,16 @@ int ppv_fftconv_fwd(const float* img, const void* otfT, float* out, void* signs,
     return PPV_ERR_BAD_SIZE;
 }
 
+// The same with uint8 pixels (decoded as x / 255 inside the row transform, datasets.py:46).
+int ppv_fftconv_fwd_u8(const unsigned char* img, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
+                       int B, int C, int N, int mode, int conj_otf, hipStream_t stream) {
+    if (!img || !otfT || !out || !workspace) return PPV_ERR_NULL;
+    if (mode == 0 && !signs) return PPV_ERR_NULL;
+    if (N == 512) return fftconv_fwd_t<8, unsigned char>(img, otfT, out, signs, partial_max, workspace, B, C, mode, conj_otf, stream);
+    if (N == 256) return fftconv_fwd_t<4, unsigned char>(img, otfT, out, signs, partial_max, workspace, B, C, mode, conj_otf, stream);
+    return PPV_ERR_BAD_SIZE;
+}
+
 int ppv_fftconv_partials_per_image(int C, int N, int mode) {
     const int H = (mode == 0) ? N / 2 : N;
     return C * (H / 2) / 16;
@@ -810,6 +823,17 @@ int ppv_fftconv_ic_bwd(const float* img, const float* g_sensor, const float* sen
     if (g_img && !otfT) return PPV_ERR_NULL;
     if (N == 512) return fftconv_bwd_t<8>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, g_img, workspace, B, C, stream);
     if (N == 256) return fftconv_bwd_t<4>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, g_img, workspace, B, C, stream);
+    return PPV_ERR_BAD_SIZE;
+}
+
+// ppv_fftconv_ic_bwd with uint8 pixels (no gradient w.r.t. the image: g_img must be null)
+int ppv_fftconv_ic_bwd_u8(const unsigned char* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
+                          const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64, long sc, long sy, long sx,
+                          float* g_img, void* workspace, int B, int C, int N, hipStream_t stream) {
+    if (!img || !g_sensor || !sensor || !signs || !maxv || !dotcnt || !workspace) return PPV_ERR_NULL;
+    if (g_img) return PPV_ERR_BAD_SIZE;
+    if (N == 512) return fftconv_bwd_t<8, unsigned char>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, nullptr, workspace, B, C, stream);
+    if (N == 256) return fftconv_bwd_t<4, unsigned char>(img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, nullptr, workspace, B, C, stream);
     return PPV_ERR_BAD_SIZE;
 }
 

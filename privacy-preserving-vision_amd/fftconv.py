@@ -26,20 +26,21 @@ def otf_build(psf_chw_view, P, N, workspace=None):
 
 
 def fftconv_fwd(img, otf, mode, conj_otf=False, workspace=None):
-    """mode 0 (IC): img [B,C,P,P] -> (|conv| [B,C,P,P], signs, partial_max);  mode 1 (FD): circular, [B,C,N,N]."""
+    """mode 0 (IC): img [B,C,P,P] -> (|conv| [B,C,P,P], signs, partial_max);  mode 1 (FD): circular, [B,C,N,N].
+    img: float32, or uint8 pixels that the row transform decodes as x / 255 (datasets.py:46)."""
     _lib.require_cuda(img, otf)
     img = img.contiguous()
     B, C, H, W = img.shape
     N = 2 * H if mode == 0 else H
-    assert H == W and otf.shape == (C, N // 2 + 1, N) and img.dtype == torch.float32
+    assert H == W and otf.shape == (C, N // 2 + 1, N) and img.dtype in (torch.float32, torch.uint8)
     dev = img.device
     ws = workspace if workspace is not None else _workspace(B, C, N, dev)
-    out = torch.empty_like(img)
+    out = torch.empty(img.shape, dtype=torch.float32, device=dev)
     ppi = _lib.lib().ppv_fftconv_partials_per_image(C, N, mode)
     partial = torch.empty(B * ppi, dtype=torch.float32, device=dev)
     signs = torch.zeros(B * C * H * (N // 128), dtype=torch.int64, device=dev) if mode == 0 else None   # row P-1 is never written
-    check(_lib.lib().ppv_fftconv_fwd(ptr(img), ptr(otf), ptr(out), ptr(signs), ptr(partial), ptr(ws), B, C, N, mode,
-                                     int(conj_otf), stream_ptr()), "ppv_fftconv_fwd")
+    fn = _lib.lib().ppv_fftconv_fwd_u8 if img.dtype == torch.uint8 else _lib.lib().ppv_fftconv_fwd
+    check(fn(ptr(img), ptr(otf), ptr(out), ptr(signs), ptr(partial), ptr(ws), B, C, N, mode, int(conj_otf), stream_ptr()), "ppv_fftconv_fwd")
     return out, signs, partial
 
 

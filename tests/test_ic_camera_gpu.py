@@ -144,3 +144,26 @@ def test_layout_a_and_optimizer_survives_checkpoint_switch():
     before = cam.zernike_coeffs_train.detach().clone()
     opt.step()
     assert not torch.equal(before, cam.zernike_coeffs_train.detach())
+
+
+def test_uint8_pixels_are_decoded_inside_the_row_transform():
+    """the data set holds uint8 [N,3,256,256] (utils.py:94-150) and the loader divides by 255 (datasets.py:46).
+    A uint8 batch handed to the camera must give the sensor image and the lens gradient of the float batch x / 255."""
+    from ppv_amd.camera_lens import OpticsZernike
+    dev = torch.device("cuda", 0)
+    cam = OpticsZernike(input_shape=[None, 128, 128, 3], device=dev, zernike_terms=36, patch_size=128, height_tolerance=2e-8,
+                        sensor_distance=0.025, wave_resolution=[448, 448], sample_interval=3e-06, coeff_layout="B")
+    with torch.no_grad():
+        cam.zernike_coeffs_train[0] = -11.0
+    u8 = torch.randint(0, 256, (3, 3, 128, 128), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+    noise = torch.rand(1, 448, 448, 1, generator=torch.Generator().manual_seed(1)).to(dev)
+    w = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(2)).to(dev)
+    s_f, _, _, _ = cam(u8.float() / 255.0, None, None, noise_u01=noise)
+    (s_f * w).sum().backward()
+    g_f = cam.zernike_coeffs_train.grad.clone()
+    cam.zernike_coeffs_train.grad = None
+    s_u, _, _, _ = cam(u8, None, None, noise_u01=noise)
+    (s_u * w).sum().backward()
+    g_u = cam.zernike_coeffs_train.grad
+    assert s_u.dtype == torch.float32 and (s_u - s_f).abs().max().item() < 2e-6 * s_f.abs().max().item()
+    assert ((g_u - g_f).norm() / g_f.norm()).item() < 1e-5

@@ -107,6 +107,14 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
 int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const float* red_coef,
                       const void* addend, const void* mask_bits, const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N,
                       int R, int S, int a, int off, int div, int red_rows, ppv_stream_t stream);
+/* RAFT SepConvGRU (Face-DeId/RAFT/core/update.py:33-77): stride-1 convolution with a rectangular kernel and separate row / column
+ * paddings (1 x 5 with (0, 2), 5 x 1 with (2, 0)); the gate arithmetic between the convolutions, NHWC f32 */
+int ppv_conv_gemm_rect(const void* X, const void* Wt, void* out, const void* zero_page, int B, int H, int W, int Cs, int N, int R,
+                       int S, int pad_h, int pad_w, int out_f32, ppv_stream_t stream);
+int ppv_gru_zr(const float* zr, int ldzr, const float* bias, const float* h, float* z, float* rh, long rows, int Ch,
+               ppv_stream_t stream);
+int ppv_gru_out(const float* q, int ldq, const float* bias, const float* z, const float* h, float* hn, long rows, int Ch,
+                ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
 int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, ppv_stream_t stream);

@@ -16,7 +16,8 @@ struct ConvGeom {
     int Ho, Wo;          // output pixels per image (GEMM rows m = (b, ho, wo))
     int N;               // GEMM columns (output channels)
     int R, S;            // taps
-    int a, off, sh;      // source step, tap offset, log2(div)
+    int a, off, sh;      // source step, tap offset (rows; columns too unless offw differs), log2(div)
+    int offw;            // tap offset of the columns (rectangular kernels: 1 x 5 / 5 x 1 of RAFT's SepConvGRU)
     int flat;            // 1x1, unit step, no offset, same grid: GEMM row m IS source pixel m (no (b, ho, wo) decomposition)
     long M;              // B * Ho * Wo
 };

@@ -22,6 +22,7 @@
 // The RED instantiations of the pipe kernel (ppv_conv_gemm_red: data-gradient launches of the trunk's backward) also take, in that
 // store loop, the sums the following BatchNorm backward needs (sum g, sum g * x per channel; optional recomputed ReLU mask), so
 // that BatchNorm's own reduce pass over the stored tensor disappears.
+#include <climits>
 #include "conv_common.h"
 
 namespace ppv {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
         const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
         const int ho = rem / g.Wo, wo = rem % g.Wo;
         a_h0[i] = ho * g.a + g.off;
-        a_w0[i] = wo * g.a + g.off;
+        a_w0[i] = wo * g.a + g.offw;
         a_pix[i] = (long)b * g.Hs * g.Ws;
     }
     const int ktaps = g.R * g.S, kc = g.Cs / BK, nk = ktaps * kc;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
             const int b = (int)(mm / HoWo), rem = (int)(mm % HoWo);
             const int ho = rem / g.Wo, wo = rem % g.Wo;
             a_h0[i] = ho * g.a + g.off;
-            a_w0[i] = wo * g.a + g.off;
+            a_w0[i] = wo * g.a + g.offw;
             a_pix[i] = b * g.Hs * g.Ws;
         }
     }
@@ -666,6 +667,7 @@ __global__ __launch_bounds__(256) void weight_layout_multi_kernel(const WLayoutD
 using namespace ppv;
 
 static int g_conv_variant = 0;
+static thread_local int g_conv_offw_override = INT_MIN;   // set by ppv_conv_gemm_rect around its call into conv_gemm_impl
 #ifdef PPV_STAMPS
 namespace ppv { __device__ unsigned long long* g_stamps = nullptr; }
 #endif
@@ -699,9 +701,9 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     if (red_x_ && (!stat_part || out_f32 || N % 64 || (red_coef && addend))) return PPV_ERR_BAD_SIZE;
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
-    g.a = a; g.off = off; g.sh = (div == 2) ? 1 : 0;
+    g.a = a; g.off = off; g.offw = (g_conv_offw_override != INT_MIN) ? g_conv_offw_override : off; g.sh = (div == 2) ? 1 : 0;
     g.M = (long)B * Ho * Wo;
-    g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
+    g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
     if (((g_conv_variant == 0 && addend && !out_f32) || g_conv_variant == 8) && conv1x1_stream_supported(g, Cs, div))
         return conv1x1_stream_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
@@ -793,6 +795,18 @@ int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part,
     if (!red_part || !red_x) return PPV_ERR_NULL;
     return conv_gemm_impl(X, Wt, out, red_part, addend, mask_bits, zero_page, red_x, red_coef, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div, 0,
                           red_rows, stream);
+}
+
+// Stride-1 convolution with a rectangular kernel and separate row / column paddings (RAFT SepConvGRU: 1 x 5 with padding (0, 2),
+// 5 x 1 with padding (2, 0); Face-DeId/RAFT/core/update.py:36-42).  X [B,H,W,Cs] bf16, Wt [N][R][S][Cs] bf16 -> out [B,H,W,N],
+// bf16 or f32 (out_f32 = 1).  Same kernels as ppv_conv_gemm.
+int ppv_conv_gemm_rect(const void* X, const void* Wt, void* out, const void* zero_page, int B, int H, int W, int Cs, int N, int R,
+                       int S, int pad_h, int pad_w, int out_f32, hipStream_t stream) {
+    g_conv_offw_override = -pad_w;
+    const int rc = conv_gemm_impl(X, Wt, out, nullptr, nullptr, nullptr, zero_page, nullptr, nullptr, B, H, W, Cs, H, W, N, R, S, 1,
+                                  -pad_h, 1, out_f32, 0, stream);
+    g_conv_offw_override = INT_MIN;
+    return rc;
 }
 
 // rows of the BN partial buffer a conv with M output pixels should use

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
 // 20-45 % faster there (tools/conv_timeline.py: per wave and step the epilogue here is an LDS round trip + stores behind the
 // MFMAs, 2.3-2.9 us against the 1.4 us a step's 32 KB of output takes at HBM rate).
 bool conv1x1_stream_supported(const ConvGeom& g, int Cs, int div) {
-    if (g.R != 1 || g.S != 1 || g.off != 0 || div != 1) return false;
+    if (g.R != 1 || g.S != 1 || g.off != 0 || g.offw != 0 || div != 1) return false;
     if ((g.M + 256) * g.N >= (1L << 31)) return false;          // 32-bit element offsets in the epilogue
     if (Cs != 64 && Cs != 128 && Cs != 256) return false;
     if (g.N % 64 || g.N < 2 * Cs) return false;                 // wide outputs only: the narrow ones are read-bound (tiled kernel)

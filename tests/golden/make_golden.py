@@ -14,6 +14,7 @@ come from ``oracle/zernike.py`` (parity unpinned vs poppy / OpenCV, see oracle/_
 Everything else that executes is the reference's code, unmodified, on torch CPU.
 """
 import math
+import zlib
 import os
 import subprocess
 import sys
@@ -288,6 +289,28 @@ def gen_decoder():
 
 
 # --------------------------------------------------------------------------- SSIM loss (Image_Caption/pytorch_ssim)
+def gen_raft_gru():
+    """RAFT's SepConvGRU (RAFT/core/update.py:33-60): the reference module with parameters filled by name, three chained updates."""
+    sys.path.insert(0, os.path.join(REF, "Face-DeId"))
+    from RAFT.core.update import SepConvGRU
+    torch.manual_seed(0)
+    gru = SepConvGRU(hidden_dim=128, input_dim=256).eval()
+    with torch.no_grad():
+        for name, t in gru.state_dict().items():
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+            t.copy_(torch.randn(t.shape, generator=g) * ((1.0 / t[0].numel()) ** 0.5 if t.dim() > 1 else 0.1))
+    h = torch.tanh(torch.randn(2, 128, 12, 20, generator=torch.Generator().manual_seed(1)))
+    x = torch.randn(2, 256, 12, 20, generator=torch.Generator().manual_seed(2))
+    outs = []
+    with torch.no_grad():
+        hh = h
+        for _ in range(3):
+            hh = gru(hh, x)
+            outs.append(hh.numpy().copy())
+    np.savez_compressed(os.path.join(HERE, "raft_gru.npz"), h=h.numpy(), x=x.numpy(), out1=outs[0], out3=outs[2])
+    print("raft_gru", outs[2].shape, stats(torch.from_numpy(outs[2])))
+
+
 def gen_ssim():
     sys.path.insert(0, os.path.join(REF, "Image_Caption"))
     import pytorch_ssim
@@ -309,7 +332,7 @@ def gen_ssim():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim"):
+        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim", "raft_gru"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim}[what]()
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim, "raft_gru": gen_raft_gru}[what]()

@@ -115,6 +115,12 @@ int ppv_gru_zr(const float* zr, int ldzr, const float* bias, const float* h, flo
                ppv_stream_t stream);
 int ppv_gru_out(const float* q, int ldq, const float* bias, const float* z, const float* h, float* hn, long rows, int Ch,
                 ppv_stream_t stream);
+/* Dense layers of the caption decoder (Image_Caption/models.py:199-214) in exact f32 on v_mfma_f32_16x16x4_f32:
+ * out[m][n] = sum_k x[m][k] W[n][k] + bias[n]; x [M][K] (row stride ldx), W [N][K] (row stride ldw), bias [N] or NULL, out row stride
+ * ldo.  K % 16 == 0.  ksplit > 1 ADDS partial sums with f32 atomics into a PRE-ZEROED out (ppv_gemm_f32_ksplit gives the count). */
+int ppv_gemm_f32_ksplit(int M, int N, int K);
+int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
+                 int ksplit, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
 int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, ppv_stream_t stream);

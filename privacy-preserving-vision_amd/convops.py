@@ -179,6 +179,27 @@ def conv_wgrad(g, x, R, S, stride, pad, scratch=None, out=None):
     return out
 
 
+# ----------------------------------------------------------------------------- dense layers in exact f32 (csrc/gemm_f32.hip)
+def linear_f32(x, w, bias=None, out=None):
+    """out = x @ w^T (+ bias) on v_mfma_f32_16x16x4_f32 (exact f32).  x [m, K] f32 with unit column stride (rows may be strided,
+    e.g. a column block of a wider buffer), w [N, K] f32 (same), out: optional f32 [m, N] with unit column stride."""
+    m, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == F32 and w.dtype == F32 and x.stride(1) == 1 and w.stride(1) == 1
+    if K % 16 or x.stride(0) % 4 or w.stride(0) % 4 or x.data_ptr() % 16 or w.data_ptr() % 16:
+        raise ValueError("linear_f32: K must be a multiple of 16 and rows 16-byte aligned")
+    ks = L().ppv_gemm_f32_ksplit(m, N, K)
+    if out is None:
+        out = (torch.zeros if ks > 1 else torch.empty)((m, N), dtype=F32, device=x.device)
+    else:
+        assert tuple(out.shape) == (m, N) and out.stride(1) == 1 and out.dtype == F32
+        if ks > 1:
+            out.zero_()
+    check(L().ppv_gemm_f32(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), m, N, K, ks, stream_ptr()),
+          "ppv_gemm_f32")
+    return out
+
+
 # ----------------------------------------------------------------------------- stem
 def stem_weight_layout(w, mode):
     out = torch.empty((64, 24, 8) if mode == 0 else (16, 4, 4, 64), dtype=BF16, device=w.device)

@@ -133,6 +133,19 @@ def _pool_tables(Hc, Wc, Eo, dev):
             "cell_cls": t(cell_cls, torch.int32), "Q": len(classes), "P": len(pix)}
 
 
+def _linear(x, w, bias, out, hip):
+    """x @ w^T (+ bias): exact f32 on the matrix pipe (convops.linear_f32) where its layout rules hold (K % 16 == 0, 16-byte
+    aligned rows), the library GEMM otherwise (toy sizes; the 9490-wide transposed vocabulary layer, whose rows are not aligned)."""
+    K = x.shape[1]
+    ok = (hip and K % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+          and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (out is None or out.stride(1) == 1))
+    if ok:
+        return co.linear_f32(x, w, bias, out=out)
+    if bias is None:
+        return torch.mm(x, w.t(), out=out) if out is not None else x @ w.t()
+    return torch.addmm(bias, x, w.t(), out=out) if out is not None else torch.addmm(bias, x, w.t())
+
+
 class _DecoderFn(torch.autograd.Function):
     """Whole decoder forward / hand-written BPTT.  ``src`` is encoder_out f32 [B,...,E] (general path, tables None) or the
     cell map bf16 [B,Hc,Wc,E] (compact path); then the 19 parameters in ``DecoderWithAttention._plist`` order."""
@@ -172,7 +185,13 @@ class _DecoderFn(torch.autograd.Function):
         w0 = torch.cat([w_h0, w_c0], 0).detach()                 # [2D, E]
         b0 = torch.cat([b_h0, b_c0], 0).detach()
         wfull = w_full.detach().reshape(-1).contiguous()
-        hc0 = torch.addmm(b0, mean, w0.t())                      # models.py:150-155
+        # The dense layers run in exact f32 on the matrix pipe (convops.linear_f32 -> csrc/gemm_f32.hip: the LSTM state feeds back
+        # every step, bf16 products are not an option); PPV_DEC_GEMM=lib keeps the rocBLAS f32 calls (A/B).  Layers whose K is not a
+        # multiple of 16 (toy sizes) and the batched weight gradients of backward stay library GEMMs.
+        import os as _os
+        hip_gemm = _os.environ.get("PPV_DEC_GEMM", "hip") != "lib"
+        w1, w2, w0 = w1.contiguous(), w2.contiguous(), w0.contiguous()
+        hc0 = _linear(mean.contiguous(), w0, b0, None, hip_gemm)  # models.py:150-155
 
         # one zero-filled f32 workspace for everything a finished caption leaves untouched (rows >= bt of a step)
         Q = tables["Q"] if compact else 0
@@ -190,7 +209,7 @@ class _DecoderFn(torch.autograd.Function):
         lib = L()
         for t in range(T):
             bt = bts[t]
-            torch.addmm(b1, XH[t, :bt, M + E:], w1t, out=HP[t, :bt])
+            _linear(XH[t, :bt, M + E:], w1, b1, HP[t, :bt], hip_gemm)
             if compact:
                 check(lib.ppv_decc_attend_fwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(tables["cells"]), ptr(tables["w"]),
                                               ptr(tables["mult"]), ptr(tables["pix"]), ptr(AL[t]), ptr(ALQ[t]), ptr(BETA[t]),
@@ -198,7 +217,7 @@ class _DecoderFn(torch.autograd.Function):
             else:
                 check(lib.ppv_dec_attend_fwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(ebuf), ptr(AL[t]), ptr(AW[t]),
                                              ptr(XH[t]), X, M, bt, P, A, E, stream_ptr()), "ppv_dec_attend_fwd")
-            torch.addmm(b2, XH[t, :bt], w2t, out=z[:bt])
+            _linear(XH[t, :bt], w2, b2, z[:bt], hip_gemm)
             check(lib.ppv_lstm_cell_fwd(ptr(z), ptr(C[t]), ptr(G[t]), ptr(C[t + 1]), ptr(HS[t]), D, ptr(XH[t + 1, :, M + E:]), X,
                                         bt, D, stream_ptr()), "ppv_lstm_cell_fwd")
         valid = (torch.arange(B, device=dev).view(1, B, 1) < torch.tensor(bts, device=dev).view(T, 1, 1)).to(F32)
@@ -208,11 +227,12 @@ class _DecoderFn(torch.autograd.Function):
             HD = HS * dmask
         else:
             dmask, HD = None, HS
-        preds = torch.addmm(b_fc.detach(), HD.view(T * B, D), w_fc.detach().t()).view(T, B, V)
+        preds = _linear(HD.view(T * B, D), w_fc.detach().contiguous(), b_fc.detach(), None, hip_gemm).view(T, B, V)
         preds.mul_(valid)                                        # positions past a caption's end stay exactly 0 (models.py:194)
 
         ctx.mod, ctx.dims = mod, (B, P, R, E, A, D, M, V, T, X)
         ctx.bts, ctx.caps, ctx.order, ctx.tables = bts, caps, order, tables
+        ctx.hip_gemm = hip_gemm
         ctx.saved = (rows, att, mean, w1, w2, w0, wfull, XH, C, HP, AW, AL, ALQ, BETA, G, HD, dmask, valid, w_fc.detach(), w_enc.detach())
         ctx.src_shape, ctx.src_dtype = src.shape, src.dtype
         return preds.transpose(0, 1), AL.transpose(0, 1)
@@ -231,7 +251,9 @@ class _DecoderFn(torch.autograd.Function):
         gp2 = gp.view(T * B, V)
         d_wfc = gp2.t() @ HD.view(T * B, D)
         d_bfc = gp2.sum(0)
-        dHS = (gp2 @ w_fc).view(T, B, D)
+        hip_gemm = ctx.hip_gemm
+        w2T, w1T = w2.t().contiguous(), w1.t().contiguous()       # the transposed layers x @ W = linear over W^T
+        dHS = _linear(gp2, w_fc.t().contiguous(), None, None, hip_gemm).view(T, B, D)
         if dmask is not None:
             dHS = dHS * dmask
         ga = None if g_alphas is None else (g_alphas.transpose(0, 1).float() * valid).contiguous()
@@ -250,7 +272,7 @@ class _DecoderFn(torch.autograd.Function):
             check(lib.ppv_lstm_cell_bwd(ptr(G[t]), ptr(C[t]), ptr(C[t + 1]), ptr(dh), ptr(dc_a), ptr(DZ[t]), ptr(dc_b), bt, D,
                                         stream_ptr()), "ppv_lstm_cell_bwd")
             dc_a, dc_b = dc_b, dc_a                               # rows >= bt of the new dc_a are still zero from earlier steps
-            torch.mm(DZ[t, :bt], w2, out=DX[t, :bt])
+            _linear(DZ[t, :bt], w2T, None, DX[t, :bt], hip_gemm)
             gat = ptr(ga[t]) if ga is not None else None
             if compact:
                 check(lib.ppv_decc_attend_bwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(tables["cells"]), ptr(tables["w"]),
@@ -261,7 +283,7 @@ class _DecoderFn(torch.autograd.Function):
                 check(lib.ppv_dec_attend_bwd(ptr(att), ptr(rows), ptr(HP[t]), A + E, ptr(wfull), ptr(AL[t]), ptr(AW[t]), ptr(DX[t]), X, M,
                                              gat, ptr(DHP[t]), ptr(DAW[t]), ptr(scratch), ptr(datt), ptr(dwfull), bt, P, A, E,
                                              stream_ptr()), "ppv_dec_attend_bwd")
-            torch.addmm(DX[t, :bt, M + E:], DHP[t, :bt], w1, out=dh_next[:bt])
+            torch.add(DX[t, :bt, M + E:], _linear(DHP[t, :bt], w1T, None, None, hip_gemm), out=dh_next[:bt])
 
         # ---- batched over all steps
         d_w2 = DZ.view(T * B, 4 * D).t() @ XH[:T].view(T * B, X)

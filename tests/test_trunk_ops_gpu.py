@@ -176,3 +176,22 @@ def test_bn_backward_takes_a_second_batchnorms_sums(C, rows):
     want2 = co.bn_bwd(g, None, x2, coef2, 0)
     got2 = co.bn_bwd(g, None, x2, coef2, 0, part=part2, part_ready=True)
     assert rel_err(got2[0].float(), want2[0].float()) < 2 ** -7 and rel_err(got2[2], want2[2]) < 1e-4 and rel_err(got2[3], want2[3]) < 1e-4
+
+
+@pytest.mark.parametrize("m,N,K,strided", [(128, 2560, 512, True), (37, 2048, 3072, False), (300, 9490, 512, False), (5, 48, 336, True)])
+def test_linear_f32_is_exact_f32(m, N, K, strided):
+    """csrc/gemm_f32.hip (decoder dense layers, models.py:199-214): v_mfma_f32_16x16x4_f32 is an f32 fmaf chain -- the result
+    must agree with a float64 reference to f32 rounding of the accumulation (1e-6 of the row's absolute mass), far below bf16."""
+    import ppv_amd.convops as co
+    g = torch.Generator().manual_seed(0)
+    xw = torch.randn(m, K + 64, generator=g).cuda()
+    x = xw[:, 32:32 + K] if strided else xw[:, :K].contiguous()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = torch.full((m, N + 8), 7.0, device="cuda")[:, :N] if strided else None
+    got = co.linear_f32(x, w, b, out=out)
+    want = x.double() @ w.double().t() + b.double()
+    mass = (x.double().abs() @ w.double().abs().t() + b.double().abs())
+    assert ((got.double() - want).abs() / mass).max().item() < 2e-6
+    if strided:
+        assert got.data_ptr() == out.data_ptr()

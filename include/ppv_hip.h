@@ -121,6 +121,14 @@ int ppv_gru_out(const float* q, int ldq, const float* bias, const float* z, cons
 int ppv_gemm_f32_ksplit(int M, int N, int K);
 int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
                  int ksplit, ppv_stream_t stream);
+/* InstanceNorm2d / AdaIN (+ LeakyReLU) of the StarGAN-v2 blocks (Face-DeId/core/model.py:12-124), NHWC f32:
+ * y = lrelu((x - mean_bc) * invstd_bc * scale + shift), statistics per (sample, channel) over HW, eps as given; scale / shift are
+ * [C] (per_sample = 0: nn.InstanceNorm2d(affine=True)) or [B][C] (per_sample = 1: AdaIN's (1 + gamma), beta).  stats / sums:
+ * [B][C] float2 = (mean, invstd) / (d shift, d scale) per (sample, channel). */
+int ppv_instnorm_fwd(const float* x, const float* scale, const float* shift, float* y, void* stats, int B, int HW, int C,
+                     int per_sample, float slope, float eps, ppv_stream_t stream);
+int ppv_instnorm_bwd(const float* x, const float* g, const void* stats, const float* scale, const float* shift, float* dx,
+                     void* sums, int B, int HW, int C, int per_sample, float slope, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
 int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, ppv_stream_t stream);

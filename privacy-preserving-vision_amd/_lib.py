@@ -79,6 +79,8 @@ PROTOTYPES = {
     "ppv_weight_layout_multi": (_I, [_P, _I, _I, _P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
+    "ppv_instnorm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "ppv_instnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ppv_gemm_f32_ksplit": (_I, [_I, _I, _I]),
     "ppv_gemm_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P]),
     "ppv_conv_gemm_rect": (_I, [_P, _P, _P, _P] + [_I] * 10 + [_P]),

@@ -1,0 +1,132 @@
+"""Differentiable building blocks on the HIP kernels, NHWC float32 -- for the parts of the reference that TRAIN through fp32
+convolutions outside the bf16 trunk: FAN's ``get_heatmap_train`` (core/wing.py:262-272: the landmark loss back-propagates through
+the frozen regressor into the generated image) and the StarGAN-v2 blocks (core/model.py:12-124).
+
+``conv2d_f32``  convolution as three bf16 MFMA products accumulated in f32 ([x_hi | x_lo | x_hi] x [W_hi | W_hi | W_lo], product
+                error ~2^-16), forward AND data gradient (the same split on the incoming gradient against the flipped weights);
+                weight gradient on the bf16 MFMA weight-gradient kernel where its tile rules hold (channel counts multiples of
+                128), otherwise ``torch.nn.grad.conv2d_weight`` (library, on the device).
+``instance_norm_act``  InstanceNorm2d / AdaIN + LeakyReLU, forward and backward (csrc/instnorm.hip)."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib, convops as co
+from ._lib import check, ptr, stream_ptr
+
+_wcache = {}
+
+
+def _pad_to(t, dim, mult):
+    n = t.shape[dim]
+    p = (n + mult - 1) // mult * mult - n
+    if p == 0:
+        return t
+    pad = [0, 0] * (t.dim() - 1 - dim) + [0, p]
+    return F.pad(t, pad)
+
+
+def _layouts(w):
+    """(forward GEMM rows over the split input, data-gradient GEMM rows over the split gradient) of conv weight [Cout,Cin,R,S]"""
+    key = id(w)
+    ent = _wcache.get(key)
+    ver = (w._version, w.data_ptr(), w.device)
+    if ent is None or ent[0] != ver:
+        wf = w.detach().float()
+        hi = wf.bfloat16().float()
+        lo = (wf - hi).bfloat16().float()
+        fwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=1), 1, 64), 0, 64)                # [Coutp, pad64(3 Cin), R, S]
+        bwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=0), 0, 64), 1, 64)                # [pad64(3 Cout), Cinp, R, S]
+        ent = (ver, co.weight_layout(fwd.contiguous(), 0), co.weight_layout(bwd.contiguous(), 1))
+        if len(_wcache) > 4096:
+            _wcache.clear()
+        _wcache[key] = ent
+    return ent[1], ent[2]
+
+
+def _split3(t):
+    B, H, W, C = t.shape
+    cp = (3 * C + 63) // 64 * 64
+    y = torch.empty((B, H, W, cp), dtype=torch.bfloat16, device=t.device)
+    check(_lib.lib().ppv_bn_act_split3(ptr(t), None, ptr(y), B * H * W, C, cp, 0, C, stream_ptr()), "ppv_bn_act_split3")
+    return y
+
+
+class _ConvF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        _lib.require_cuda(x, weight)
+        x = x.contiguous().float()
+        Cout, Cin, R, S = weight.shape
+        assert R == S and x.shape[-1] == Cin
+        wf, _ = _layouts(weight)
+        y = co.conv_fwd(_split3(x), wf, stride, pad, out_f32=True)
+        if y.shape[-1] != Cout:
+            y = y[..., :Cout].contiguous()
+        if bias is not None:
+            y = y + bias.detach().float()
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.geom
+        Cout, Cin, R, S = weight.shape
+        gy = gy.contiguous().float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            _, wd = _layouts(weight)
+            gx = co.conv_dgrad(_split3(gy), wd, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
+            if gx.shape[-1] != Cin:
+                gx = gx[..., :Cin].contiguous()
+        if ctx.needs_input_grad[1]:
+            if Cout % 128 == 0 and Cin % 128 == 0:
+                gw = co.conv_wgrad(gy.bfloat16(), x.bfloat16(), R, S, stride, pad)
+            else:                                       # outside the MFMA weight-gradient kernel's tiles (3- and 64-channel layers)
+                gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), stride=stride, padding=pad)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 1, 2))
+        return gx, gw, gb, None, None
+
+
+def conv2d_f32(x, weight, bias=None, stride=1, pad=0):
+    """x [B,H,W,Cin] f32 NHWC, weight [Cout,Cin,k,k] (torch layout, e.g. an nn.Conv2d's parameter) -> [B,Ho,Wo,Cout] f32."""
+    return _ConvF32.apply(x, weight, bias, stride, pad)
+
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, slope, eps):
+        _lib.require_cuda(x)
+        x = x.contiguous().float()
+        B, H, W, C = x.shape
+        per_sample = scale.dim() == 2
+        scale, shift = scale.contiguous().float(), shift.contiguous().float()
+        y = torch.empty_like(x)
+        stats = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ppv_instnorm_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(stats), B, H * W, C, int(per_sample), slope, eps,
+                                          stream_ptr()), "ppv_instnorm_fwd")
+        ctx.save_for_backward(x, stats, scale, shift)
+        ctx.cfg = (per_sample, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, scale, shift = ctx.saved_tensors
+        per_sample, slope = ctx.cfg
+        B, H, W, C = x.shape
+        g = g.contiguous().float()
+        dx = torch.empty_like(x)
+        sums = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ppv_instnorm_bwd(ptr(x), ptr(g), ptr(stats), ptr(scale), ptr(shift), ptr(dx), ptr(sums), B, H * W, C,
+                                          int(per_sample), slope, stream_ptr()), "ppv_instnorm_bwd")
+        dshift, dscale = sums[..., 0], sums[..., 1]
+        if not per_sample:
+            dshift, dscale = dshift.sum(0), dscale.sum(0)
+        return dx, dscale, dshift, None, None
+
+
+def instance_norm_act(x, scale, shift, slope=1.0, eps=1e-5):
+    """lrelu_slope( InstanceNorm(x) * scale + shift ) on x [B,H,W,C] f32; scale / shift [C] (affine InstanceNorm2d) or [B,C] (AdaIN)."""
+    return _InstNormAct.apply(x, scale, shift, float(slope), float(eps))

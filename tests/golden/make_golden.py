@@ -257,6 +257,75 @@ def gen_fan():
     np.savez_compressed(os.path.join(HERE, "fan.npz"), **out)
 
 
+def _face_deid_standins():
+    install_standins()
+    munch = types.ModuleType("munch")
+    munch.Munch = dict
+    sk = types.ModuleType("skimage")
+    sk.filters = types.ModuleType("skimage.filters")
+    sk.filters.gaussian = lambda *a, **k: None
+    for name, mod in [("munch", munch), ("skimage", sk), ("skimage.filters", sk.filters)]:
+        sys.modules[name] = mod
+    if os.path.join(REF, "Face-DeId") not in sys.path:
+        sys.path.insert(0, os.path.join(REF, "Face-DeId"))
+
+
+def _fill_plain(module):
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+            if t.dim() > 1:
+                t.copy_(torch.randn(t.shape, generator=g) * (1.0 / t[0].numel()) ** 0.5)
+            elif name.endswith("weight"):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            else:
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+
+
+def gen_fan_train():
+    """FAN.get_heatmap_train (core/wing.py:262-272): the landmark heat-maps WITH autograd; gradient w.r.t. the input image."""
+    _face_deid_standins()
+    from core.wing import FAN
+    fan = FAN().eval()
+    fill_by_name(fan)
+    x = (torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(5)) * 2 - 1).requires_grad_(True)
+    hm = fan.get_heatmap_train(x, Privacy=True)
+    w0 = torch.rand(hm[0].shape, generator=torch.Generator().manual_seed(6))
+    w1 = torch.rand(hm[1].shape, generator=torch.Generator().manual_seed(7))
+    ((hm[0] * w0).sum() + (hm[1] * w1).sum()).backward()
+    np.savez_compressed(os.path.join(HERE, "fan_train.npz"), x=x.detach().numpy(), hm0=hm[0].detach().numpy(), hm1=hm[1].detach().numpy(),
+                        gx=x.grad.numpy())
+    print("fan_train hm0", stats(hm[0].detach()), "gx", stats(x.grad))
+
+
+def gen_stargan():
+    """StarGAN-v2 blocks (core/model.py:12-124): ResBlk (normalised, down-sampling, learned shortcut), AdainResBlk (up-sampling,
+    learned shortcut): outputs, input gradients and every parameter gradient."""
+    _face_deid_standins()
+    from core.model import ResBlk, AdainResBlk
+    out = {}
+    cases = {"res": (ResBlk(64, 128, normalize=True, downsample=True), (2, 64, 16, 16), None),
+             "res_plain": (ResBlk(128, 128, normalize=False, downsample=False), (1, 128, 8, 12), None),
+             "ada": (AdainResBlk(128, 64, style_dim=64, w_hpf=0, upsample=True), (2, 128, 8, 8), (2, 64))}
+    for tag, (m, xs, ss) in cases.items():
+        _fill_plain(m)
+        x = torch.randn(xs, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+        args = (x,)
+        if ss is not None:
+            s = torch.randn(ss, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
+            args = (x, s)
+        y = m(*args)
+        w = torch.rand(y.shape, generator=torch.Generator().manual_seed(3))
+        (y * w).sum().backward()
+        out[f"{tag}_x"], out[f"{tag}_y"], out[f"{tag}_gx"] = x.detach().numpy(), y.detach().numpy(), x.grad.numpy()
+        if ss is not None:
+            out[f"{tag}_s"], out[f"{tag}_gs"] = s.detach().numpy(), s.grad.numpy()
+        for n, p in m.named_parameters():
+            out[f"{tag}_g_{n}"] = p.grad.numpy()
+        print("stargan", tag, stats(y.detach()), stats(x.grad))
+    np.savez_compressed(os.path.join(HERE, "stargan.npz"), **out)
+
+
 # --------------------------------------------------------------------------- attention decoder (Image_Caption/models.py)
 def gen_decoder():
     install_standins()
@@ -332,7 +401,7 @@ def gen_ssim():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim", "raft_gru"):
+        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim", "raft_gru", "fan_train", "stargan"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim, "raft_gru": gen_raft_gru}[what]()
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim, "raft_gru": gen_raft_gru, "fan_train": gen_fan_train, "stargan": gen_stargan}[what]()

@@ -350,6 +350,75 @@ class FAN(nn.Module):
                              nl - 1, 4, stream_ptr()), "ppv_fan_head")
         return [heat[:, 0:1].clamp_(0, 1), heat[:, 1:2].clamp_(0, 1)]
 
+    # ------------------------------------------------------------------ differentiable path (wing.py:262-272 get_heatmap_train)
+    # The landmark loss of the de-identification training back-propagates THROUGH the frozen regressor into the generated image.
+    # Same arithmetic as the fp32-accurate forward (split-bf16 MFMA products, f32 activations), expressed with
+    # ppv_amd.nn_ops.conv2d_f32 (forward + data gradient on the MFMA kernels) and f32 torch element-wise ops for the eval-mode
+    # BatchNorm affine, ReLU, concatenation, pooling and resampling, so autograd carries the gradient to ``x``.  The regressor's
+    # own parameters are frozen in the reference (eval mode, no optimiser holds them); their gradients are not produced here.
+    @staticmethod
+    def _bn_relu_t(bn, t):
+        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        return torch.relu(t * scale + (bn.bias.detach() - bn.running_mean * scale))
+
+    def _convblock_t(self, blk, x):
+        from .nn_ops import conv2d_f32
+        o1 = conv2d_f32(self._bn_relu_t(blk.bn1, x), blk.conv1.weight.detach(), None, 1, 1)
+        o2 = conv2d_f32(self._bn_relu_t(blk.bn2, o1), blk.conv2.weight.detach(), None, 1, 1)
+        o3 = conv2d_f32(self._bn_relu_t(blk.bn3, o2), blk.conv3.weight.detach(), None, 1, 1)
+        res = x if blk.downsample is None else conv2d_f32(self._bn_relu_t(blk.downsample[0], x), blk.downsample[2].weight.detach(), None, 1, 0)
+        return torch.cat((o1, o2, o3), dim=-1) + res
+
+    def _hourglass_t(self, level, x):
+        m = self.m0._modules
+        up1 = self._convblock_t(m[f"b1_{level}"], x)
+        B, H, W, C = x.shape
+        low = self._convblock_t(m[f"b2_{level}"], x.view(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4)))
+        low = self._hourglass_t(level - 1, low) if level > 1 else self._convblock_t(m["b2_plus_1"], low)
+        low = self._convblock_t(m[f"b3_{level}"], low)
+        return up1 + low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)          # nearest x2 (wing.py:69)
+
+    def forward_train(self, x):
+        """x [B,3,256,256] in [0,1], autograd enabled -> ([heat-map logits [B,99,64,64]], [boundary channel])  (wing.py:212-238)."""
+        from .nn_ops import conv2d_f32
+        if self.training:
+            raise NotImplementedError("ppv_amd FAN is the frozen (eval-mode BatchNorm) regressor of the reference (model.py:298-306)")
+        if not x.is_cuda:
+            raise RuntimeError("ppv_amd FAN runs on an MI355X (input must be a cuda tensor); no CPU path")
+        if x.shape[-1] != 256 or x.shape[-2] != 256:
+            raise RuntimeError("FAN's CoordConv is built for 256 x 256 inputs (wing.py:184)")
+        B = x.shape[0]
+        dev = x.device
+        c256 = _coord_channels(256, 256).to(dev).permute(1, 2, 0)                        # [256,256,3]
+        c64 = _coord_channels(64, 64).to(dev).permute(1, 2, 0)
+        t = torch.cat([x.float().permute(0, 2, 3, 1), c256.unsqueeze(0).expand(B, -1, -1, -1)], dim=-1)      # CoordConv: + xx, yy, rr
+        t = conv2d_f32(t, self.conv1.conv.weight.detach(), self.conv1.conv.bias.detach(), 2, 3)
+        t = self._bn_relu_t(self.bn1, t)
+        t = self._convblock_t(self.conv2, t)
+        t = t.view(B, 64, 2, 64, 2, t.shape[-1]).mean(dim=(2, 4))                          # F.avg_pool2d(., 2)
+        t = self._convblock_t(self.conv4, self._convblock_t(self.conv3, t))
+        cc = self.m0.coordconv.conv
+        h = conv2d_f32(torch.cat([t, c64.unsqueeze(0).expand(B, -1, -1, -1)], dim=-1), cc.weight.detach(), cc.bias.detach(), 1, 0)
+        ll = self._convblock_t(self.top_m_0, self._hourglass_t(4, h))
+        ll = conv2d_f32(ll, self.conv_last0.weight.detach(), self.conv_last0.bias.detach(), 1, 0)
+        ll = self._bn_relu_t(self.bn_end0, ll)
+        out = conv2d_f32(ll, self.l0.weight.detach(), self.l0.bias.detach(), 1, 0).permute(0, 3, 1, 2)
+        if self.end_relu:
+            out = F.relu(out)
+        boundary = c64.permute(2, 0, 1)[1:3].unsqueeze(0).expand(B, -1, -1, -1)             # last two CoordConv input channels
+        return [out], [boundary]
+
+    def get_heatmap_train(self, x, b_preprocess=True, Privacy=False, delimiter=False):
+        """wing.py:262-272: 0-1 normalised heat-maps WITH autograd (gradient w.r.t. ``x``)."""
+        x = F.interpolate(x, size=256, mode='bilinear')
+        outputs, _ = self.forward_train(x * 0.5 + 0.5)
+        heatmaps = outputs[-1][:, :-1, :, :]
+        scale_factor = x.size(2) // heatmaps.size(2)
+        if b_preprocess and Privacy:
+            heatmaps = F.interpolate(heatmaps, scale_factor=scale_factor, mode='bilinear', align_corners=True)
+            heatmaps = [heatmaps[:, :49].sum(dim=1, keepdim=True).clamp_(0, 1), heatmaps[:, 49:].sum(dim=1, keepdim=True).clamp_(0, 1)]
+        return heatmaps
+
     @torch.no_grad()
     def forward(self, x):
         """x [B,3,256,256] in [0,1] -> ([heat-map logits [B,99,64,64] f32], [boundary channel])  (wing.py:212-238)."""

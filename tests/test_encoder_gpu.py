@@ -274,3 +274,30 @@ def test_momentum_none_is_the_cumulative_average():
     a, b = enc.resnet[1].running_mean.cpu(), ref.resnet[1].running_mean                  # stem BN: not yet touched by trunk chaos
     assert ((a - b).abs().max() / b.abs().max()).item() < 2e-2
     assert int(enc.resnet[1].num_batches_tracked) == 3
+
+
+def test_resnet101_at_batch_128_stagewise_against_the_oracle():
+    """BASELINE configs[2] batch size through the WHOLE encoder, against the oracle: the batch is 4 distinct
+    256 x 256 images repeated 32 times, so every train-mode BatchNorm sees exactly the statistics of the 4-image batch (a repeated
+    sample changes neither mean nor biased variance) and each of the 33 bottlenecks of the ORACLE, fed the product's own block
+    input for the first 4 images, must reproduce the product's block output there -- while the kernels run the B = 128 tile
+    shapes, split counts and stream kernels of the benchmark.  Forward, every stage; the copies must also agree with each other."""
+    enc, ref = _pair((3, 4, 23, 3))
+    enc.train(); ref.train()
+    torch.set_num_threads(16)
+    img4 = torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    img = img4.repeat(32, 1, 1, 1).cuda().requires_grad_(True)
+    out = enc(img)
+    fn = out.grad_fn
+    assert out.shape == (128, 36, 36, 2048)
+    oblocks = [b for li in range(4, 8) for b in ref.resnet[li]]
+    worst = 0.0
+    with torch.no_grad():
+        for ob, sv in zip(oblocks, fn.blocks):
+            xin, yout = sv[0], sv[11]
+            yo = ob(_nchw(xin[:4]))
+            worst = max(worst, rel_err(yout[:4].float(), _nhwc(yo)))
+            # the 32 copies went through different workgroups / tiles: same values up to the summation order inside a tile row
+            assert rel_err(yout[4:8].float(), yout[:4].float()) < BF
+    print(f"B = 128 stage-wise forward, worst block: {worst:.2e}")
+    assert worst < 1e-2

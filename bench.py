@@ -88,10 +88,11 @@ class _CellsMeanSquare(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cells, e):
         _, h, w, _ = cells.shape
-        qh, qw = _pool_gram(h, e, cells.device), _pool_gram(w, e, cells.device)
+        key = ("kron", h, w, e, str(cells.device))
+        if key not in _POOL_GRAM:                                 # (P^T P) (x) (P^T P) as ONE [hw, hw] matrix: a single batched GEMM of
+            _POOL_GRAM[key] = torch.kron(_pool_gram(h, e, cells.device), _pool_gram(w, e, cells.device)).contiguous()   # sane shape
         x = cells.float()
-        t = torch.einsum("hk,bkwc->bhwc", qh, x)
-        t = torch.einsum("wk,bhkc->bhwc", qw, t)
+        t = torch.matmul(_POOL_GRAM[key], x.view(x.shape[0], h * w, x.shape[3])).view_as(x)
         n = cells.shape[0] * e * e * cells.shape[3]
         ctx.save_for_backward(t)
         ctx.n = n

@@ -368,51 +368,35 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const bf16_t* __r
 template <typename TO>
 __global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const bf16_t* __restrict__ x, TO* __restrict__ y, int B, int H,
                                                                 int W, int C, int E) {
+    const int c8n = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)B * E * E * c8n;
+    if (i >= tot) return;
+    const int c0 = (int)(i % c8n) * 8;
+    const int ox = (int)((i / c8n) % E), oy = (int)((i / ((long)c8n * E)) % E), b = (int)(i / ((long)c8n * E * E));
+    const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E, w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) {
+            float v[8];
+            load8(x + (((long)b * H + h) * W + w) * C + c0, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+    TO* o = y + i * 8;
     if constexpr (sizeof(TO) == 4) {
-        // f32 output (1.36 GB at B = 128, streamed out once): FOUR channels per thread so that a wave's store instruction
-        // covers 1 KiB of consecutive bytes (16 B per lane, non-temporal); the 8-byte loads hit the L2-resident 8x8 map
-        const int c4n = C / 4;
-        const long i = (long)blockIdx.x * 256 + threadIdx.x;
-        const long tot = (long)B * E * E * c4n;
-        if (i >= tot) return;
-        const int c0 = (int)(i % c4n) * 4;
-        const int ox = (int)((i / c4n) % E), oy = (int)((i / ((long)c4n * E)) % E), b = (int)(i / ((long)c4n * E * E));
-        const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E, w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int h = h0; h < h1; ++h)
-            for (int w = w0; w < w1; ++w) {
-                const uint2 u = *reinterpret_cast<const uint2*>(x + (((long)b * H + h) * W + w) * C + c0);
-                acc[0] += __builtin_bit_cast(float, u.x << 16);
-                acc[1] += __builtin_bit_cast(float, u.x & 0xffff0000u);
-                acc[2] += __builtin_bit_cast(float, u.y << 16);
-                acc[3] += __builtin_bit_cast(float, u.y & 0xffff0000u);
-            }
-        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+        // 1.36 GB at B = 128: streamed out once, far larger than the Infinity Cache -> non-temporal 16-byte stores
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
-        const f32x4_ o = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
-        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_*>(y + i * 4));
+        const f32x4_ lo = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+        const f32x4_ hi = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+        __builtin_nontemporal_store(lo, reinterpret_cast<f32x4_*>(o));
+        __builtin_nontemporal_store(hi, reinterpret_cast<f32x4_*>(o) + 1);
     } else {
-        const int c8n = C / 8;
-        const long i = (long)blockIdx.x * 256 + threadIdx.x;
-        const long tot = (long)B * E * E * c8n;
-        if (i >= tot) return;
-        const int c0 = (int)(i % c8n) * 8;
-        const int ox = (int)((i / c8n) % E), oy = (int)((i / ((long)c8n * E)) % E), b = (int)(i / ((long)c8n * E * E));
-        const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E, w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
-        float acc[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-        for (int h = h0; h < h1; ++h)
-            for (int w = w0; w < w1; ++w) {
-                float v[8];
-                load8(x + (((long)b * H + h) * W + w) * C + c0, v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += v[k];
-            }
-        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] *= inv;
-        store8(reinterpret_cast<bf16_t*>(y) + i * 8, acc);
+        for (int k = 0; k < 8; ++k) o[k] = (TO)(acc[k] * inv);
     }
 }
 
@@ -597,7 +581,7 @@ int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* g
 int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, hipStream_t stream) {
     if (!x || !y) return PPV_ERR_NULL;
     if (C % 8) return PPV_ERR_BAD_SIZE;
-    const long tot = (long)B * E * E * (C / (out_f32 ? 4 : 8));
+    const long tot = (long)B * E * E * (C / 8);
     const unsigned gb = (unsigned)((tot + 255) / 256);
     if (out_f32) adaptive_pool_fwd_kernel<float><<<gb, 256, 0, stream>>>((const bf16_t*)x, (float*)y, B, H, W, C, E);
     else adaptive_pool_fwd_kernel<__bf16><<<gb, 256, 0, stream>>>((const bf16_t*)x, (__bf16*)y, B, H, W, C, E);

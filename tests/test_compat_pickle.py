@@ -48,7 +48,8 @@ def test_whole_module_pickle_round_trip():
     with torch.no_grad():
         assert torch.equal(back["encoder"](img), enc(img))
         caps, lens = torch.randint(0, 30, (2, 6), device="cuda"), torch.tensor([[6], [4]], device="cuda")
-        assert torch.equal(back["decoder"](enc(img), caps, lens)[0], dec(enc(img), caps, lens)[0])
+        # the decoder's f32 GEMM splits K over workgroups and adds the partials atomically: same values, summation order free
+        torch.testing.assert_close(back["decoder"](enc(img), caps, lens)[0], dec(enc(img), caps, lens)[0], rtol=1e-5, atol=1e-6)
         x = torch.rand(2, 3, 128, 128, device="cuda")
         noise = torch.rand(1, 448, 448, 1, device="cuda")
         a = cam(x, None, None, noise_u01=noise)[0]

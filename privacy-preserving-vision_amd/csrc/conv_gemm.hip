@@ -253,6 +253,8 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
+    PPV_STAMP_DECL;
+    PPV_STAMP(0);
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 < nk) stage(s0);
+    PPV_STAMP(1);
     int rd = 0, wr = (NSTAGE - 1) % NSTAGE;
     for (int t = 0; t < nk; ++t) {
         // stages issued so far: min(nk, t + NSTAGE - 1); those younger than stage t may stay in flight
@@ -374,14 +377,19 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         else if (NSTAGE >= 4 && younger == NSTAGE - 3) wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
         else wait_vmcnt_le<0>();
         __builtin_amdgcn_s_barrier();
+#ifdef PPV_STAMPS
+        if (t == 0) PPV_STAMP(2);
+        if (t == 1) PPV_STAMP(5);
+#endif
         if (t + NSTAGE - 1 < nk) stage(wr);
         compute(rd);
         rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
         wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
     }
     __syncthreads();
+    PPV_STAMP(3);
 
-    // ---------------------------------------------------------------- epilogue (as conv_gemm_kernel)
+    // ---------------------------------------------------------------- epilogue
     if (OUT_F32) {
         float* out = reinterpret_cast<float*>(Out);
 #pragma unroll
@@ -396,7 +404,8 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                 }
         return;
     }
-    constexpr int LDO = BN * 2 + 16;
+    constexpr int LDO = BN * 2 + 32;                           // row stride = 8 words mod 64 (packed tile write below)
+    constexpr int LDS_TOTAL = NSTAGE * STAGE_BYTES > BM * LDO + 4096 ? NSTAGE * STAGE_BYTES : BM * LDO + 4096;   // = the host's `lds`
     char* sO = smem;
     float* sStat = reinterpret_cast<float*>(smem + BM * LDO);
     constexpr int CPR = BN / 8;
@@ -434,11 +443,11 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         // the addend tile comes in as whole 16-byte chunks (coalesced), is parked in LDS behind the output staging
         // area and added fragment-wise in f32: one rounding of (acc + addend), no 2-byte global gathers
         char* sAdd = smem + BM * LDO + 2048;
-        if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES && WM % 2 != 0) {
+        if constexpr (2 * BM * LDO + 2048 > LDS_TOTAL && WM % 2 != 0) {
             return;                                             // host never pairs this tile shape with an addend
-        } else if constexpr (2 * BM * LDO + 2048 > NSTAGE * STAGE_BYTES) {
+        } else if constexpr (2 * BM * LDO + 2048 > LDS_TOTAL) {
             // small ring (BK = 32): the output tile and the addend tile are processed in two 128-row halves
-            static_assert(BM * LDO + 2048 <= NSTAGE * STAGE_BYTES, "two-pass epilogue geometry");
+            static_assert(BM * LDO + 2048 <= LDS_TOTAL, "two-pass epilogue geometry");
             constexpr int HR = BM / 2;                          // rows per pass
             char* sOh = smem;
             char* sAh = smem + HR * LDO;
@@ -543,29 +552,54 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                     acc[mi][ni][j] += bf2f(*reinterpret_cast<const bf16_t*>(sAdd + row * LDO + col * 2));
                 }
     }
+    // accumulators -> bf16 tile in LDS.  The MFMA result layout gives a lane ONE column (fr) and four consecutive rows per tile;
+    // written as it stands that is 64 two-byte LDS writes per lane, two lanes to a bank word (measured: 2.0 us of a 256 x 128
+    // tile's 3.4-us epilogue).  Here a lane packs its rows pairwise (v_cvt_pk_bf16_f32: [row j | row j+1]), swaps with its
+    // column neighbour (DPP quad_perm [1,0,3,2]) and one v_perm_b32 makes a full word of two ADJACENT columns: even lanes take
+    // row j, odd lanes row j+1 -- 32 conflict-free ds_write_b32 per lane (row stride = 8 words mod 64).  The BatchNorm sums come
+    // off the matrix pipe from the same packed registers: ones x P = column sums, P^T x P = Gram matrix whose diagonal is the
+    // sum of squares (the k index of an MFMA operand may be any permutation of the 32 rows of two tiles).
+    static_assert(MI % 2 == 0, "row tiles are taken in pairs");
+    {
+        const int par = fr & 1;
+        const unsigned sel = par ? 0x03020706u : 0x05040100u;
+        char* lbase = sO + (wm * WROWS + fq * 4 + par) * LDO + (wn * WCOLS + (fr & ~1)) * 2;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        const u32x4_t ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        float s1 = 0.f, s2 = 0.f;
-        const int col = wn * WCOLS + ni * 16 + fr;
+        for (int ni = 0; ni < NI; ++ni) {
+            f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mp = 0; mp < MI / 2; ++mp) {
+                unsigned pk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16_t h = f2bf(acc[mi][ni][j]);
-                const float v = bf2f(h);
-                s1 += v;
-                s2 += v * v;
-                *reinterpret_cast<bf16_t*>(sO + (wm * WROWS + mi * 16 + fq * 4 + j) * LDO + col * 2) = h;
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const int mi = mp * 2 + h;
+                        const unsigned own = pack2(acc[mi][ni][jp * 2], acc[mi][ni][jp * 2 + 1]);
+                        pk[h * 2 + jp] = own;
+                        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xf, 0xf, true);
+                        *reinterpret_cast<unsigned*>(lbase + (mi * 16 + jp * 2) * LDO + ni * 32) = __builtin_amdgcn_perm(nb, own, sel);
+                    }
+                if (!RED && stat_part) {
+                    const u32x4_t pu = {pk[0], pk[1], pk[2], pk[3]};
+                    const bf16x8 P = __builtin_bit_cast(bf16x8, pu);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, P, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(P, P, c2, 0, 0, 0);
+                }
             }
-        if (!RED && stat_part) {
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (fq == 0) {
-                sStat[(wm * 2 + 0) * BN + col] = s1;
-                sStat[(wm * 2 + 1) * BN + col] = s2;
+            if (!RED && stat_part) {
+                const int col = wn * WCOLS + ni * 16 + fr;
+                const int d = fr & 3;
+                const float q = d == 0 ? c2[0] : d == 1 ? c2[1] : d == 2 ? c2[2] : c2[3];
+                if (fq == 0) sStat[(wm * 2 + 0) * BN + col] = c1[0];
+                if (fq == (fr >> 2)) sStat[(wm * 2 + 1) * BN + col] = q;
             }
         }
     }
+    PPV_STAMP(7);
     __syncthreads();
     if (!RED && stat_part && tid < 2 * BN) {
         const int which = tid / BN, col = tid % BN;
@@ -585,23 +619,69 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
             }
         }
     }
+    // store loop.  Whole tiles (all but the last row tile of a launch) take the three-phase form: every global read this loop
+    // needs (mask bytes, BatchNorm input rows) is requested first, then every LDS chunk, then the stores -- one latency of each
+    // kind per tile instead of one per 16-byte chunk (the per-chunk form measured 1.0-2.8 us per tile: eight dependent
+    // LDS round trips behind 64-bit address products and row predicates).
+    static_assert(NT % CPR == 0 && (BM * CPR) % NT == 0, "a thread keeps its chunk column");
+    constexpr int RSTEP = NT / CPR, SITERS = BM / RSTEP;
+    if (m0 + BM <= g.M) {
+        const int row0 = tid / CPR, ch = tid % CPR;
+        const long e0 = (m0 + row0) * g.N + n0 + ch * 8;
+        const long estep = (long)RSTEP * g.N;
+        constexpr int GRP = RED ? (WGPCU > 1 ? 2 : 4) : SITERS;            // RED: rounds of a few chunks (register budget)
 #pragma unroll
-    for (int it = 0; it < (BM * CPR + NT - 1) / NT; ++it) {
-        const int idx = it * NT + tid;
-        const int row = idx / CPR, ch = idx % CPR;
-        const long m = m0 + row;
-        if (idx < BM * CPR && m < g.M)
-        {
-            uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
-            if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
-            if constexpr (RED) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8);
-                if (red_coef) v = red_mask8(v, xv, rsc, rsh);
-                red_acc8(v, xv, ra, rb);
+        for (int i0 = 0; i0 < SITERS; i0 += GRP) {
+            unsigned char mbv[GRP];
+            uint4 xv[RED ? GRP : 1];
+            if (mask_bits) {
+#pragma unroll
+                for (int it = 0; it < GRP; ++it) mbv[it] = mask_bits[(e0 + (i0 + it) * estep) >> 3];
             }
-            *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
+            if constexpr (RED) {
+#pragma unroll
+                for (int it = 0; it < GRP; ++it) xv[it] = *reinterpret_cast<const uint4*>(red_x + e0 + (i0 + it) * estep);
+            }
+            uint4 v[GRP];
+#pragma unroll
+            for (int it = 0; it < GRP; ++it) v[it] = *reinterpret_cast<const uint4*>(sO + (row0 + (i0 + it) * RSTEP) * LDO + ch * 16);
+            if (mask_bits) {
+#pragma unroll
+                for (int it = 0; it < GRP; ++it) v[it] = relu_mask8(v[it], mbv[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < GRP; ++it) {
+                if constexpr (RED) {
+                    if (red_coef) v[it] = red_mask8(v[it], xv[it], rsc, rsh);
+                    red_acc8(v[it], xv[it], ra, rb);
+                }
+                *reinterpret_cast<uint4*>(out + e0 + (i0 + it) * estep) = v[it];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < SITERS; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / CPR, ch = idx % CPR;
+            const long m = m0 + row;
+            if (m < g.M) {
+                uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+                if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
+                if constexpr (RED) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8);
+                    if (red_coef) v = red_mask8(v, xv, rsc, rsh);
+                    red_acc8(v, xv, ra, rb);
+                }
+                *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
+            }
         }
     }
+#ifdef PPV_STAMPS
+    PPV_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PPV_STAMP(6);
+    PPV_STAMP_FLUSH(0, 0);
+#endif
     if constexpr (RED) {
         __syncthreads();                                        // every chunk of the staged tile has been read
         red_finish();
@@ -724,7 +804,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     } while (0)
 #define PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, REDOK_)                                                               \
     do {                                                                                                                \
-        constexpr int lds = NS_ * (BM_ + BN_) * BK_ * 2;                                                                \
+        constexpr int ring = NS_ * (BM_ + BN_) * BK_ * 2, epi = BM_ * (BN_ * 2 + 32) + 4096, lds = ring > epi ? ring : epi;             \
         const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;                                                      \
         auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, false>;                                         \
         auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, true, false>;                                          \

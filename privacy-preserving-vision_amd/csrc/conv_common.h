@@ -124,6 +124,12 @@ extern __device__ unsigned long long* g_stamps;
 #define PPV_STAMP_FLUSH(base, who) do { } while (0)
 #endif
 
+// conv_halo.hip: 3x3 / stride 1 / pad 1 convolutions whose 256-row tiles are whole image rows (input tile + border resident in LDS).
+bool conv3x3_halo_supported(const ConvGeom& g, int Cs, int div);
+int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
+                        const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
+                        const ConvGeom& g, int stat_rows, hipStream_t stream);
+
 // conv_stream.hip: 1x1 convolutions with at most 256 input channels (pixel rows resident in registers, weights streamed).
 // Returns false when the problem is outside that kernel (the caller then takes a tiled kernel).
 bool conv1x1_stream_supported(const ConvGeom& g, int Cs, int div);

@@ -1,0 +1,278 @@
+// 3x3 / stride 1 / pad 1 NHWC bf16 convolution with the input tile RESIDENT in LDS ("halo" form), gfx950.
+//
+// Same GEMM as conv_gemm_pipe_kernel (rows = output pixels, columns = output channels, K = taps x input channels; reference
+// semantics: the 3x3 convolutions of torchvision's Bottleneck behind Image_Caption/models.py:17-21 and their data gradients), other
+// K order.  The tiled kernel walks K tap-major and stages a [256 pixels x 64 channels] slice of the input for EVERY tap: the same
+// pixels nine times, shifted.  tools/tiled_timeline.py (layer 3, 256 -> 256 @ 16 x 16, B = 128): K loop 39.5 of 44.6 us per
+// workgroup at 45 GB/s of LDS-DMA per CU (the L2 -> LDS rate), MFMA pipe 30 % busy -- the launch is bound by staged bytes, and
+// 2/3 of them are those re-staged input slices.  Here a workgroup's 256 output pixels are whole image rows (16 x 16: one image;
+// 32 x 32: 8 rows), so the pixels all nine taps touch are that rectangle plus a one-pixel border: per 64-channel chunk the
+// (TH + 2) x (W + 2) halo tile is staged ONCE (<= 344 pixels x 128 B), the nine taps read it at shifted rows, and only the weights
+// stream (one [128 x 64] tap slice per step through a four-slot ring).  Staged bytes per workgroup and chunk: 41-44 KB + 9 x 16 KB
+// against 9 x 48 KB.
+//
+// Pipeline: one barrier and one counted vmcnt wait per step (tap); step t computes weight slot t % 4 from fragments whose first
+// half was read during step t-1, while slice t+1 has landed and t+2, t+3 are in flight; the NEXT chunk's halo tile is requested in
+// 1-KiB slices during the first steps of the current chunk into the other halo buffer (free since the previous chunk's last step).
+// LDS-DMA completes in order, so a step's wait covers everything older than the weight slice it needs -- the halo slices of a
+// chunk are all older than the chunk's first weight slice.
+// Bank conflicts: a halo row is 128 B = 8 chunks of 16 B, stored at chunk ^ (halo column & 7): the 16 lanes of an A-fragment read
+// hold 16 consecutive columns of one image row at one logical chunk -> 8 distinct physical chunks twice = conflict-free b128 reads
+// for every tap shift (8-pixel-wide images: two rows per fragment, 2-way).  Weight rows as in conv_gemm_pipe_kernel (chunk ^ row & 7).
+#include "conv_common.h"
+#include "conv_tile_epilogue.h"
+
+namespace ppv {
+
+struct HaloGeom {
+    int H, W, TH, IMGS;      // image rows / columns, tile rows per image, images per tile (IMGS * TH * W == 256)
+    int pitch;               // W + 2
+    int hpx;                 // halo pixels of a tile: IMGS * (TH + 2) * pitch  (<= 344)
+    int hpi;                 // 1-KiB halo instructions per chunk: ceil(hpx / 8)
+    int hpw;                 // steps that carry a halo slice: ceil(hpi / 8)  (<= 6)
+    int tiles_n;
+};
+
+constexpr int HL_BM = 256, HL_BN = 128, HL_BK = 64, HL_NT = 512;
+constexpr int HL_HALO_PX = 344, HL_HALO_BYTES = HL_HALO_PX * 128, HL_WSTAGE = HL_BN * HL_BK * 2, HL_NWS = 4;
+constexpr int HL_LDS = 2 * HL_HALO_BYTES + HL_NWS * HL_WSTAGE;               // 153 600 B: one workgroup per CU
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform
+    if (n >= 3) wait_vmcnt_le<3>();
+    else if (n == 2) wait_vmcnt_le<2>();
+    else if (n == 1) wait_vmcnt_le<1>();
+    else wait_vmcnt_le<0>();
+}
+
+template <bool RED>
+__global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+                                                                void* __restrict__ Out, float* __restrict__ stat_part,
+                                                                const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
+                                                                const bf16_t* __restrict__ zero_page, ConvGeom g, HaloGeom hg,
+                                                                int stat_rows, const bf16_t* __restrict__ red_x,
+                                                                const float* __restrict__ red_coef) {
+    constexpr int MI = 4, NI = 4, WN = 2, WROWS = 64, WCOLS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const s_halo = smem;
+    char* const s_w = smem + 2 * HL_HALO_BYTES;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: scalar, so the step's
+    int bid = blockIdx.x;                                                                              // wait / issue conditions are too
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / hg.tiles_n, tile_n = bid % hg.tiles_n;
+    const long m0 = (long)tile_m * HL_BM;
+    const int n0 = tile_n * HL_BN;
+    const int HW = hg.H * hg.W;
+    const int b0 = (int)(m0 / HW), y0 = (int)(m0 % HW) / hg.W;
+    const int rl = lane >> 3, p8 = lane & 7;
+    const long zdelta = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+
+    // ---- halo slices of this wave: slice t = 1-KiB instruction t * 8 + wave = halo pixels (t * 8 + wave) * 8 .. + 7
+    constexpr int MAXS = 6;                                 // ceil(344 / 64)
+    long h_off[MAXS];
+    int h_inc[MAXS];
+    const int img_px = (hg.TH + 2) * hg.pitch;
+#pragma unroll
+    for (int t = 0; t < MAXS; ++t) {
+        const int hp = (t * 8 + wave) * 8 + rl;
+        const int img = hp / img_px, rem = hp % img_px;
+        const int hy = rem / hg.pitch, hx = rem % hg.pitch;
+        const int y = y0 + hy - 1, x = hx - 1;
+        const bool ok = (hp < hg.hpx) & ((unsigned)y < (unsigned)hg.H) & ((unsigned)x < (unsigned)hg.W);
+        const int gch = p8 ^ (hx & 7);
+        h_off[t] = (ok ? ((long)(b0 + img) * HW + (long)y * hg.W + x) * g.Cs * 2 : zdelta) + gch * 16;
+        h_inc[t] = ok ? HL_BK * 2 : 0;
+    }
+    auto issue_halo_slice = [&](int t, int buf) __attribute__((always_inline)) {       // t < hg.hpw, t * 8 + wave < hg.hpi checked by caller
+        GLDS16(reinterpret_cast<const char*>(X) + h_off[t], s_halo + buf * HL_HALO_BYTES + (t * 8 + wave) * 1024);
+        h_off[t] += h_inc[t];
+    };
+    // ---- weight slices: rows n0 .. n0 + 127 of Wt [N][9][Cs], 64 channels of one tap per step
+    const long wrow = 9L * g.Cs;
+    const bf16_t* wbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 8 + rl;
+        wbase[i] = Wt + (long)(n0 + row) * wrow + (p8 ^ (row & 7)) * 8;
+    }
+    auto issue_w = [&](int slot, int tap, int c0) __attribute__((always_inline)) {
+        char* sb = s_w + slot * HL_WSTAGE;
+        const int koff = tap * g.Cs + c0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) GLDS16(wbase[i] + koff, sb + (i * 8 + wave) * 1024);
+    };
+
+    // ---- A-fragment addressing
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    int hb[MI];
+    int xk = 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = wm * WROWS + mi * 16 + fr;
+        const int x = p % hg.W, yy = (p / hg.W) % hg.TH, img = p / (hg.W * hg.TH);
+        hb[mi] = (img * img_px + yy * hg.pitch + x) * 128;
+        xk = x;                                             // x & 7 is the same for every mi (tiles start at multiples of 16 or 8)
+    }
+    int aoff[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) aoff[s][kk] = ((kk * 4 + fq) ^ ((xk + s) & 7)) * 16;
+    int boff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) boff[kk] = ((kk * 4 + fq) ^ (fr & 7)) * 16;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = g.Cs / HL_BK, T = nchunks * 9;
+    // prologue: halo tile of chunk 0, weight slices of steps 0, 1, 2
+#pragma unroll
+    for (int t = 0; t < MAXS; ++t)
+        if (t < hg.hpw && t * 8 + wave < hg.hpi) issue_halo_slice(t, 0);
+    issue_w(0, 0, 0);
+    issue_w(1, 1, 0);
+    issue_w(2, 2, 0);
+    wait_vmcnt_le<4>();                                       // halo 0 and slice 0 are older than slices 1, 2
+    __builtin_amdgcn_s_barrier();
+
+    // Register pipeline: a step's first-half fragments (kk = 0) are read during the PREVIOUS step's second-half MFMAs, its
+    // second-half fragments during its own first-half MFMAs -- the matrix pipe never waits for the LDS round trip that used to
+    // open every step (measured before: 2530 cycles per step against 1024 of MFMA issue per SIMD).
+    // The fragment reads are inline asm with hand-counted lgkmcnt waits: left to hipcc, every first-half MFMA batch sat behind
+    // s_waitcnt lgkmcnt(0), i.e. behind the second-half reads issued just before it (LDS returns in order: lgkmcnt(8) is enough).
+    bf16x8 af0[MI], bf0[NI];
+    auto lds_addr = [](const char* p) __attribute__((always_inline)) {
+        return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+    };
+    auto load_frags = [&](bf16x8 (&af)[MI], bf16x8 (&bfr)[NI], const char* hbuf, const char* sb, int shift, int s, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const unsigned a = lds_addr(hbuf + hb[mi] + shift + aoff[s][kk]);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[mi]) : "v"(a));
+        }
+        const unsigned b = lds_addr(sb + (wn * WCOLS + fr) * 128 + boff[kk]);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[0]) : "v"(b));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(bfr[1]) : "v"(b));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bfr[2]) : "v"(b));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(bfr[3]) : "v"(b));
+    };
+    auto lgkm_wait8 = []() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load_frags(af0, bf0, s_halo, s_w, 0, 0, 0);
+
+    int step = 0, slot = 0;
+    bool had_prev = false;                                   // this wave issued a halo slice in the previous step
+    for (int c = 0; c < nchunks; ++c) {
+        const char* hcur = s_halo + (c & 1) * HL_HALO_BYTES;
+        const char* hoth = s_halo + ((c + 1) & 1) * HL_HALO_BYTES;
+        const bool more = c + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, s = tap % 3;
+            // slice step + 1 (and, at a chunk's last tap, the next halo tile: older than that slice) has landed for this wave ...
+            wait_vmcnt_dyn((step + 2 < T ? 2 : 0) + (had_prev ? 1 : 0));
+            __builtin_amdgcn_s_barrier();                    // ... and for every wave; every wave is past step - 1
+            had_prev = false;
+            if (tap < MAXS) {
+                if (more && tap < hg.hpw && tap * 8 + wave < hg.hpi) {
+                    issue_halo_slice(tap, (c + 1) & 1);
+                    had_prev = true;
+                }
+            }
+            if (step + 3 < T) {
+                int t3 = tap + 3, c3 = c;
+                if (t3 >= 9) { t3 -= 9; ++c3; }
+                issue_w((slot + 3) & 3, t3, c3 * HL_BK);
+            }
+            const char* sb = s_w + slot * HL_WSTAGE;
+            const int shift = (r * hg.pitch + s) * 128;
+            bf16x8 af1[MI], bf1[NI];
+            load_frags(af1, bf1, hcur, sb, shift, s, 1);
+            lgkm_wait8();                                    // the first-half fragments (read one step ago) are in
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[mi], bf0[ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // unconditional (the last step reads a landed slot for nothing): a branch here makes hipcc drain lgkmcnt to 0 below
+                const int tn = (tap + 1) % 9;
+                const int rn = tn / 3, sn = tn % 3;
+                load_frags(af0, bf0, tap == 8 ? hoth : hcur, s_w + ((slot + 1) & 3) * HL_WSTAGE, (rn * hg.pitch + sn) * 128, sn, 0);
+            }
+            lgkm_wait8();                                    // this step's second-half fragments are in
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[mi], bf1[ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ++step;
+            slot = (slot + 1) & 3;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the last step's look-ahead reads: their registers are free only now
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af0[i]), "v"(bf0[i]));
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#ifdef PPV_STAMPS
+    unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, stamp_);
+#else
+    tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0);
+#endif
+}
+
+static bool halo_geom(const ConvGeom& g, int Cs, int div, HaloGeom* hg) {
+    if (g.R != 3 || g.S != 3 || g.a != 1 || g.off != -1 || g.offw != -1 || div != 1 || g.Hs != g.Ho || g.Ws != g.Wo) return false;
+    const int W = g.Wo, H = g.Ho;
+    if (W != 16 && W != 32) return false;           // 8 and 64 columns need 400 halo pixels (and are layer 4 / layer 1: too few tiles / 64 channels)
+    if (Cs % HL_BK || g.N % HL_BN || g.M % HL_BM) return false;
+    const int rows = HL_BM / W;                      // image rows per tile
+    const int TH = rows < H ? rows : H;
+    if (H % TH || (HL_BM % (TH * W))) return false;
+    const int IMGS = HL_BM / (TH * W);
+    if (IMGS > 1 && TH != H) return false;
+    hg->H = H; hg->W = W; hg->TH = TH; hg->IMGS = IMGS; hg->pitch = W + 2;
+    hg->hpx = IMGS * (TH + 2) * (W + 2);
+    hg->hpi = (hg->hpx + 7) / 8;
+    hg->hpw = (hg->hpi + 7) / 8;
+    hg->tiles_n = g.N / HL_BN;
+    return hg->hpx <= HL_HALO_PX && hg->hpw <= 6;
+}
+
+bool conv3x3_halo_supported(const ConvGeom& g, int Cs, int div) {
+    HaloGeom hg;
+    return halo_geom(g, Cs, div, &hg);
+}
+
+int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
+                        const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
+                        const ConvGeom& g, int stat_rows, hipStream_t stream) {
+    HaloGeom hg;
+    if (!halo_geom(g, g.Cs, 1, &hg)) return PPV_ERR_BAD_SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+        attr_set = true;
+    }
+    const int grid = (int)(g.M / HL_BM) * hg.tiles_n;
+    if (red_x)
+        conv3x3_halo_kernel<true><<<grid, HL_NT, HL_LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, red_x, red_coef);
+    else
+        conv3x3_halo_kernel<false><<<grid, HL_NT, HL_LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, nullptr, nullptr);
+    return ppv_last_error();
+}
+
+}  // namespace ppv

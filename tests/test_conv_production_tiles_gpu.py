@@ -145,7 +145,8 @@ def test_forced_tile_dgrad(variant, B, H, Cin, Cout, k, stride):
 
 # problems that the automatic rule sends to each production tile (t256 = ceil(M / 256) * N / 128):
 AUTO_FWD = [
-    (32, 32, 256, 256, 3, 1),     # M = 32 768, N = 256: t256 = 256  -> <256,128,3,64,1>
+    (32, 32, 256, 256, 3, 1),     # M = 32 768, N = 256: t256 = 256  -> conv_halo.hip (8 image rows per tile); variant 7: <256,128,3,64,1>
+    (128, 16, 256, 256, 3, 1),    # the layer-3 conv2 shape itself at B = 128 -> conv_halo.hip (one image per tile)
     (64, 32, 128, 512, 1, 1),     # M = 65 536, N = 512: t256 = 1024 -> <256,128,3,32,2>
     (32, 64, 256, 64, 1, 1),      # M = 131 072, N = 64              -> <128,64,3,32,4>
     (33, 64, 64, 64, 3, 1),       # ragged M, 64 columns, 3x3        -> <128,64,3,32,4>
@@ -156,7 +157,7 @@ AUTO_FWD = [
     (32, 64, 256, 512, 1, 2),     # layer-2 projection shortcut (stride 2) -> conv_stream.hip, strided pixel rows
 ]
 AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
-    (32, 32, 256, 256, 3, 1),     # N = 256, M = 32 768 -> <256,128,3,64,1>
+    (32, 32, 256, 256, 3, 1),     # N = 256, M = 32 768 -> conv_halo.hip; variant 7: <256,128,3,64,1>
     (64, 32, 512, 128, 1, 1),     # N = 512, M = 65 536 -> <256,128,3,32,2> (conv1 data gradient: addend + mask + sums)
     (32, 64, 64, 256, 1, 1),      # N = 64, M = 131 072 -> <128,64,3,32,4>
     (16, 32, 256, 512, 1, 2),     # stride-2 projection data gradient (zero-page taps), N = 256
@@ -165,21 +166,43 @@ AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 8])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", AUTO_FWD)
 def test_benchmark_sized_forward(variant, B, H, Cin, Cout, k, stride):
     if variant == 8 and (k != 1 or Cin > 256 or Cout < 2 * Cin):
         pytest.skip("outside conv_stream.hip: variant 8 = variant 0")
+    if variant == 7 and (k != 3 or stride != 1 or Cout % 128):
+        pytest.skip("variant 7 (tiled kernels only) differs from variant 0 where conv_halo.hip takes the launch")
     with _variant(variant):
         _check_forward(B, H, Cin, Cout, k, stride)
 
 
-@pytest.mark.parametrize("variant", [0, 8])
+@pytest.mark.parametrize("variant", [0, 7, 8])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", AUTO_DGRAD)
 def test_benchmark_sized_dgrad(variant, B, H, Cin, Cout, k, stride):
     if variant == 8 and (k != 1 or Cout > 256 or Cin < 2 * Cout):
         pytest.skip("outside conv_stream.hip: variant 8 = variant 0")
+    if variant == 7 and (k != 3 or stride != 1 or Cin % 128):
+        pytest.skip("variant 7 (tiled kernels only) differs from variant 0 where conv_halo.hip takes the launch")
     with _variant(variant):
+        _check_dgrad(B, H, Cin, Cout, k, stride)
+
+
+# conv_halo.hip forced (variant 9) on both tile geometries it has: 16 x 16 (one image per tile), 32 x 32 (8 image rows per tile), with
+# one / two / three / four 64-channel chunks (the halo double buffer turns over) and one / two column tiles
+HALO = [(16, 16, 128, 128, 3, 1), (4, 32, 128, 256, 3, 1), (4, 16, 192, 128, 3, 1), (3, 32, 64, 128, 3, 1), (16, 16, 256, 256, 3, 1),
+        (1, 32, 256, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", HALO)
+def test_halo_forward(B, H, Cin, Cout, k, stride):
+    with _variant(9):
+        _check_forward(B, H, Cin, Cout, k, stride)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride", [c for c in HALO if c[2] % 128 == 0])
+def test_halo_dgrad(B, H, Cin, Cout, k, stride):
+    with _variant(9):
         _check_dgrad(B, H, Cin, Cout, k, stride)
 
 

@@ -41,8 +41,8 @@ def timeline(fn):
     md = lambda v: f"{np.median(v):5.2f}/{np.percentile(v, 90):5.2f}"
     st = np.sort(s[:, 0])
     print(f"   {len(s)} WGs; starts: p25 {st[len(st)//4]:5.1f} p50 {st[len(st)//2]:5.1f} p75 {st[3*len(st)//4]:5.1f} max {st[-1]:5.1f}; last drain {s[:, 6].max():5.1f} us\n"
-          f"   per WG median/p90 us: setup+issue {md(s[:, 1] - s[:, 0])}, first stage lands {md(s[:, 2] - s[:, 1])}, second {md(s[:, 5] - s[:, 2])}, "
-          f"rest of K loop {md(s[:, 3] - s[:, 5])}, epilogue: tile -> LDS {md(s[:, 7] - s[:, 3])}, barrier + stat atomics + store loop {md(s[:, 4] - s[:, 7])}, store drain {md(s[:, 6] - s[:, 4])}, total {md(s[:, 6] - s[:, 0])}")
+          f"   per WG median/p90 us: address setup {md(s[:, 5] - s[:, 0])}, ring prologue issued {md(s[:, 1] - s[:, 5])}, first stage lands {md(s[:, 2] - s[:, 1])}, "
+          f"K loop {md(s[:, 3] - s[:, 2])}, epilogue: tile -> LDS {md(s[:, 7] - s[:, 3])}, barrier + stat atomics + store loop {md(s[:, 4] - s[:, 7])}, store drain {md(s[:, 6] - s[:, 4])}, total {md(s[:, 6] - s[:, 0])}")
 
 
 def cold(shape, n=6):

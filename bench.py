@@ -112,11 +112,14 @@ def head_stand_in(enc_out):
     return _CellsMeanSquare.apply(cells, enc_out.shape[1])
 
 
-def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=False):
+def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=False, graph=False):
+    """graph=True: the step is going to be captured into a hipGraph (graph_step below): Adam keeps its step counters on the device
+    (capturable) and the cross-STEP overlap of the encoder's Adam with the next camera forward is off (a captured step is
+    self-contained)."""
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
-    opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True)
-    opt_cam = torch.optim.Adam(cam_params, lr=5e-7)
+    opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True, capturable=graph)
+    opt_cam = torch.optim.Adam(cam_params, lr=5e-7, capturable=graph)
     rank = dist.get_rank() if dist.is_initialized() else 0
     imgs = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(device)
     # PPV_BENCH_H2D=1: the PCIe-inclusive variant (DESIGN.md, never `value`): the batch starts in pinned host memory every step
@@ -124,12 +127,12 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     if decoder is not None:                                                       # BASELINE.json config 3 / 5
         from torch.nn.utils.rnn import pack_padded_sequence
         dec_params = [p for p in decoder.parameters() if p.requires_grad]
-        opt_dec = torch.optim.Adam(dec_params, lr=4e-4, fused=True)                # train.py:33,100-101
+        opt_dec = torch.optim.Adam(dec_params, lr=4e-4, fused=True, capturable=graph)   # train.py:33,100-101
         gen = torch.Generator().manual_seed(100 + rank)
         caps = torch.randint(0, decoder.vocab_size, (batch, 52), generator=gen).to(device)
         caplens = torch.randint(9, 19, (batch, 1), generator=gen).to(device)      # COCO-like lengths incl. <start>/<end>
 
-    opt_stream = torch.cuda.Stream(device=device) if os.environ.get("PPV_OPT_OVERLAP", "1") != "0" else None
+    opt_stream = torch.cuda.Stream(device=device) if (os.environ.get("PPV_OPT_OVERLAP", "1") != "0" and not graph) else None
 
     def step():
         nonlocal imgs
@@ -189,6 +192,29 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         return loss
 
     return step, enc_params + cam_params
+
+
+def graph_step(step, device, warm=2):
+    """Capture one whole training step (camera + encoder forward, losses, backward incl. its side streams, clipping, Adam, weight
+    re-layout: ~800 launches) into a hipGraph and return a callable that replays it.  A dependent launch costs ~4.2 us on the
+    command processor when enqueued one by one and ~1.6 us inside a graph (tools/micro/graph_chain.py); every replay executes the
+    same kernels on the same (synthetic, resident) batch as the eager step."""
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warm):                                   # allocator / lazy-init warm-up on the capture stream
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        loss = step()
+
+    def replay():
+        g.replay()
+        return loss
+    replay.graph = g
+    return replay
 
 
 def _latest_profile(suffix):
@@ -414,7 +440,11 @@ def main():
         torch.manual_seed(3)
         decoder = DecoderWithAttention(attention_dim=512, embed_dim=512, decoder_dim=512, vocab_size=9490, dropout=0.3).to(device)
         decoder.train()
-    step, params = make_step(camera, encoder, args.batch, device, sync, decoder, args.ssim)
+    use_graph = os.environ.get("PPV_BENCH_GRAPH", "0") == "1"
+    step, params = make_step(camera, encoder, args.batch, device, sync, decoder, args.ssim, graph=use_graph)
+    eager_step = step
+    if use_graph:
+        step = graph_step(step, device)
 
     for _ in range(args.warmup):
         step()
@@ -433,7 +463,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    roof = None if args.no_roofline else roofline_of_dominant_kernel(step)
+    roof = None if args.no_roofline else roofline_of_dominant_kernel(eager_step)
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
         line = {

@@ -138,6 +138,13 @@ int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S
 size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs);
 int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs,
                    int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream);
+
+/* P <= 24 weight gradients of ONE 1x1 / unit-stride shape in one launch, each reduced over all its rows by one workgroup per
+ * tile (no split-M slabs, no scratch, no reduce launch): G[p] [B,H,W,N] bf16, X[p] [B,H,W,Cs] bf16 -> out[p] [N][Cs] f32.
+ * Host arrays of device pointers.  Replaces P cuDNN weight-gradient calls of the bottleneck 1x1 convolutions behind
+ * Image_Caption/models.py:17-21 (autograd of torchvision Bottleneck.conv1 / conv3).  N % 128 == 0, Cs % 128 == 0. */
+int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* const* out, int P, const void* zero_page, int B, int H,
+                         int W, int Cs, int N, hipStream_t stream);
 int ppv_wgrad_set_variant(int v);  /* tuning hook, see csrc/conv_wgrad_stem.hip */
 /* stem 7x7/2 conv (resnet.0), f32 NCHW sensor image in, NHWC bf16 out; data gradient via ppv_conv_gemm (N = 16) */
 int ppv_stem_weight_layout(const float* w, void* out, int mode, ppv_stream_t stream);

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "ppv_conv_set_variant": (_I, [_I]),
     "ppv_conv_wgrad_scratch_bytes": (_Z, [_L, _I, _I, _I, _I]),
     "ppv_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "ppv_conv_wgrad_group": (_I, [_P, _P, _P, _I, _P] + [_I] * 5 + [_P]),
     "ppv_wgrad_set_variant": (_I, [_I]),
     "ppv_stem_weight_layout": (_I, [_P, _P, _I, _P]),
     "ppv_stem_conv": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -179,6 +179,28 @@ def conv_wgrad(g, x, R, S, stride, pad, scratch=None, out=None):
     return out
 
 
+def conv_wgrad_group(gs, xs, outs=None):
+    """Weight gradients of up to 24 1x1 / unit-stride convolutions of ONE shape in one launch, each reduced over all its rows (no
+    split-M slabs, no reduce launch: csrc/conv_wgrad_stem.hip conv_wgrad_group_kernel).  gs[i] [B,H,W,Cout] bf16, xs[i] [B,H,W,Cin] bf16
+    -> list of [Cout,Cin,1,1] f32 (outs[i] when given: contiguous f32 destinations, e.g. slices of a gradient bucket)."""
+    import ctypes
+    P = len(gs)
+    B, H, W, Cout = gs[0].shape
+    Cin = xs[0].shape[-1]
+    assert 1 <= P <= 24 and all(g.shape == gs[0].shape and g.is_contiguous() for g in gs)
+    assert all(x.shape == (B, H, W, Cin) and x.is_contiguous() for x in xs)
+    if outs is None:
+        outs = [None] * P
+    outs = [o if o is not None else torch.empty((Cout, Cin, 1, 1), dtype=F32, device=gs[0].device) for o in outs]
+    assert all(o.shape == (Cout, Cin, 1, 1) and o.dtype == F32 and o.is_contiguous() for o in outs)
+    arr = ctypes.c_void_p * P
+    ga, xa, oa = arr(*[g.data_ptr() for g in gs]), arr(*[x.data_ptr() for x in xs]), arr(*[o.data_ptr() for o in outs])
+    _timed("conv_wgrad", 2.0 * P * B * H * W * Cout * Cin, lambda: check(
+        L().ppv_conv_wgrad_group(ga, xa, oa, P, ptr(zero_page(gs[0].device)), B, H, W, Cin, Cout, stream_ptr()), "ppv_conv_wgrad_group"),
+        nbytes=P * ((gs[0].numel() + xs[0].numel()) * 2.0 + outs[0].numel() * 4.0))
+    return outs
+
+
 # ----------------------------------------------------------------------------- dense layers in exact f32 (csrc/gemm_f32.hip)
 def linear_f32(x, w, bias=None, out=None):
     """out = x @ w^T (+ bias) on v_mfma_f32_16x16x4_f32 (exact f32).  x [m, K] f32 with unit column stride (rows may be strided,

@@ -193,36 +193,18 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int
 // workgroup count against the two-stage kernel also halves the f32-atomic bytes (the other bound of this kernel).
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// One 128 (c) x TN (n) tile of dW over the rows [m_begin, m_end): the body of conv_wgrad_pipe_kernel and conv_wgrad_group_kernel.
 template <int TN, int NSTAGE>
-__global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
-                                                                    float* __restrict__ dW,
-                                                                    const bf16_t* __restrict__ zero_page, WgradGeom g) {
+__device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X, float* __restrict__ dst,
+                                                const bf16_t* __restrict__ zero_page, const WgradGeom& g, long m_begin, long m_end,
+                                                int n0, int tap, int c0, bool atomic) {
     constexpr int NT = TN * 2, NW = NT / 64, NH = TN / 128;               // threads, waves, 128-column halves of G
     constexpr int HALF = 64 * 256;                                        // one [64][128] bf16 tile
     constexpr int STAGE_BYTES = (NH + 1) * HALF;
     constexpr int GI = (NH * 16) / NW, XI = 16 / NW, L = GI + XI;         // wave-instructions per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // XCD-aware decode of a 1-D grid: every tile of one m-slice runs on the SAME XCD at the same time, so the G rows
-    // (shared by the c-tiles / taps) and the X rows (shared by the n-tiles) are fetched from HBM once and re-read from
-    // that XCD's L2 (measured before: L2 hit rate 1 %, 2.3x over-fetch).  blocks b and b+8 share an XCD (speed only).
-    const int ctiles = g.Cs / 128;
-    const int tiles_y = g.R * g.S * ctiles, tiles = (g.N / TN) * tiles_y;
-    int zslice, tl;
-    if (g.xcd_group) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        zslice = (idx / tiles) * 8 + xcd;
-        tl = idx % tiles;
-    } else {
-        zslice = blockIdx.x / tiles;
-        tl = blockIdx.x % tiles;
-    }
-    if (zslice >= g.splits) return;
-    const int n0 = (tl % (g.N / TN)) * TN, by = tl / (g.N / TN);
-    const int tap = by / ctiles, c0 = (by % ctiles) * 128;
     const int r = tap / g.S, s = tap % g.S;
-    const long m_begin = (long)zslice * g.stages_per_split * 64;
-    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
     const int nst = (int)((m_end - m_begin + 63) / 64);
     if (nst <= 0) return;
     const int HoWo = g.Ho * g.Wo;
@@ -316,7 +298,6 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
 
     const int fr = lane & 15, fq = lane >> 4;
     const long wrow = (long)g.R * g.S * g.Cs;
-    float* dst = dW + (long)zslice * g.slab_elems;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -326,9 +307,55 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
                 const int n = n0 + wm * 64 + mi * 16 + fq * 4 + j;
                 const int c = c0 + wn * 64 + ni * 16 + fr;
                 float* q = &dst[(long)n * wrow + (long)tap * g.Cs + c];
-                if (g.slab_elems) *q = acc[mi][ni][j];        // per-slice slab: plain stores (4-5x the f32-atomic rate)
+                if (!atomic) *q = acc[mi][ni][j];             // per-slice slab / final tensor: plain stores (4-5x the f32-atomic rate)
                 else atomicAdd(q, acc[mi][ni][j]);
             }
+}
+
+template <int TN, int NSTAGE>
+__global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                                    float* __restrict__ dW,
+                                                                    const bf16_t* __restrict__ zero_page, WgradGeom g) {
+    // XCD-aware decode of a 1-D grid: every tile of one m-slice runs on the SAME XCD at the same time, so the G rows
+    // (shared by the c-tiles / taps) and the X rows (shared by the n-tiles) are fetched from HBM once and re-read from
+    // that XCD's L2 (measured before: L2 hit rate 1 %, 2.3x over-fetch).  blocks b and b+8 share an XCD (speed only).
+    const int ctiles = g.Cs / 128;
+    const int tiles_y = g.R * g.S * ctiles, tiles = (g.N / TN) * tiles_y;
+    int zslice, tl;
+    if (g.xcd_group) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        zslice = (idx / tiles) * 8 + xcd;
+        tl = idx % tiles;
+    } else {
+        zslice = blockIdx.x / tiles;
+        tl = blockIdx.x % tiles;
+    }
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % (g.N / TN)) * TN, by = tl / (g.N / TN);
+    const int tap = by / ctiles, c0 = (by % ctiles) * 128;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    wgrad_pipe_body<TN, NSTAGE>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0);
+}
+
+// Several weight gradients of ONE shape (1x1, unit stride: the conv1 / conv3 of a layer's bottlenecks) in one launch, each reduced
+// over ALL its rows by one workgroup per tile: no split-M slabs, no reduce launch, the result goes straight to the torch tensor.
+// tools/micro/wgrad_longk.py: the slab form costs 59-64 us per layer-3 problem (kernel + reduce), the un-split steady state 39-43 us.
+// Problem p runs on XCD p % 8 with all its tiles at once, so the tiles walk the same rows of G and X through that XCD's L2.
+struct WgradGroupPtrs {
+    const bf16_t* G[24];
+    const bf16_t* X[24];
+    float* out[24];
+};
+
+template <int TN, int NSTAGE>
+__global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_group_kernel(WgradGroupPtrs ptrs, int P, const bf16_t* __restrict__ zero_page, WgradGeom g) {
+    const int tiles = (g.N / TN) * (g.Cs / 128);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int p = (idx / tiles) * 8 + xcd, tl = idx % tiles;
+    if (p >= P) return;
+    const int n0 = (tl % (g.N / TN)) * TN, c0 = (tl / (g.N / TN)) * 128;
+    wgrad_pipe_body<TN, NSTAGE>(ptrs.G[p], ptrs.X[p], ptrs.out[p], zero_page, g, 0, g.M, n0, 0, c0, false);
 }
 
 // ----------------------------------------------------------------------------- streamed weight gradient (one tap per workgroup)
@@ -1243,6 +1270,31 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         conv_wgrad_pipe_kernel<128, 4><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     }
     wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)splits);
+    return ppv_last_error();
+}
+
+// P <= 24 weight gradients of one 1x1 / unit-stride shape in one launch, each reduced over all its rows (no scratch, no reduce
+// launch): G[p] [B,H,W,N] bf16, X[p] [B,H,W,Cs] bf16 -> out[p] [N][Cs] f32 (torch layout of a 1x1 weight).  N % 128 == 0, Cs % 128 == 0.
+int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* const* out, int P, const void* zero_page, int B, int H, int W,
+                         int Cs, int N, hipStream_t stream) {
+    if (!G || !X || !out || !zero_page) return PPV_ERR_NULL;
+    if (P < 1 || P > 24 || N % 128 || Cs % 128) return PPV_ERR_BAD_SIZE;
+    WgradGeom g;
+    g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1; g.st = 1; g.pad = 0;
+    g.M = (long)B * H * W;
+    if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;
+    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs;
+    WgradGroupPtrs ptrs;
+    for (int p = 0; p < 24; ++p) {
+        const int q = p < P ? p : 0;
+        if (!G[q] || !X[q] || !out[q]) return PPV_ERR_NULL;
+        ptrs.G[p] = (const bf16_t*)G[q]; ptrs.X[p] = (const bf16_t*)X[q]; ptrs.out[p] = out[q];
+    }
+    const int tiles = (N / 128) * (Cs / 128);
+    constexpr int lds = 2 * 2 * 64 * 256;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    conv_wgrad_group_kernel<128, 2><<<(unsigned)(8 * ((P + 7) / 8) * tiles), 256, lds, stream>>>(ptrs, P, (const bf16_t*)zero_page, g);
     return ppv_last_error();
 }
 

@@ -265,6 +265,43 @@ class _TrunkFn(torch.autograd.Function):
                 if sync is not None:
                     loose.append(t)
 
+        # Same-shape 1x1 / unit-stride weight gradients (conv1 / conv3 of a layer's bottlenecks: 22 + 23 in layer 3) are collected and
+        # computed by ONE launch per shape without split-M slabs (co.conv_wgrad_group) once the layer's data-gradient chain has
+        # produced them all; PPV_WGRAD_GROUP=0 computes each where it arises (the round-1 form), =n sets the smallest group.
+        group_min = int(_os.environ.get("PPV_WGRAD_GROUP", "0"))
+        pending = {}
+
+        def _gkey(rec, gx):
+            return (rec.conv.in_channels, rec.conv.out_channels, gx.shape[1] * gx.shape[2])
+
+        w_counts = {}
+        if group_min:
+            for blk_, sv_ in zip(enc._blocks, ctx.blocks):
+                for rec_, gy_ in zip(blk_, (sv_[1], sv_[4], sv_[7], sv_[9])):
+                    if rec_ is not None and rec_.conv.weight.requires_grad and rec_.k == 1 and rec_.stride == 1 \
+                            and rec_.conv.in_channels % 128 == 0 and rec_.conv.out_channels % 128 == 0:
+                        k_ = _gkey(rec_, gy_)
+                        w_counts[k_] = w_counts.get(k_, 0) + 1
+
+        def flush_group(key):
+            items = pending.pop(key, [])
+            if not items:
+                return
+            gs, xs, ws = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
+            dsts = [sync.grad_view(w) for w in ws] if bucketed else None
+            if side is not None:
+                ev = torch.cuda.Event(); ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    dws = co.conv_wgrad_group(gs, xs, dsts)
+                    for t in gs + xs:
+                        t.record_stream(side)
+                    for w, dw in zip(ws, dws):
+                        deliver(w, dw)
+            else:
+                for w, dw in zip(ws, co.conv_wgrad_group(gs, xs, dsts)):
+                    deliver(w, dw)
+
         def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None, sums2=None):
             trainable = rec.conv.weight.requires_grad
             affine = rec.bn.weight.requires_grad
@@ -272,7 +309,15 @@ class _TrunkFn(torch.autograd.Function):
             gx, gpre, dg, db = co.bn_bwd(gy, y, xraw, coef, relu, want_gpre=want_gpre, want_affine=affine,
                                          part=bn_part(xraw.shape[-1]) if sums is None else sums, part_ready=sums is not None,
                                          sums2=sums2, out_affine=oa)
-            if trainable:
+            if trainable and group_min and rec.k == 1 and rec.stride == 1 and w_counts.get(_gkey(rec, gx), 0) >= group_min:
+                # one of a layer's many same-shape 1x1 convolutions: its weight gradient waits for the others (flush_groups)
+                key = _gkey(rec, gx)
+                for k_ in [k_ for k_ in pending if k_[2] != key[2]]:
+                    flush_group(k_)                            # a key of another resolution: that layer is done
+                pending.setdefault(key, []).append((gx, xin, rec.conv.weight))
+                if len(pending[key]) == 24:
+                    flush_group(key)
+            elif trainable:
                 w = rec.conv.weight
                 dst = sync.grad_view(w) if bucketed else None
                 if side is not None:
@@ -347,6 +392,8 @@ class _TrunkFn(torch.autograd.Function):
                 taps.append((g_blk_out, g))
         g_img = None
         needs_img = ctx.needs_input_grad[1]
+        for k_ in list(pending):
+            flush_group(k_)
         if needs_img or enc._stem.bn.weight.requires_grad or enc._stem.conv.weight.requires_grad:
             raw0, c0, y0, arg0 = ctx.saved["stem"]
             gpre0 = co.maxpool_relu_bwd(g, y0, arg0, (raw0.shape[1], raw0.shape[2]))

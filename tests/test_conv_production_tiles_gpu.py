@@ -238,3 +238,27 @@ def test_benchmark_sized_wgrad(B, H, Cin, Cout, k, stride, variant):
         co.L().ppv_wgrad_set_variant(0)
     assert got.shape == w.shape
     assert rel_err(got, w.grad) < 1e-3
+
+
+@pytest.mark.parametrize("P,B,H,Cin,Cout", [(3, 8, 16, 256, 128), (9, 32, 16, 1024, 256), (24, 4, 8, 128, 384), (2, 5, 7, 128, 128)])
+def test_grouped_wgrad(P, B, H, Cin, Cout):
+    """co.conv_wgrad_group: P same-shape 1x1 weight gradients in one launch, un-split over the rows, against torch autograd per problem
+    (P = 9, 24: the second and third round of the problem -> XCD mapping; 5 x 7 x 7 rows: a ragged last 64-row stage)."""
+    import ppv_amd.convops as co
+    co.zero_page(torch.device("cuda", 0))
+    gs, xs, want = [], [], []
+    for p in range(P):
+        x, w = _mk(B, H, Cin, Cout, 1, seed=p)
+        w.requires_grad_(True)
+        y = F.conv2d(x, w)
+        g = torch.randn(y.shape, generator=torch.Generator().manual_seed(100 + p)).bfloat16().float()
+        y.backward(g)
+        want.append(w.grad)
+        gs.append(g.permute(0, 2, 3, 1).contiguous().cuda().bfloat16())
+        xs.append(x.permute(0, 2, 3, 1).contiguous().cuda().bfloat16())
+    outs = [None] * P
+    outs[0] = torch.full((Cout, Cin, 1, 1), 7.0, device="cuda")            # a caller-provided destination is overwritten, not added to
+    got = co.conv_wgrad_group(gs, xs, outs)
+    assert got[0].data_ptr() == outs[0].data_ptr()
+    for p in range(P):
+        assert rel_err(got[p], want[p]) < 1e-3, p

@@ -80,15 +80,15 @@ __global__ __launch_bounds__(256) void rows_r2c_kernel(const TIN* __restrict__ i
 // ----------------------------------------------------------------------------- column pass
 // otfT layout: [C][NH+1][N]  (kx-major, ky contiguous; entry kx == NH is the Nyquist column).
 template <int R>
-__global__ __launch_bounds__(512) void cols_mul_kernel(const float2* __restrict__ S1, float2* __restrict__ S2,
+__global__ __launch_bounds__(512, 4) void cols_mul_kernel(const float2* __restrict__ S1, float2* __restrict__ S2,
                                                        const float2* __restrict__ otfT,
                                                        const float2* __restrict__ twg, int C, int H_in, int row_off,
                                                        int H_out, int conj_otf, float scale) {
     constexpr int N = 64 * R, NH = N / 2, LD = 17;
     __shared__ float2 s_tw[N];
     __shared__ float2 s_scr[8][fft_scratch_elems<R>()];
-    __shared__ float2 s_tile[N * LD];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    extern __shared__ __attribute__((aligned(16))) float2 s_tile[];   // max(H_in, H_out) x LD: the IC geometry (256 of 512 rows) leaves
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;    // room for two workgroups per CU (load / FFT / store overlap)
     const int plane = blockIdx.y, tile = blockIdx.x, ch = plane % C;
     for (int i = tid; i < N; i += 512) s_tw[i] = twg[i];
     for (int idx = tid; idx < H_in * 8; idx += 512) {
@@ -136,14 +136,25 @@ __global__ __launch_bounds__(512) void cols_mul_kernel(const float2* __restrict_
         }
         ifft_wave<R>(u, s_scr[wave], s_tw, lane);
 #pragma unroll
-        for (int q = 0; q < R; ++q) s_tile[(lane + 64 * q) * LD + c] = make_float2(u[q].x * scale, u[q].y * scale);
+        for (int q = 0; q < R; ++q) {                         // column c of the tile belongs to this wave alone: rows may be overwritten
+            const int row = lane + 64 * q - row_off;
+            if ((unsigned)row < (unsigned)H_out) s_tile[row * LD + c] = make_float2(u[q].x * scale, u[q].y * scale);
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < H_out * 8; idx += 512) {
         const int row = idx >> 3, c4 = idx & 7;
-        const float2 a = s_tile[(row_off + row) * LD + c4 * 2], b = s_tile[(row_off + row) * LD + c4 * 2 + 1];
+        const float2 a = s_tile[row * LD + c4 * 2], b = s_tile[row * LD + c4 * 2 + 1];
         *reinterpret_cast<float4*>(&S2[((long)plane * H_out + row) * NH + tile * 16 + c4 * 2]) =
             make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+template <int R> static void cols_mul_lds_attr() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)cols_mul_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * R * 17 * (int)sizeof(float2));
+        done = true;
     }
 }
 
@@ -336,21 +347,30 @@ __global__ __launch_bounds__(512) void cols_corr_acc_kernel(const float2* __rest
 #pragma unroll
     for (int q = 0; q < R; ++q) acc[0][q] = acc[1][q] = accn[q] = make_float2(0.f, 0.f);
     const int b0 = chunk * bchunk, b1 = min(B, b0 + bchunk);
-    for (int b = b0; b < b1; ++b) {
+    // the next image's two tiles travel in registers while this one's columns are transformed (HX, HG <= N/2: four 16-byte pieces each)
+    constexpr int PF = (N / 2 * 8) / 512;
+    float4 px[PF], pg[PF];
+    auto fetch = [&](int b) {
         const long plane = (long)b * C + ch;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int idx = i * 512 + tid, row = idx >> 3, c4 = idx & 7;
+            px[i] = row < HX ? *reinterpret_cast<const float4*>(&SX[(plane * HX + row) * NH + tile * 16 + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pg[i] = row < HG ? *reinterpret_cast<const float4*>(&SG[(plane * HG + row) * NH + tile * 16 + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (b0 < b1) fetch(b0);
+    for (int b = b0; b < b1; ++b) {
         __syncthreads();
-        for (int idx = tid; idx < HX * 8; idx += 512) {
-            const int row = idx >> 3, c4 = idx & 7;
-            const float4 v = *reinterpret_cast<const float4*>(&SX[(plane * HX + row) * NH + tile * 16 + c4 * 2]);
-            s_x[row * LD + c4 * 2] = make_float2(v.x, v.y);
-            s_x[row * LD + c4 * 2 + 1] = make_float2(v.z, v.w);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int idx = i * 512 + tid, row = idx >> 3, c4 = idx & 7;
+            s_x[row * LD + c4 * 2] = make_float2(px[i].x, px[i].y);
+            s_x[row * LD + c4 * 2 + 1] = make_float2(px[i].z, px[i].w);
+            s_g[row * LD + c4 * 2] = make_float2(pg[i].x, pg[i].y);
+            s_g[row * LD + c4 * 2 + 1] = make_float2(pg[i].z, pg[i].w);
         }
-        for (int idx = tid; idx < HG * 8; idx += 512) {
-            const int row = idx >> 3, c4 = idx & 7;
-            const float4 v = *reinterpret_cast<const float4*>(&SG[(plane * HG + row) * NH + tile * 16 + c4 * 2]);
-            s_g[row * LD + c4 * 2] = make_float2(v.x, v.y);
-            s_g[row * LD + c4 * 2 + 1] = make_float2(v.z, v.w);
-        }
+        if (b + 1 < b1) fetch(b + 1);
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -639,7 +659,8 @@ int fftconv_fwd_t(const TIN* img, const void* otfT, float* out, void* signs, flo
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
     const float scale = 1.0f / ((float)N * (float)N);
     rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, S1, tw, planes, H, H, ppw);
-    cols_mul_kernel<R><<<dim3(N / 32, planes), 512, 0, stream>>>(S1, S2, (const float2*)otfT, tw, C, H, 0, H, conj_otf,
+    cols_mul_lds_attr<R>();
+    cols_mul_kernel<R><<<dim3(N / 32, planes), 512, (size_t)H * 17 * sizeof(float2), stream>>>(S1, S2, (const float2*)otfT, tw, C, H, 0, H, conj_otf,
                                                                 scale);
     if (mode == 0)
         rows_c2r_kernel<R, 0><<<g1, 256, 0, stream>>>(S2, out, (unsigned long long*)signs, partial_max, tw, planes, H,
@@ -690,7 +711,8 @@ int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, co
     }
     if (g_img) {   // adjoint convolution (Utils.py:285-286): SG x conj(OTF) -> plain P x P crop
         float2* S2b = SX;   // SX is free again (or unused)
-        cols_mul_kernel<R><<<dim3(N / 32, planes), 512, 0, stream>>>(SG, S2b, (const float2*)otfT, tw, C, P, 0, P, 1,
+        cols_mul_lds_attr<R>();
+        cols_mul_kernel<R><<<dim3(N / 32, planes), 512, (size_t)P * 17 * sizeof(float2), stream>>>(SG, S2b, (const float2*)otfT, tw, C, P, 0, P, 1,
                                                                     1.0f / ((float)N * (float)N));
         rows_c2r_kernel<R, 2><<<g1, 256, 0, stream>>>(S2b, g_img, nullptr, nullptr, tw, planes, P, ppw, 1.f);
     }

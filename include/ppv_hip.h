@@ -160,6 +160,17 @@ int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, 
                     float* run_var, float momentum, float eps, float* coef, int C, ppv_stream_t stream);
 int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, void* pos_bits, long n, int C,
                int res_mode, int relu, long res_mod, ppv_stream_t stream);
+
+/* Train-mode BatchNorm in ONE launch: partial statistics [T][2][C] (as ppv_conv_gemm leaves them) -> per-channel coefficients (written
+ * to coef [4][C] = scale, shift, mean, invstd for the backward pass; running statistics updated with `momentum`, unbiased variance)
+ * -> y = act(x * scale + shift (+ residual)).  res_mode 0: none, 1: identity r, 2: r normalised by its own BatchNorm (the *2
+ * arguments: the projection shortcut's).  pos_bits as ppv_bn_act.  Replaces ppv_bn_finalize + ppv_bn_act for
+ * torch BatchNorm2d(training) + ReLU (+ add) of torchvision's Bottleneck (Image_Caption/models.py:17-21, train.py:245).
+ * C % 64 == 0 for C <= 256, else C % 256 == 0. */
+int ppv_bn_act_train(const void* x, const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                     float* run_var, float momentum, float eps, float* coef, const void* r, const float* part2, int T2,
+                     const float* gamma2, const float* beta2, float* run_mean2, float* run_var2, float momentum2, float eps2,
+                     float* coef2, void* y, void* pos_bits, long rows, int C, int res_mode, int relu, hipStream_t stream);
 int ppv_bn_bwd_blocks(long rows, int C);
 int ppv_bn_bwd(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,

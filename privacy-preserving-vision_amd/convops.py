@@ -263,6 +263,31 @@ def bn_finalize(stat_part, count, gamma, beta, run_mean, run_var, momentum=0.1, 
     return coef
 
 
+def bn_act_train(x, stat_part, count, bn, momentum, res=None, res_stats=None, relu=True, want_bits=False):
+    """Train-mode BatchNorm2d `bn` on the raw conv output x [..., C] bf16 from its partial statistics stat_part [T,2,C] (+ ReLU, +
+    residual) in ONE launch (csrc/trunk_ops.hip bn_act_train_kernel = bn_finalize + bn_act).  res: identity residual, or with
+    res_stats = (stat_part2, bn2, momentum2) the raw output of a projection shortcut normalised by its own BatchNorm.
+    -> (y, bits or None, coef [4,C], coef2 or None); running statistics of bn (and bn2) updated in place."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if want_bits else None
+    coef = torch.empty((4, C), dtype=F32, device=x.device)
+    coef2 = None
+    a2 = [None, 0, None, None, None, None, 0.0, 0.0, None]
+    mode = 0 if res is None else 1
+    if res_stats is not None:
+        sp2, bn2, mom2 = res_stats
+        coef2 = torch.empty((4, C), dtype=F32, device=x.device)
+        a2 = [ptr(sp2), sp2.shape[0], ptr(bn2.weight.detach()), ptr(bn2.bias.detach()), ptr(bn2.running_mean), ptr(bn2.running_var),
+              mom2, bn2.eps, ptr(coef2)]
+        mode = 2
+    check(L().ppv_bn_act_train(ptr(x), ptr(stat_part), stat_part.shape[0], float(count), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                               ptr(bn.running_mean), ptr(bn.running_var), momentum, bn.eps, ptr(coef), ptr(res), *a2, ptr(y), ptr(bits),
+                               rows, C, mode, int(relu), stream_ptr()), "ppv_bn_act_train")
+    return y, bits, coef, coef2
+
+
 def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, want_bits=False):
     """y = act(x*scale + shift + res); res_broadcast: res holds one image's worth of elements shared by the batch.
     want_bits: also return the (y > 0) bit mask (uint8, numel / 8 bytes) that conv_dgrad(relu_bits=...) consumes."""

@@ -24,6 +24,14 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&f)[8]) {
         f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
     }
 }
+__device__ __forceinline__ void unpack8_(const uint4 u, float (&f)[8]) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
 __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
     unsigned w[4];
 #pragma unroll
@@ -97,6 +105,123 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 8; ++k) b |= (o[k] > 0.f ? 1u : 0u) << k;
         pos_bits[i] = (unsigned char)b;
+    }
+}
+
+// ----------------------------------------------------------------------------- train-mode BN: statistics -> coefficients -> apply, one launch
+// bn_finalize + bn_act in one kernel (round 2): the coefficient launch was 4.8 us of dispatch latency per BatchNorm for ~1 us of
+// work (104 launches per step, tools/micro/graph_chain.py: a dependent tiny kernel costs 4.2 us).  A workgroup owns a block of
+// CB = min(C, 256) channels and walks rows rb, rb + RB, ...; its prologue folds the [T][2][C] partial sums of ITS channels (thread
+// (tc, tr) takes rows tr, tr + rpp, ... of its eight channels, the partials meet in LDS, totals in double as bn_finalize_kernel) --
+// 16 KB of L2-resident reads against >= 64 KB of payload.  Row block 0 also writes coef [4][C] (for the backward pass) and the
+// running statistics.  RES == 2: the residual has its own BatchNorm (projection shortcut): both are folded here.
+struct BnFold {
+    const float* part; int T; double count;
+    const float* gamma; const float* beta; float* run_mean; float* run_var; float momentum; float eps; float* coef;
+};
+
+__device__ __forceinline__ void bn_fold8(const BnFold& f, int C, int c0, int tc, int tr, int rpp, int tpr, bool writer, float* s_red,
+                                         float (&sc)[8], float (&sh)[8]) {
+    float ps[8], pq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ps[k] = pq[k] = 0.f;
+    for (int t = tr; t < f.T; t += rpp) {
+        const float4 a0 = *reinterpret_cast<const float4*>(f.part + ((long)t * 2 + 0) * C + c0), a1 = *reinterpret_cast<const float4*>(f.part + ((long)t * 2 + 0) * C + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(f.part + ((long)t * 2 + 1) * C + c0), b1 = *reinterpret_cast<const float4*>(f.part + ((long)t * 2 + 1) * C + c0 + 4);
+        ps[0] += a0.x; ps[1] += a0.y; ps[2] += a0.z; ps[3] += a0.w; ps[4] += a1.x; ps[5] += a1.y; ps[6] += a1.z; ps[7] += a1.w;
+        pq[0] += b0.x; pq[1] += b0.y; pq[2] += b0.z; pq[3] += b0.w; pq[4] += b1.x; pq[5] += b1.y; pq[6] += b1.z; pq[7] += b1.w;
+    }
+    __syncthreads();                                  // s_red may still be read by a previous fold
+    float* mine = s_red + ((tr * tpr + tc) * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mine[k] = ps[k]; mine[8 + k] = pq[k]; }
+    __syncthreads();
+    double s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.0;
+    for (int j = 0; j < rpp; ++j) {
+        const float* o = s_red + ((j * tpr + tc) * 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += (double)o[k]; q[k] += (double)o[8 + k]; }
+    }
+    // every workgroup repeats this for its channels: no f64 division / square root here (hundreds of instructions each) -- products
+    // with 1 / count in double, then the f32 reciprocal square root refined by one Newton step (<= 1 ulp of the rounded f64 value)
+    const double inv_n = 1.0 / f.count;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        const double mean = s[k] * inv_n;
+        double var = q[k] * inv_n - mean * mean;
+        if (var < 0) var = 0;
+        const float ve = (float)(var + (double)f.eps);
+        float invstd = __builtin_amdgcn_rsqf(ve);
+        invstd = invstd * (1.5f - 0.5f * ve * invstd * invstd);
+        sc[k] = f.gamma[c] * invstd;
+        sh[k] = f.beta[c] - (float)mean * sc[k];
+        if (writer) {
+            f.coef[c] = sc[k];
+            f.coef[C + c] = sh[k];
+            f.coef[2 * C + c] = (float)mean;
+            f.coef[3 * C + c] = invstd;
+            if (f.run_mean) {
+                f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * (float)mean;
+                const double unb = f.count > 1 ? var * f.count / (f.count - 1.0) : var;
+                f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * (float)unb;
+            }
+        }
+    }
+}
+
+template <int RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_act_train_kernel(const bf16_t* __restrict__ x, BnFold f1, const bf16_t* __restrict__ r, BnFold f2,
+                                                           bf16_t* __restrict__ y, unsigned char* __restrict__ pos_bits, long rows, int C,
+                                                           int ncb) {
+    __shared__ float s_red[256 * 16];
+    const int CB = C < 256 ? C : 256;
+    const int tpr = CB / 8, rpp = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb, RB = gridDim.x / ncb;
+    const int c0 = cb * CB + tc * 8;
+    float s1[8], t1[8], s2[8], t2[8];
+    bn_fold8(f1, C, c0, tc, tr, rpp, tpr, rb == 0 && tr == 0, s_red, s1, t1);
+    if (RES == 2) bn_fold8(f2, C, c0, tc, tr, rpp, tpr, rb == 0 && tr == 0, s_red, s2, t2);
+    // eight rows in flight per thread (64 KB per CU at two workgroups per CU): few workgroups, because each one re-reads its
+    // channels' whole [T][2][CB] partial-sum block (64 KB at T = 32, C = 256) -- 2048 workgroups made that 4x the tensor itself
+    constexpr int U = 8;
+    const long stride = (long)RB * rpp;
+    for (long row0 = (long)rb * rpp + tr; row0 < rows; row0 += U * stride) {
+        uint4 xr[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * stride;
+            if (row < rows) {
+                xr[u] = *reinterpret_cast<const uint4*>(x + row * C + c0);
+                if (RES) rr[u] = *reinterpret_cast<const uint4*>(r + row * C + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * stride;
+            if (row >= rows) break;
+            const long e = row * C + c0;
+            float xv[8], rv[8], o[8];
+            unpack8_(xr[u], xv);
+            if (RES) unpack8_(rr[u], rv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float v = xv[k] * s1[k] + t1[k];
+                if (RES == 1) v += rv[k];
+                if (RES == 2) v += rv[k] * s2[k] + t2[k];
+                o[k] = RELU ? fmaxf(v, 0.f) : v;
+            }
+            store8(y + e, o);
+            if (pos_bits) {
+                unsigned b = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b |= (o[k] > 0.f ? 1u : 0u) << k;
+                pos_bits[e >> 3] = (unsigned char)b;
+            }
+        }
     }
 }
 
@@ -473,6 +598,40 @@ int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* co
     else if (res_mode == 1) bn_act_kernel<1, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
     else if (relu) bn_act_kernel<2, true><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
     else bn_act_kernel<2, false><<<gb, 256, 0, stream>>>(xx, coef1, rr, coef2, yy, pb, n8, C, res_mod / 8);
+    return ppv_last_error();
+}
+
+// Train-mode BatchNorm in one launch: statistics [T][2][C] (as ppv_conv_gemm leaves them) -> coefficients (coef [4][C] written for
+// the backward pass, running statistics updated) -> y = act(x * s + t (+ res)).  res_mode 0 none, 1 identity r, 2 r normalised by
+// its own BatchNorm (part2 ... coef2: the projection shortcut's).  Replaces ppv_bn_finalize + ppv_bn_act (reference:
+// torch BatchNorm2d in training mode + ReLU (+ residual add) of torchvision's Bottleneck, Image_Caption/models.py:17-21, train.py:245).
+// C % 64 == 0 (C <= 256) or C % 256 == 0; rows * C < 2^31 * 8.
+int ppv_bn_act_train(const void* x, const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                     float* run_var, float momentum, float eps, float* coef, const void* r, const float* part2, int T2,
+                     const float* gamma2, const float* beta2, float* run_mean2, float* run_var2, float momentum2, float eps2,
+                     float* coef2, void* y, void* pos_bits, long rows, int C, int res_mode, int relu, hipStream_t stream) {
+    if (!x || !part || !gamma || !beta || !coef || !y || (res_mode && !r)) return PPV_ERR_NULL;
+    if (res_mode == 2 && (!part2 || !gamma2 || !beta2 || !coef2)) return PPV_ERR_NULL;
+    if (C % 64 || (C > 256 && C % 256) || T < 1 || (res_mode == 2 && T2 < 1)) return PPV_ERR_BAD_SIZE;
+    BnFold f1{part, T, count, gamma, beta, run_mean, run_var, momentum, eps, coef};
+    BnFold f2{part2, T2, count, gamma2, beta2, run_mean2, run_var2, momentum2, eps2, coef2};
+    const int CB = C < 256 ? C : 256, ncb = C / CB, rpp = 256 / (CB / 8);
+    long rbk = (rows + rpp - 1) / rpp;                          // row blocks if every workgroup took one pass
+    const long want = (512 + ncb - 1) / ncb;                    // ~512 workgroups (2 per CU), eight rows in flight per thread
+    if (rbk > want) rbk = want;
+    if (rbk < 1) rbk = 1;
+    const unsigned grid = (unsigned)(rbk * ncb);
+    const bf16_t *xx = (const bf16_t*)x, *rr = (const bf16_t*)r;
+    bf16_t* yy = (bf16_t*)y;
+    unsigned char* pb = (unsigned char*)pos_bits;
+#define PPV_BNT(RES_, RELU_) bn_act_train_kernel<RES_, RELU_><<<grid, 256, 0, stream>>>(xx, f1, rr, f2, yy, pb, rows, C, ncb)
+    if (res_mode == 0 && relu) PPV_BNT(0, true);
+    else if (res_mode == 0) PPV_BNT(0, false);
+    else if (res_mode == 1 && relu) PPV_BNT(1, true);
+    else if (res_mode == 1) PPV_BNT(1, false);
+    else if (relu) PPV_BNT(2, true);
+    else PPV_BNT(2, false);
+#undef PPV_BNT
     return ppv_last_error();
 }
 

@@ -104,12 +104,16 @@ class _ConvRec:
         self._wt = self._wd = None
 
 
+def _bn_momentum(bn):
+    # momentum=None is torch's cumulative moving average: factor 1 / (batches seen, this one included)
+    return bn.momentum if bn.momentum is not None else 1.0 / (int(bn.num_batches_tracked) + 1)
+
+
 def _bn_coef(rec, stat_part, count):
     bn = rec.bn
     if bn.training:
-        # momentum=None is torch's cumulative moving average: factor 1 / (batches seen, this one included)
-        mom = bn.momentum if bn.momentum is not None else 1.0 / (int(bn.num_batches_tracked) + 1)
-        return co.bn_finalize(stat_part, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, mom, bn.eps)
+        return co.bn_finalize(stat_part, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                              _bn_momentum(bn), bn.eps)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight.detach() * invstd
     return torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
@@ -159,6 +163,8 @@ class _TrunkFn(torch.autograd.Function):
         saved["stem"] = (raw0, c0, y0, arg0)
         x = y0
         blocks = []
+        import os as _os
+        fused_bn = train and _os.environ.get("PPV_BN_FUSED", "0") == "1"      # 1: bn_finalize + bn_act in one launch (measured slower: DESIGN 4b)
         xin_bits = None        # (block input > 0) bit mask; the first block's input is the max-pool output, masked by its own backward
         for blk in enc._blocks:
             xin = x
@@ -166,9 +172,28 @@ class _TrunkFn(torch.autograd.Function):
             Bn, Hin, Win, _ = xin.shape
             p = part_for(Bn * Hin * Win, r1.conv.out_channels)
             x1 = co.conv_fwd(xin, r1.wt(tok), 1, 0, p)
+            H2, W2 = Hin // r2.stride, Win // r2.stride
+            if fused_bn and all(r_.bn.training for r_ in blk if r_ is not None):
+                # train mode: statistics -> coefficients -> apply in one launch per BatchNorm (co.bn_act_train)
+                y1, _, c1, _ = co.bn_act_train(x1, p, Bn * Hin * Win, r1.bn, _bn_momentum(r1.bn))
+                p = part_for(Bn * H2 * W2, r2.conv.out_channels)
+                x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
+                y2, _, c2, _ = co.bn_act_train(x2, p, Bn * H2 * W2, r2.bn, _bn_momentum(r2.bn))
+                p = part_for(Bn * H2 * W2, r3.conv.out_channels)
+                x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
+                if rd is not None:
+                    pd = part_for(Bn * H2 * W2, rd.conv.out_channels)
+                    xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, pd)
+                    yout, ybits, c3, cd = co.bn_act_train(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xd,
+                                                         res_stats=(pd, rd.bn, _bn_momentum(rd.bn)), want_bits=True)
+                else:
+                    xd = cd = None
+                    yout, ybits, c3, _ = co.bn_act_train(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xin, want_bits=True)
+                blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
+                x, xin_bits = yout, ybits
+                continue
             c1 = _bn_coef(r1, p, Bn * Hin * Win)
             y1 = co.bn_act(x1, c1)
-            H2, W2 = Hin // r2.stride, Win // r2.stride
             p = part_for(Bn * H2 * W2, r2.conv.out_channels)
             x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
             c2 = _bn_coef(r2, p, Bn * H2 * W2)

@@ -195,3 +195,54 @@ def test_linear_f32_is_exact_f32(m, N, K, strided):
     assert ((got.double() - want).abs() / mass).max().item() < 2e-6
     if strided:
         assert got.data_ptr() == out.data_ptr()
+
+
+@pytest.mark.parametrize("rows,C,T", [(4096, 64, 32), (2048, 256, 16), (1031, 1024, 8), (520, 2048, 4), (37, 128, 1), (32768, 256, 32)])
+@pytest.mark.parametrize("res_mode", [0, 1, 2])
+def test_batchnorm_train_single_launch(rows, C, T, res_mode):
+    """co.bn_act_train (statistics -> coefficients -> apply in one launch) against torch BatchNorm2d(training) on the CPU: the stored
+    tensor within one bf16 rounding, coefficients and running statistics at f32 accuracy, ReLU bits consistent with the stored tensor."""
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(C + rows)
+    x = r16(torch.randn(rows, C, generator=g0) * 1.5 + 0.3)
+    res = r16(torch.randn(rows, C, generator=g0))
+
+    def mk_bn():
+        bn = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=g0) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=g0) * 0.2)
+            bn.running_mean.copy_(torch.randn(C, generator=g0) * 0.1)
+            bn.running_var.copy_(torch.rand(C, generator=g0) + 0.5)
+        return bn.train()
+
+    def part_of(t):                                          # [T][2][C] partial sums as the conv epilogue leaves them (any split)
+        idx = torch.arange(rows) % T
+        p = torch.zeros(T, 2, C)
+        p[:, 0].index_add_(0, idx, t)
+        p[:, 1].index_add_(0, idx, t * t)
+        return p
+
+    bn1, bn2 = mk_bn(), mk_bn()
+    ref1, ref2 = mk_bn(), mk_bn()
+    for a, b in ((bn1, ref1), (bn2, ref2)):
+        b.load_state_dict(a.state_dict())
+    as4 = lambda t: t.t().reshape(1, C, rows, 1)
+    want = ref1(as4(x))
+    if res_mode == 1:
+        want = want + as4(res)
+    if res_mode == 2:
+        want = want + ref2(as4(res))
+    want = torch.relu(want).reshape(C, rows).t()
+    d1, d2 = bn1.cuda(), bn2.cuda()
+    y, bits, coef, coef2 = co.bn_act_train(x.cuda().bfloat16(), part_of(x).cuda(), rows, d1, 0.1, res=None if res_mode == 0 else res.cuda().bfloat16(),
+                                            res_stats=(part_of(res).cuda(), d2, 0.1) if res_mode == 2 else None, want_bits=True)
+    assert rel_err(y.float(), want) < BF
+    assert rel_err(d1.running_mean.cpu(), ref1.running_mean) < 1e-5 and rel_err(d1.running_var.cpu(), ref1.running_var) < 1e-5
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    assert rel_err(coef[2].cpu(), mean) < 1e-5 and rel_err(coef[3].cpu(), torch.rsqrt(var + 1e-5)) < 1e-5
+    assert rel_err(coef[0].cpu(), ref1.weight.detach() * torch.rsqrt(var + 1e-5)) < 1e-5
+    if res_mode == 2:
+        assert rel_err(d2.running_var.cpu(), ref2.running_var) < 1e-5 and rel_err(coef2[2].cpu(), res.mean(0)) < 1e-5
+    k = (bits.view(-1, 1).int() >> torch.arange(8, device="cuda").int()) & 1
+    assert torch.equal(k.view(-1).bool(), (y > 0).view(-1))

@@ -9,7 +9,7 @@
 //
 // fp64 throughout the field chain: k*sqrt(x^2+y^2+d^2) ~ 7e6 rad cannot live in fp32.
 // Fields are planar per wavelength [L][RR][RR] double2.  The FFT length M = RR + 2*(RR/4)
-// (1344 = 2^6*3*7 for RR = 896) is kept (padding to 2048 would change the physics); radices 2,3,4,7.
+// (1344 = 2^6*3*7 for RR = 896) is kept (padding to 2048 would change the physics); radices 2,3,4,7 as butterflies, 5,11,13,23 by direct summation.
 #include <hip/hip_runtime.h>
 #include "ppv_common.h"
 
@@ -88,6 +88,31 @@ __device__ __forceinline__ void dstage(const double2* __restrict__ in, double2* 
     }
 }
 
+// Stockham stage of ANY radix by direct summation (R^2 twiddled adds per butterfly): the odd primes the hand-written butterflies
+// above do not cover (5, 11, 13, 23: e.g. 1104 = 1.5 x 736 = 2^4 * 3 * 23, the transform of the reference constructor's default
+// wave_resolution, Lens.py:21).  W_R^j = tw[(j mod R) * M / R].
+__device__ __forceinline__ void dstage_any(const double2* __restrict__ in, double2* __restrict__ out, const double2* __restrict__ tw,
+                                           int M, int R, int p, int tid, int nthr) {
+    const int T = M / R;
+    const int step = M / (p * R), wr = M / R;
+    for (int i = tid; i < T; i += nthr) {
+        const int k = i % p;
+        const int j = (i - k) * R + k;
+        for (int q = 0; q < R; ++q) {
+            double2 acc = in[i];
+            int e = 0;                                         // (q * r) mod R
+            for (int r = 1; r < R; ++r) {
+                e += q;
+                if (e >= R) e -= R;
+                double2 v = in[i + r * T];
+                if (p > 1) v = dmul(v, tw[r * k * step]);
+                acc = dadd(acc, dmul(v, tw[e * wr]));
+            }
+            out[j + q * p] = acc;
+        }
+    }
+}
+
 // forward FFT of the sequence in buf a (scratch b); returns the buffer that holds the result.
 // Callers must __syncthreads()-separate groups: `sync` = workgroup barrier functor is implicit (all threads of the
 // workgroup call this together, possibly on different sequences).
@@ -99,7 +124,8 @@ __device__ __forceinline__ double2* dfft(double2* a, double2* b, const double2* 
         if (R == 4) dstage<4>(a, b, tw, pl.M, p, tid, nthr);
         else if (R == 2) dstage<2>(a, b, tw, pl.M, p, tid, nthr);
         else if (R == 3) dstage<3>(a, b, tw, pl.M, p, tid, nthr);
-        else dstage<7>(a, b, tw, pl.M, p, tid, nthr);
+        else if (R == 7) dstage<7>(a, b, tw, pl.M, p, tid, nthr);
+        else dstage_any(a, b, tw, pl.M, R, p, tid, nthr);
         __syncthreads();
         double2* t = a; a = b; b = t;
         p *= R;
@@ -462,6 +488,8 @@ int make_plan(int M, FftPlan* pl) {
     while (m % 2 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 2; m /= 2; }
     while (m % 3 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 3; m /= 3; }
     while (m % 7 == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = 7; m /= 7; }
+    for (int q : {5, 11, 13, 23})                               // direct-summation stages (dstage_any)
+        while (m % q == 0 && pl->nst < MAXST) { pl->radix[pl->nst++] = q; m /= q; }
     return m == 1 ? PPV_OK : PPV_ERR_BAD_SIZE;
 }
 

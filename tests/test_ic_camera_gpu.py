@@ -167,3 +167,53 @@ def test_uint8_pixels_are_decoded_inside_the_row_transform():
     g_u = cam.zernike_coeffs_train.grad
     assert s_u.dtype == torch.float32 and (s_u - s_f).abs().max().item() < 2e-6 * s_f.abs().max().item()
     assert ((g_u - g_f).norm() / g_f.norm()).item() < 1e-5
+
+
+def test_constructor_default_geometry_against_the_oracle():
+    """The reference constructor's own defaults (Lens.py:21-22: wave_resolution 736, patch_size 368; its scripts pass 896 / 256): the
+    Fresnel transform is 1104 = 2^4 * 3 * 23 points (radix-23 stage by direct summation, csrc/psf_ic.hip dstage_any), the image
+    convolution 736 points (torch.fft on the device, camera_lens._sensor_library).  Forward and gradients against the oracle."""
+    from oracle import ic_camera as ic
+    from ppv_amd.camera_lens import OpticsZernike
+    cam = OpticsZernike(input_shape=[None, 368, 368, 3], device=torch.device("cuda"), zernike_terms=36, height_tolerance=2e-8,
+                        sensor_distance=0.025, sample_interval=3e-06, upsample=False, coeff_layout="B")
+    assert cam.patch_size == 368 and cam.wave_res == [736, 736] and not cam._sensor_native
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        c = (torch.rand(33, 1, 1, generator=g) - 0.5) * 0.4
+        c[0] = -11.0
+        cam.zernike_coeffs_train.copy_(c)
+    img = torch.rand(2, 3, 368, 368, generator=torch.Generator().manual_seed(0))
+    w = torch.rand(2, 3, 368, 368, generator=torch.Generator().manual_seed(5))
+    noise = torch.rand(1, 736, 736, 1, generator=torch.Generator().manual_seed(1))
+    co = cam._concat().detach().cpu().requires_grad_(True)
+    io = img.clone().requires_grad_(True)
+    s_o, psf_o, _ = ic.forward(io, co, cam.zernike_volume.cpu(), noise, prueba=None, height_tolerance=2e-8, sensor_distance=0.025,
+                               sample_interval=3e-6)
+    (s_o * w).sum().backward()
+    ig = img.cuda().requires_grad_(True)
+    sensor, psf, _, loss = cam(ig, None, None, noise_u01=noise.cuda())
+    assert loss is None and psf.shape == (1, 368, 368, 3) and sensor.shape == (2, 3, 368, 368)
+    assert rel_err(psf.cpu(), psf_o.detach()) < TOL
+    assert rel_err(sensor.cpu(), s_o.detach()) < TOL and float(sensor.detach().max()) == 1.0
+    (sensor * w.cuda()).sum().backward()
+    assert rel_err(cam.zernike_coeffs_train.grad.reshape(-1).cpu(), co.grad.reshape(-1)[3:]) < TOL
+    assert rel_err(ig.grad.cpu(), io.grad) < TOL
+
+
+def test_library_sensor_path_equals_the_native_one():
+    """camera_lens._sensor_library (torch.fft) and the fftconv.hip kernels are the same function where both exist (patch 128)."""
+    cam = _mid_cam()
+    img = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(0)).cuda()
+    w = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(5)).cuda()
+    noise = torch.rand(1, 448, 448, 1, generator=torch.Generator().manual_seed(1)).cuda()
+    res = []
+    for native in (True, False):
+        cam._sensor_native = native
+        cam.zero_grad(set_to_none=True)
+        ig = img.clone().requires_grad_(True)
+        sensor, _, _, _ = cam(ig, None, None, noise_u01=noise)
+        (sensor * w).sum().backward()
+        res.append((sensor.detach(), cam.zernike_coeffs_train.grad.clone(), ig.grad.clone()))
+    for a, b in zip(*res):
+        assert rel_err(b, a) < 1e-4

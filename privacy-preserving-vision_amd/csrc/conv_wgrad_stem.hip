@@ -43,6 +43,7 @@ struct WgradGeom {
     int splits;            // number of m-slices
     int xcd_group;         // 1: tiles of one m-slice share an XCD (1-D grid decode)
     long slab_elems;       // > 0: slice z stores its tile plainly into dW + z * slab_elems (no atomics)
+    int xcc_slabs;         // 1: every slice ADDS (f32 atomics) into the slab of the XCD it runs on (dW + XCC_ID * slab_elems, pre-zeroed)
 };
 
 // 32-byte block swizzle key of a staged row (conflict-free ds_read_b64_tr_b16: see file header)
@@ -335,6 +336,14 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
     const int tap = by / ctiles, c0 = (by % ctiles) * 128;
     const long m_begin = (long)zslice * g.stages_per_split * 64;
     const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    if (g.xcc_slabs) {
+        // One slab per XCD instead of one per m-slice: the slices that run on an XCD add into ITS slab with f32 atomics.  A slab's lines
+        // then live in one L2 only (no cross-XCD line migration, which is what made atomics into a single accumulator slow), 8 slabs are
+        // reduced instead of 24-48, and the index comes from the hardware (HW_REG_XCC_ID), so it is right for any block -> XCD mapping.
+        const int xcc = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;
+        wgrad_pipe_body<TN, NSTAGE>(G, X, dW + (long)xcc * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, true);
+        return;
+    }
     wgrad_pipe_body<TN, NSTAGE>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0);
 }
 
@@ -1178,6 +1187,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     WgradGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S; g.st = stride; g.pad = pad;
     g.M = (long)B * Ho * Wo;
+    g.xcc_slabs = 0;
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;            // fast_divmod range
     int variant = g_wgrad_variant & 0xff;
     g.xcd_group = (g_wgrad_variant & 0x100) ? 0 : 1;
@@ -1252,6 +1262,12 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         return ppv_last_error();
     }
     g.slab_elems = elems;
+    int nslab = (int)splits;
+    if ((g_wgrad_variant & 0x400) && splits > 8) {             // XCC-local atomic slabs (see conv_wgrad_pipe_kernel): 8 pre-zeroed slabs
+        g.xcc_slabs = 1;
+        nslab = 8;
+        (void)hipMemsetAsync(slabs, 0, 8 * elems * sizeof(float), stream);
+    }
     const unsigned grid = g.xcd_group ? (unsigned)(8 * ((splits + 7) / 8) * tiles) : (unsigned)(splits * tiles);
     if (TN == 256) {
         constexpr int lds = 3 * 3 * 64 * 256;
@@ -1269,7 +1285,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
         conv_wgrad_pipe_kernel<128, 4><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     }
-    wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)splits);
+    wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab);
     return ppv_last_error();
 }
 
@@ -1283,7 +1299,7 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
     g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1; g.st = 1; g.pad = 0;
     g.M = (long)B * H * W;
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;
-    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs;
+    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0;
     WgradGroupPtrs ptrs;
     for (int p = 0; p < 24; ++p) {
         const int q = p < P ? p : 0;

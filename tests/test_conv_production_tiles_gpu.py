@@ -217,6 +217,8 @@ WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> th
     (32, 32, 256, 1024, 1, 1, 7),   # streamed kernel (loader / consumer waves), 256-wide
     (32, 32, 1024, 128, 1, 1, 7),   # streamed kernel, 128-wide
     (16, 64, 128, 128, 3, 2, 7),    # streamed kernel, strided taps with padding
+    (32, 32, 256, 1024, 1, 1, 0x400),   # one f32-atomic slab per XCD (HW_REG_XCC_ID) instead of one slab per m-slice
+    (64, 16, 1024, 256, 1, 1, 0x400),
 ]
 
 

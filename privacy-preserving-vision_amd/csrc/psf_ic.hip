@@ -113,6 +113,14 @@ __device__ __forceinline__ void dstage_any(const double2* __restrict__ in, doubl
     }
 }
 
+// Layout of the two intermediates of the 2-D transform (T1 after the row pass, T2 after the column pass): [L][M / CB][RR][CB] -- blocks of
+// CB = 8 columns (2 when M % 8 != 0).  The row passes then touch 128-byte pieces, and the column pass (two columns per workgroup) reads
+// 32-byte pieces that are ADJACENT to its neighbours' inside one contiguous RR x 128-byte block, instead of 32-byte pieces 16 * M bytes
+// apart (row-major [L][RR][M]: 0.64 TB/s, 181 us per pass at M = 1344).
+__device__ __forceinline__ long tix(int l, int y, int kx, int RR, int M, int CB) {
+    return (((long)l * (M / CB) + kx / CB) * RR + y) * CB + kx % CB;
+}
+
 // forward FFT of the sequence in buf a (scratch b); returns the buffer that holds the result.
 // Callers must __syncthreads()-separate groups: `sync` = workgroup barrier functor is implicit (all threads of the
 // workgroup call this together, possibly on different sequences).
@@ -263,7 +271,8 @@ __global__ __launch_bounds__(256) void dfft_rows_kernel(const double2* __restric
     }
     __syncthreads();
     const double2* r = dfft(s_a, s_b, s_tw, pl, tid, 256);
-    for (int i = tid; i < M; i += 256) out[row * M + i] = r[i];
+    const int l = (int)(row / RR), y = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
+    for (int i = tid; i < M; i += 256) out[tix(l, y, i, RR, M, CB)] = r[i];
 }
 
 // cols: two columns per workgroup.  T1 [L][RR][M] rows placed at row offset pad -> column FFT -> x Ht[l][kx][ky]
@@ -277,7 +286,14 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
     __shared__ double2 s_b[2][MAXM];
     __shared__ const double2* s_ptr[2];
     const int tid = threadIdx.x, M = pl.M;
-    const int l = blockIdx.y, kx0 = blockIdx.x * 2;
+    // the four workgroups that share an 8-column block run on ONE XCD (blocks b, b + 8, ... share an XCD): its L2 fetches each 128-byte
+    // piece once for all four
+    int pb = blockIdx.x;
+    if (gridDim.x % 32 == 0) {
+        const int xcd = pb & 7, idx = pb >> 3;
+        pb = (idx >> 2) * 32 + xcd * 4 + (idx & 3);
+    }
+    const int l = blockIdx.y, kx0 = pb * 2;
     const int col = tid >> 8, t = tid & 255;
     const int kx = kx0 + col;
     for (int i = tid; i < M; i += 512) s_tw[i] = twg[i];
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
     for (int i = tid; i < M; i += 512) {
         const int y = i - pad;
         double4 v = make_double4(0.0, 0.0, 0.0, 0.0);
-        if (y >= 0 && y < RR) v = *reinterpret_cast<const double4*>(T1 + ((long)l * RR + y) * M + kx0);
+        if (y >= 0 && y < RR) v = *reinterpret_cast<const double4*>(T1 + tix(l, y, kx0, RR, M, (M % 8 == 0) ? 8 : 2));
         s_a[0][i] = make_double2(v.x, v.y);
         s_a[1][i] = make_double2(v.z, v.w);
     }
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
     const double2 *z0 = s_ptr[0], *z1 = s_ptr[1];
     for (int i = tid; i < RR; i += 512) {
         const double2 a = z0[i + pad], b = z1[i + pad];
-        *reinterpret_cast<double4*>(T2 + ((long)l * RR + i) * M + kx0) = make_double4(a.x * scale, -a.y * scale, b.x * scale, -b.y * scale);
+        *reinterpret_cast<double4*>(T2 + tix(l, i, kx0, RR, M, (M % 8 == 0) ? 8 : 2)) = make_double4(a.x * scale, -a.y * scale, b.x * scale, -b.y * scale);
     }
 }
 
@@ -320,9 +336,10 @@ __global__ __launch_bounds__(256) void difft_rows_kernel(const double2* __restri
     __shared__ double2 s_b[MAXM];
     const int tid = threadIdx.x, M = pl.M;
     const long row = blockIdx.x;
+    const int l_ = (int)(row / RR), y_ = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
     for (int i = tid; i < M; i += 256) {
         s_tw[i] = twg[i];
-        const double2 v = T2[row * M + i];
+        const double2 v = T2[tix(l_, y_, i, RR, M, CB)];
         s_a[i] = make_double2(v.x, -v.y);
     }
     __syncthreads();

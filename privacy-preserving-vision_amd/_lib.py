@@ -140,7 +140,15 @@ def check(status, what):
         raise RuntimeError(f"libppv_hip: {what} failed with status {status}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a void*.  torch.cuda.current_stream() costs ~8 us per call (device-index
+    resolution, a Stream object): at ~1600 kernel launches per step that was 5 ms of host time; the raw accessors are ~0.3 us."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -459,7 +459,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache"):
             st.pop(k, None)
         return st
 
@@ -529,6 +529,7 @@ class Encoder(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_weight_cache()
+        self.__dict__["_plist_gen"] = self.__dict__.get("_plist_gen", 0) + 1      # assign=True replaces the Parameter objects
         return out
 
     def prefetch_weight_layouts(self):
@@ -540,7 +541,18 @@ class Encoder(nn.Module):
         object.__setattr__(self, "_wl_prefetched", True)
 
     def _param_list(self):
-        return list(self.resnet.parameters())
+        # cached: walking the module tree costs ~0.8 ms and the trunk calls this twice per step; the trunk's structure is fixed after
+        # __init__ (Parameter OBJECTS are replaced by load_state_dict(assign=True) / .to_empty(): the cache is keyed on their ids)
+        cached = self.__dict__.get("_plist_cache")
+        if cached is not None and cached[0] == self.__dict__.get("_plist_gen", 0):
+            return cached[1]
+        lst = list(self.resnet.parameters())
+        self.__dict__["_plist_cache"] = (self.__dict__.get("_plist_gen", 0), lst)
+        return lst
+
+    def _apply(self, fn, *a, **kw):                       # .cuda() / .to() / .float(): parameters may be new objects afterwards
+        self.__dict__["_plist_gen"] = self.__dict__.get("_plist_gen", 0) + 1
+        return super()._apply(fn, *a, **kw)
 
     @property
     def _nbt(self):

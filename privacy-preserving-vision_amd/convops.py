@@ -161,10 +161,12 @@ def wgrad_scratch_bytes(M, N, R, S, Cs):
     return L().ppv_conv_wgrad_scratch_bytes(M, N, R, S, Cs)
 
 
-def conv_wgrad(g, x, R, S, stride, pad, scratch=None, out=None):
+def conv_wgrad(g, x, R, S, stride, pad, scratch=None, out=None, stream=None):
     """g [B,Ho,Wo,Cout] bf16, x [B,H,W,Cin] bf16 -> dW in torch layout [Cout,Cin,R,S] f32.
     scratch: optional uint8 buffer of >= wgrad_scratch_bytes(...) (reused across convs; no zeroing needed).
-    out: optional contiguous f32 [Cout,Cin,R,S] destination (e.g. a slice of a flat gradient bucket, dist_sync.GradSync)."""
+    out: optional contiguous f32 [Cout,Cin,R,S] destination (e.g. a slice of a flat gradient bucket, dist_sync.GradSync).
+    stream: optional torch.cuda.Stream to launch on instead of the current one (no `with torch.cuda.stream(...)` round trip: that
+    context costs the host ~10 us per use, 93 uses per step in the trunk's backward); allocate `out` / `scratch` yourself then."""
     B, Ho, Wo, Cout = g.shape
     _, H, W, Cin = x.shape
     need = wgrad_scratch_bytes(B * Ho * Wo, Cout, R, S, Cin)
@@ -175,7 +177,8 @@ def conv_wgrad(g, x, R, S, stride, pad, scratch=None, out=None):
     assert out.shape == (Cout, Cin, R, S) and out.dtype == F32 and out.is_contiguous()
     _timed("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, lambda: check(
         L().ppv_conv_wgrad(ptr(g), ptr(x), ptr(out), ptr(scratch), ptr(zero_page(g.device)), B, H, W, Cin, Ho, Wo, Cout, R, S,
-                           stride, pad, stream_ptr()), "ppv_conv_wgrad"), nbytes=(g.numel() + x.numel()) * 2.0 + out.numel() * 4.0)
+                           stride, pad, stream_ptr() if stream is None else _lib.ctypes.c_void_p(stream.cuda_stream)), "ppv_conv_wgrad"),
+        nbytes=(g.numel() + x.numel()) * 2.0 + out.numel() * 4.0)
     return out
 
 

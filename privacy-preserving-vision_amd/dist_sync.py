@@ -73,12 +73,15 @@ class GradSync:
         b, o, n = s
         return self._flat[b][o:o + n].view(p.shape)
 
-    def mark_ready(self, p):
-        """The slice of ``p`` has been written on the CURRENT stream; the bucket is reduced when all its slices are."""
+    def mark_ready(self, p, stream=None):
+        """The slice of ``p`` has been written on ``stream`` (default: the CURRENT stream); the bucket is reduced when all its slices are."""
         b = self._slot[id(p)][0]
         if self._flat[b].is_cuda:
             ev = torch.cuda.Event()
-            ev.record()
+            if stream is None:
+                ev.record()
+            else:
+                ev.record(stream)
             self._bevents[b].append(ev)
         self._pending[b] -= 1
         if self._pending[b] == 0:

@@ -346,7 +346,16 @@ class _TrunkFn(torch.autograd.Function):
             elif trainable:
                 w = rec.conv.weight
                 dst = sync.grad_view(w) if bucketed else None
-                if side is not None and sync is None and co.PROFILE is None:
+                if side is not None and bucketed and co.PROFILE is None:
+                    # data-parallel fast path: the kernel writes the bucket slice on the side stream (launched there by pointer), the
+                    # bucket's all-reduce waits for an event recorded on that stream
+                    ev = torch.cuda.Event(); ev.record(main_stream)
+                    side.wait_event(ev)
+                    co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst, stream=side)
+                    gx.record_stream(side); xin.record_stream(side)
+                    w.grad = dst
+                    sync.mark_ready(w, stream=side)
+                elif side is not None and sync is None and co.PROFILE is None:
                     # single-process fast path: the launch goes to the side stream by pointer (the stream context manager and the
                     # current-stream look-ups cost the host ~25 us per weight gradient, 93 per step)
                     ev = torch.cuda.Event(); ev.record(main_stream)

@@ -223,10 +223,10 @@ def _latest_profile(suffix):
     import glob
     import re
     best = None
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)):
-        m = re.match(r"r(\d+)", os.path.basename(f))
-        if m and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), f)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix))):      # r02a < r02b < ...: the last snapshot of a round wins
+        m = re.match(r"r(\d+)([a-z]*)", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), m.group(2)) >= best[0]):
+            best = ((int(m.group(1)), m.group(2)), f)
     return best[1] if best else None
 
 

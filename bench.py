@@ -230,11 +230,29 @@ def _latest_profile(suffix):
     return best[1] if best else None
 
 
-def _step_hbm(sec_per_step):
-    """Whole-step HBM view: bytes per step from the committed PMC passes (same workload) over the measured step time."""
-    pmc = _latest_profile("_pmc_traffic.json")
+def _load_profile(path):
+    """-> (dict or None, stale).  A committed counter profile is used only if it was collected on the kernel sources the running
+    library was built from (tools/csrc_hash.py, stored by tools/collect_pmc.py / collect_mfma.py as "csrc_sha16"); otherwise the
+    counter-derived fields print as null with "stale": true."""
     try:
-        d = json.load(open(pmc))
+        d = json.load(open(path))
+    except Exception:
+        return None, False
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
+    if d.get("csrc_sha16") != csrc_hash(ROOT):
+        return None, True
+    return d, False
+
+
+def _step_hbm(sec_per_step):
+    """Whole-step HBM view: bytes per step from the committed PMC passes (same workload, same kernel sources) over the measured
+    step time."""
+    pmc = _latest_profile("_pmc_traffic.json")
+    d, stale = _load_profile(pmc)
+    if d is None:
+        return {"GB_per_step_pmc": None, "stale": True, "pmc_file": os.path.basename(pmc)} if stale else None
+    try:
         gb = d["total_fetch_GB_per_step"] + d["total_write_GB_per_step"]
     except Exception:
         return None
@@ -298,8 +316,11 @@ def roofline_of_dominant_kernel(step):
     match = _class_kernels(dom)
     traffic = mfma_busy = None
     pmc_file, mu_file = _latest_profile("_pmc_traffic.json"), _latest_profile("_mfma_util.json")
+    pmc_d, stale_a = _load_profile(pmc_file)
+    mu_d, stale_b = _load_profile(mu_file)
+    stale = stale_a or stale_b
     try:
-        pk = json.load(open(pmc_file))["per_kernel"]
+        pk = pmc_d["per_kernel"]
         tot_b = tot_n = 0.0
         for name, v in pk.items():
             if match(name):
@@ -311,7 +332,7 @@ def roofline_of_dominant_kernel(step):
     except Exception:
         traffic = None
     try:
-        pk = json.load(open(mu_file))["per_kernel"]
+        pk = mu_d["per_kernel"]
         num = den = 0.0
         for name, v in pk.items():
             if match(name):
@@ -322,6 +343,7 @@ def roofline_of_dominant_kernel(step):
         mfma_busy = None
     return {"bound": "mfma", "kernel": dom, "chosen_by": "largest share of device time among the MFMA launch classes",
             "mfma_busy_frac_pmc": mfma_busy, "pmc_files": [os.path.basename(f) for f in (pmc_file, mu_file) if f],
+            "stale": stale,   # true: the committed counter profiles were taken on other kernel sources -> traffic / mfma_busy are null
             "measured_in": "one extra step with every launch serialised on one stream (kernel alone on the device)", "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
             "avg_launch_us": round(sec / n * 1e6, 2),
@@ -380,6 +402,32 @@ def cpu_baseline(camera):
             "sample": f"camera (896/350/256, prueba '3') + ResNet-101 fwd+bwd fp32, B={B} @256x256, best of {len(ts)} pass(es)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (one process per
+    GPU, rendezvous on 127.0.0.1), relay its output (rank 0 prints the JSON line) and return its exit code.  Runs before anything in
+    this process touches the GPU (torch.cuda.device_count() does not initialise it); never os.exec*."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < n and not os.environ.get("PPV_FORCE_DEVICE0"):      # PPV_FORCE_DEVICE0=1: several ranks on one GPU (rehearsal)
+        print(f"[bench] --gpus {n} but {visible} GPU(s) visible: refusing", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] launching {n} ranks: {' '.join(cmd[1:10])} ...", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                                     # relay as it comes (rank 0's JSON line is the last one)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,8 +451,14 @@ def main():
     if args.config == 3:
         args.decoder = True
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))                       # `python bench.py --gpus N`: N ranks as a child torchrun, nothing on the GPU here
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a mislabelled line",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
     # PPV_FORCE_DIST=1: run the data-parallel machinery (process group, RCCL all-reduce on the side stream, global-max exchange)
     # even with one rank -- the one-GPU rehearsal of the N-GPU path (tests/test_dist_gpu.py)
     force_dist = world == 1 and bool(os.environ.get("PPV_FORCE_DIST"))

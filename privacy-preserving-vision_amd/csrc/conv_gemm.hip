@@ -490,13 +490,16 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
     if (stat_part && addend && !red_x_) return PPV_ERR_BAD_SIZE; // the epilogue parks the addend tile where the statistics are folded
     if (red_x_ && (!stat_part || out_f32 || N % 64 || (red_coef && addend))) return PPV_ERR_BAD_SIZE;
+    if (mask_bits && out_f32) return PPV_ERR_BAD_SIZE;          // the mask applies to the bf16 store path only (checked before ANY dispatch)
     ConvGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S;
     g.a = a; g.off = off; g.offw = (g_conv_offw_override != INT_MIN) ? g_conv_offw_override : off; g.sh = (div == 2) ? 1 : 0;
     g.M = (long)B * Ho * Wo;
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
-    if (((g_conv_variant == 0 && addend && !out_f32) || g_conv_variant == 8) && conv1x1_stream_supported(g, Cs, div))
+    // (its f32 instantiation has no epilogue options: variant 8 leaves f32 launches with an addend / sums to the tiled kernels)
+    if (((g_conv_variant == 0 && addend && !out_f32) || (g_conv_variant == 8 && (!out_f32 || (!addend && !red_x_ && !stat_part)))) &&
+        conv1x1_stream_supported(g, Cs, div))
         return conv1x1_stream_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
                                      (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
                                      out_f32, stat_rows, stream);
@@ -511,7 +514,6 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     const bf16_t* ad = (const bf16_t*)addend;
     const bf16_t* rx = (const bf16_t*)red_x_;
     const unsigned char* mk = (const unsigned char*)mask_bits;
-    if (mk && out_f32) return PPV_ERR_BAD_SIZE;                 // the mask applies to the bf16 store path only
     const bf16_t* z = (const bf16_t*)zero_page;
 #define PPV_LAUNCH(BN_, WM_, TN_)                                                                                       \
     do {                                                                                                                \

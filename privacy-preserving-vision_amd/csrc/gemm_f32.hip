@@ -4,7 +4,10 @@
 //     out[m][n] (+)= sum_k x[m][k] * W[n][k]  (+ bias[n])        x [M][K] f32 (row stride ldx), W [N][K] f32 (row stride ldw)
 //
 // These GEMMs have 128 rows per time step (one per caption still alive) against 10-40 MB of weights: they are weight streams.
-// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate, a k-ordered fmaf chain: bit-for-bit f32 arithmetic, 157 TFLOP/s dense) keeps the
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate, a k-ordered fmaf chain: every product and partial sum is plain f32 arithmetic, 157
+// TFLOP/s dense; the K-slices are combined with f32 atomics, so with MORE THAN TWO slices the order of that last addition -- and
+// with it the last bit of the result -- varies from run to run; PPV_GEMM_DETERMINISTIC=1 caps the split at two slices, whose sum
+// commutes: bit-reproducible at a few per cent of config 3's speed) keeps the
 // reference's precision for the recurrence without splitting operands into bf16 terms -- a three-term bf16 split reads 1.5x the
 // weight bytes of f32 and needs 16-20 workgroups' worth of 128 x 128 tiles, i.e. 100 us per step at the ~20 GB/s one CU can take in
 // (measured: config 3 was 14 % slower with it than with the library GEMMs).
@@ -107,8 +110,9 @@ static int ksplit_target() {                                   // workgroups a l
 
 int ppv_gemm_f32_ksplit(int M, int N, int K) {
     const long wgs = (long)((N + 15) / 16) * ((M + 127) / 128);
+    static const int ks_max = (getenv("PPV_GEMM_DETERMINISTIC") && atoi(getenv("PPV_GEMM_DETERMINISTIC"))) ? 2 : 8;
     int ks = 1;
-    while (ks < 8 && wgs * ks < ksplit_target() && K / (16 * 4 * ks * 2) >= 2) ks *= 2;
+    while (ks < ks_max && wgs * ks < ksplit_target() && K / (16 * 4 * ks * 2) >= 2) ks *= 2;
     return ks;
 }
 

@@ -28,6 +28,11 @@ class GradSync:
         self.stream = None
         self.defer_join = False
         self.launched = 0
+        # average inside the collective where the backend has it (RCCL: ncclAvg, no separate scaling pass over every bucket)
+        try:
+            self._avg = dist.get_backend(process_group) == "nccl"
+        except Exception:
+            self._avg = False
         # loose tensors
         self._bucket, self._size, self._events = [], 0, []
         # pre-flattened buckets
@@ -42,7 +47,15 @@ class GradSync:
     def attach(self, params):
         """params: the parameters whose gradients this object owns, in the order backward finishes them."""
         params = [p for p in params if p.requires_grad]
+        if not params:                                                # nothing trainable (fine_tune(False)): no buckets
+            self._params, self._flat, self._slot, self._count, self._pending, self._bevents = [], [], {}, [], [], []
+            return
         if [id(p) for p in params] == [id(p) for p in self._params] and self._flat and self._flat[0].device == params[0].device:
+            # same layout as last step.  The per-bucket counters are reset HERE, at the start of every bucketed backward: a backward
+            # that aborted midway (an exception caught and retried by the harness) leaves them partly decremented, and the next step
+            # would then fire a bucket's all-reduce before all its slices are written (r2 advisor)
+            self._pending = list(self._count)
+            self._bevents = [[] for _ in self._count]
             return
         self._params = params
         self._flat, self._slot, self._count = [], {}, []
@@ -118,8 +131,7 @@ class GradSync:
 
         def run():
             buf = flat if flat is not None else torch.cat([g.reshape(-1) for g in scatter_to])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            buf.mul_(1.0 / self.world)
+            self._all_reduce_mean(buf)
             if flat is None:
                 off = 0
                 for g in scatter_to:
@@ -137,6 +149,14 @@ class GradSync:
                     g.record_stream(self.stream)
         else:
             run()
+
+    def _all_reduce_mean(self, buf):
+        if self._avg:
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                        # gloo (CPU tests, one-GPU rehearsals) has no AVG
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                buf.mul_(1.0 / self.world)
 
     # ------------------------------------------------------------------ joins
     def launch_pending(self):
@@ -169,5 +189,4 @@ class GradSync:
         """Blocking-order average of a few small tensors (lens coefficients) on the current stream."""
         for t in tensors:
             if t is not None:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                t.mul_(1.0 / self.world)
+                self._all_reduce_mean(t)

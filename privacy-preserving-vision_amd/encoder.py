@@ -478,7 +478,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid"):
             st.pop(k, None)
         return st
 
@@ -564,8 +564,15 @@ class Encoder(nn.Module):
         # __init__ (Parameter OBJECTS are replaced by load_state_dict(assign=True) / .to_empty(): the cache is keyed on their ids)
         cached = self.__dict__.get("_plist_cache")
         if cached is not None and cached[0] == self.__dict__.get("_plist_gen", 0):
-            return cached[1]
+            lst = cached[1]
+            # cheap validation on every call: a PARENT module's load_state_dict(assign=True) or direct weight surgery replaces
+            # Parameter objects without passing through this class's hooks (r2 advisor) -- sentinels from the stem, the first
+            # trainable block and the last block must still be the cached objects
+            r, sent = self.resnet, self.__dict__.get("_plist_mid")
+            if sent is not None and sent[0] is r[0].weight and sent[1] is r[5][0].conv1.weight and sent[2] is r[7][-1].bn3.bias:
+                return lst
         lst = list(self.resnet.parameters())
+        self.__dict__["_plist_mid"] = (self.resnet[0].weight, self.resnet[5][0].conv1.weight, self.resnet[7][-1].bn3.bias)
         self.__dict__["_plist_cache"] = (self.__dict__.get("_plist_gen", 0), lst)
         return lst
 

@@ -363,10 +363,10 @@ class FAN(nn.Module):
 
     def _convblock_t(self, blk, x):
         from .nn_ops import conv2d_f32
-        o1 = conv2d_f32(self._bn_relu_t(blk.bn1, x), blk.conv1.weight.detach(), None, 1, 1)
-        o2 = conv2d_f32(self._bn_relu_t(blk.bn2, o1), blk.conv2.weight.detach(), None, 1, 1)
-        o3 = conv2d_f32(self._bn_relu_t(blk.bn3, o2), blk.conv3.weight.detach(), None, 1, 1)
-        res = x if blk.downsample is None else conv2d_f32(self._bn_relu_t(blk.downsample[0], x), blk.downsample[2].weight.detach(), None, 1, 0)
+        o1 = conv2d_f32(self._bn_relu_t(blk.bn1, x), blk.conv1.weight, None, 1, 1, weight_grad=False)
+        o2 = conv2d_f32(self._bn_relu_t(blk.bn2, o1), blk.conv2.weight, None, 1, 1, weight_grad=False)
+        o3 = conv2d_f32(self._bn_relu_t(blk.bn3, o2), blk.conv3.weight, None, 1, 1, weight_grad=False)
+        res = x if blk.downsample is None else conv2d_f32(self._bn_relu_t(blk.downsample[0], x), blk.downsample[2].weight, None, 1, 0, weight_grad=False)
         return torch.cat((o1, o2, o3), dim=-1) + res
 
     def _hourglass_t(self, level, x):
@@ -392,17 +392,17 @@ class FAN(nn.Module):
         c256 = _coord_channels(256, 256).to(dev).permute(1, 2, 0)                        # [256,256,3]
         c64 = _coord_channels(64, 64).to(dev).permute(1, 2, 0)
         t = torch.cat([x.float().permute(0, 2, 3, 1), c256.unsqueeze(0).expand(B, -1, -1, -1)], dim=-1)      # CoordConv: + xx, yy, rr
-        t = conv2d_f32(t, self.conv1.conv.weight.detach(), self.conv1.conv.bias.detach(), 2, 3)
+        t = conv2d_f32(t, self.conv1.conv.weight, self.conv1.conv.bias, 2, 3, weight_grad=False)
         t = self._bn_relu_t(self.bn1, t)
         t = self._convblock_t(self.conv2, t)
         t = t.view(B, 64, 2, 64, 2, t.shape[-1]).mean(dim=(2, 4))                          # F.avg_pool2d(., 2)
         t = self._convblock_t(self.conv4, self._convblock_t(self.conv3, t))
         cc = self.m0.coordconv.conv
-        h = conv2d_f32(torch.cat([t, c64.unsqueeze(0).expand(B, -1, -1, -1)], dim=-1), cc.weight.detach(), cc.bias.detach(), 1, 0)
+        h = conv2d_f32(torch.cat([t, c64.unsqueeze(0).expand(B, -1, -1, -1)], dim=-1), cc.weight, cc.bias, 1, 0, weight_grad=False)
         ll = self._convblock_t(self.top_m_0, self._hourglass_t(4, h))
-        ll = conv2d_f32(ll, self.conv_last0.weight.detach(), self.conv_last0.bias.detach(), 1, 0)
+        ll = conv2d_f32(ll, self.conv_last0.weight, self.conv_last0.bias, 1, 0, weight_grad=False)
         ll = self._bn_relu_t(self.bn_end0, ll)
-        out = conv2d_f32(ll, self.l0.weight.detach(), self.l0.bias.detach(), 1, 0).permute(0, 3, 1, 2)
+        out = conv2d_f32(ll, self.l0.weight, self.l0.bias, 1, 0, weight_grad=False).permute(0, 3, 1, 2)
         if self.end_relu:
             out = F.relu(out)
         boundary = c64.permute(2, 0, 1)[1:3].unsqueeze(0).expand(B, -1, -1, -1)             # last two CoordConv input channels

@@ -7,13 +7,15 @@ the frozen regressor into the generated image) and the StarGAN-v2 blocks (core/m
                 weight gradient on the bf16 MFMA weight-gradient kernel where its tile rules hold (channel counts multiples of
                 128), otherwise ``torch.nn.grad.conv2d_weight`` (library, on the device).
 ``instance_norm_act``  InstanceNorm2d / AdaIN + LeakyReLU, forward and backward (csrc/instnorm.hip)."""
+import weakref
+
 import torch
 import torch.nn.functional as F
 
 from . import _lib, convops as co
 from ._lib import check, ptr, stream_ptr
 
-_wcache = {}
+_wcache = {}            # id(weight tensor) -> (version key, forward layout, data-gradient layout, weakref to that tensor)
 
 
 def _pad_to(t, dim, mult):
@@ -26,21 +28,33 @@ def _pad_to(t, dim, mult):
 
 
 def _layouts(w):
-    """(forward GEMM rows over the split input, data-gradient GEMM rows over the split gradient) of conv weight [Cout,Cin,R,S]"""
+    """(forward GEMM rows over the split input, data-gradient GEMM rows over the split gradient) of conv weight [Cout,Cin,R,S].
+    Cached per weight OBJECT: an entry lives exactly as long as the tensor it was built from (its weak reference drops the entry when
+    the tensor dies, so a recycled id() can never return another tensor's layout and layouts of dead models are released) and is
+    rebuilt when the tensor's version counter or storage changes.  Pass the long-lived Parameter (conv2d_f32(..., weight_grad=False)
+    for frozen weights), not a `.detach()` temporary: a temporary's entry dies with it, i.e. the layouts are rebuilt on every call.
+    In-place writes through ``.data`` bump no version counter: call ``drop_layouts(w)`` after such a write."""
     key = id(w)
     ent = _wcache.get(key)
     ver = (w._version, w.data_ptr(), w.device)
-    if ent is None or ent[0] != ver:
+    if ent is None or ent[0] != ver or ent[3]() is not w:
         wf = w.detach().float()
         hi = wf.bfloat16().float()
         lo = (wf - hi).bfloat16().float()
         fwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=1), 1, 64), 0, 64)                # [Coutp, pad64(3 Cin), R, S]
         bwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=0), 0, 64), 1, 64)                # [pad64(3 Cout), Cinp, R, S]
-        ent = (ver, co.weight_layout(fwd.contiguous(), 0), co.weight_layout(bwd.contiguous(), 1))
-        if len(_wcache) > 4096:
-            _wcache.clear()
+        ent = (ver, co.weight_layout(fwd.contiguous(), 0), co.weight_layout(bwd.contiguous(), 1),
+               weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)))
         _wcache[key] = ent
     return ent[1], ent[2]
+
+
+def drop_layouts(w=None):
+    """Forget the cached layouts of ``w`` (all weights when None)."""
+    if w is None:
+        _wcache.clear()
+    else:
+        _wcache.pop(id(w), None)
 
 
 def _split3(t):
@@ -53,12 +67,12 @@ def _split3(t):
 
 class _ConvF32(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
+    def forward(ctx, x, weight, bias, stride, pad, wf, wd):
         _lib.require_cuda(x, weight)
         x = x.contiguous().float()
         Cout, Cin, R, S = weight.shape
         assert R == S and x.shape[-1] == Cin
-        wf, _ = _layouts(weight)
+        ctx.wd = wd
         y = co.conv_fwd(_split3(x), wf, stride, pad, out_f32=True)
         if y.shape[-1] != Cout:
             y = y[..., :Cout].contiguous()
@@ -76,8 +90,7 @@ class _ConvF32(torch.autograd.Function):
         gy = gy.contiguous().float()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            _, wd = _layouts(weight)
-            gx = co.conv_dgrad(_split3(gy), wd, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
+            gx = co.conv_dgrad(_split3(gy), ctx.wd, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
             if gx.shape[-1] != Cin:
                 gx = gx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
@@ -87,12 +100,18 @@ class _ConvF32(torch.autograd.Function):
                 gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), stride=stride, padding=pad)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(dim=(0, 1, 2))
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def conv2d_f32(x, weight, bias=None, stride=1, pad=0):
-    """x [B,H,W,Cin] f32 NHWC, weight [Cout,Cin,k,k] (torch layout, e.g. an nn.Conv2d's parameter) -> [B,Ho,Wo,Cout] f32."""
-    return _ConvF32.apply(x, weight, bias, stride, pad)
+def conv2d_f32(x, weight, bias=None, stride=1, pad=0, weight_grad=True):
+    """x [B,H,W,Cin] f32 NHWC, weight [Cout,Cin,k,k] (torch layout, e.g. an nn.Conv2d's parameter) -> [B,Ho,Wo,Cout] f32.
+    weight_grad=False: the weight (and bias) are treated as constants whatever their requires_grad says (a frozen network, FAN in
+    core/wing.py:262-272) -- the bf16 layouts stay cached on the Parameter object itself."""
+    wf, wd = _layouts(weight)
+    if not weight_grad:
+        weight = weight.detach()
+        bias = None if bias is None else bias.detach()
+    return _ConvF32.apply(x, weight, bias, stride, pad, wf, wd)
 
 
 class _InstNormAct(torch.autograd.Function):

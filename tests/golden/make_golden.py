@@ -357,7 +357,70 @@ def gen_decoder():
     print("decoder loss", loss.item(), "preds", stats(preds), "alphas", stats(alphas), "g_enc", stats(enc.grad))
 
 
-# --------------------------------------------------------------------------- SSIM loss (Image_Caption/pytorch_ssim)
+
+# --------------------------------------------------------------------------- ResNet-101 encoder (Image_Caption/models.py:8-54)
+def gen_encoder():
+    """The reference's own ``models.Encoder`` (models.py:8-54: children()[:-2] of torchvision.models.resnet101, fine_tune() on
+    children [5:], AdaptiveAvgPool2d + permute) run on CPU in train mode (train.py:245).  torchvision is absent offline: the stand-in
+    for ``torchvision.models.resnet101`` returns a module with torchvision's child order (conv1, bn1, relu, maxpool, layer1-4,
+    avgpool, fc) whose trunk is assembled from oracle/resnet.py's pieces (that restatement is itself pinned against the independent
+    ResNet-101 v1.5 of `transformers`, tests/test_oracle_trunk_pin.py); everything the Encoder class does with it is the
+    reference's code.  Weights: tests/trunk_fill.py (by state_dict name).  4 x 3 x 64 x 64 input: layer 4 sees a 2 x 2 map."""
+    install_standins()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import resnet as R
+    from trunk_fill import fill_trunk_by_name
+    from torch import nn
+
+    class TVResNet(nn.Module):                                  # torchvision.models.resnet.ResNet's attribute / child order
+        def __init__(self):
+            super().__init__()
+            t = R.make_resnet101_trunk()
+            self.conv1, self.bn1, self.relu, self.maxpool = t[0], t[1], t[2], t[3]
+            self.layer1, self.layer2, self.layer3, self.layer4 = t[4], t[5], t[6], t[7]
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(2048, 1000)
+
+    sys.modules["torchvision"].models.resnet101 = lambda pretrained=False, **kw: TVResNet()
+    sys.path.insert(0, os.path.join(REF, "Image_Caption"))
+    import models as ref_models
+    out = {}
+    for tag, E in (("e3", 3), ("e36", 36)):
+        enc = ref_models.Encoder(encoded_image_size=E)
+        fill_trunk_by_name(enc)
+        enc.train()
+        img = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(0)).requires_grad_(True)
+        y = enc(img)
+        w = torch.rand(y.shape, generator=torch.Generator().manual_seed(5))
+        (y * w).sum().backward()
+        names = [n for n, _ in enc.named_parameters()]
+        if tag == "e3":
+            out["state_names"] = np.array(list(enc.state_dict().keys()))
+            out["param_names"] = np.array(names)
+            out["requires_grad"] = np.array([p.requires_grad for _, p in enc.named_parameters()])
+            out["img_grad"] = img.grad.numpy()
+            out["out"] = y.detach().numpy()
+            # every parameter gradient as (sum, sum of squares, first 8 values); None (frozen) -> zeros
+            gs = np.zeros((len(names), 10))
+            for i, (_, p) in enumerate(enc.named_parameters()):
+                if p.grad is not None:
+                    g = p.grad.double().reshape(-1)
+                    gs[i, 0], gs[i, 1] = g.sum().item(), (g * g).sum().item()
+                    gs[i, 2:2 + min(8, g.numel())] = g[:8].numpy()
+            out["param_grad_stats"] = gs
+            sd = enc.state_dict()
+            out["running_mean"] = np.concatenate([sd[k].numpy() for k in sd if k.endswith("running_mean")])
+            out["running_var"] = np.concatenate([sd[k].numpy() for k in sd if k.endswith("running_var")])
+            out["num_batches_tracked"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")])
+            out["g_layer2_conv1"] = enc.resnet[5][0].conv1.weight.grad.numpy()          # one whole weight gradient (128x256x1x1)
+            out["g_layer4_bn3"] = enc.resnet[7][2].bn3.weight.grad.numpy()
+        else:
+            out["out36_sub"] = y.detach()[:, ::7, ::7, ::16].numpy()
+            out["out36_stats"] = stats(y)
+        print("encoder", tag, y.shape, stats(y), "img grad", stats(img.grad))
+    np.savez_compressed(os.path.join(HERE, "encoder.npz"), **out)
+
+# --------------------------------------------------------------------------- RAFT SepConvGRU
 def gen_raft_gru():
     """RAFT's SepConvGRU (RAFT/core/update.py:33-60): the reference module with parameters filled by name, three chained updates."""
     sys.path.insert(0, os.path.join(REF, "Face-DeId"))
@@ -380,6 +443,7 @@ def gen_raft_gru():
     print("raft_gru", outs[2].shape, stats(torch.from_numpy(outs[2])))
 
 
+# --------------------------------------------------------------------------- SSIM loss (Image_Caption/pytorch_ssim)
 def gen_ssim():
     sys.path.insert(0, os.path.join(REF, "Image_Caption"))
     import pytorch_ssim
@@ -401,7 +465,7 @@ def gen_ssim():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim", "raft_gru", "fan_train", "stargan"):
+        for w in ("ic", "fd", "corr", "fan", "decoder", "ssim", "raft_gru", "fan_train", "stargan", "encoder"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim, "raft_gru": gen_raft_gru, "fan_train": gen_fan_train, "stargan": gen_stargan}[what]()
+        {"ic": gen_ic, "fd": gen_fd, "corr": gen_corr, "fan": gen_fan, "decoder": gen_decoder, "ssim": gen_ssim, "raft_gru": gen_raft_gru, "fan_train": gen_fan_train, "stargan": gen_stargan, "encoder": gen_encoder}[what]()

@@ -155,6 +155,11 @@ AUTO_FWD = [
     (128, 16, 256, 1024, 1, 1),   # the layer-3 conv3 shape itself at B = 128 -> conv_stream.hip (K = 256)
     (32, 64, 64, 256, 1, 1),      # layer-1 conv3 -> conv_stream.hip (K = 64)
     (32, 64, 256, 512, 1, 2),     # layer-2 projection shortcut (stride 2) -> conv_stream.hip, strided pixel rows
+    # VERDICT r2 task 1c: the benchmark's own layer-4 (8 x 8 maps, M = 8192) and layer-2 3x3 (32 x 32, M = 131 072) launches at B = 128
+    (128, 8, 512, 2048, 1, 1),    # layer-4 conv3
+    (128, 8, 2048, 512, 1, 1),    # layer-4 conv1 (K = 2048)
+    (128, 8, 512, 512, 3, 1),     # layer-4 3x3 (K = 4608)
+    (128, 32, 128, 128, 3, 1),    # layer-2 3x3
 ]
 AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
     (32, 32, 256, 256, 3, 1),     # N = 256, M = 32 768 -> conv_halo.hip; variant 7: <256,128,3,64,1>
@@ -163,6 +168,10 @@ AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
     (16, 32, 256, 512, 1, 2),     # stride-2 projection data gradient (zero-page taps), N = 256
     (128, 16, 1024, 256, 1, 1),   # the layer-3 conv1 data gradient at B = 128 -> conv_stream.hip with addend + mask + sums
     (32, 64, 256, 64, 1, 1),      # layer-1 conv1 data gradient (K = 64 -> 256 columns) -> conv_stream.hip
+    (128, 8, 512, 2048, 1, 1),    # layer-4 conv3 data gradient (K = 2048 -> 512 columns)
+    (128, 8, 2048, 512, 1, 1),    # layer-4 conv1 data gradient (512 -> 2048 columns, addend + mask + sums)
+    (128, 8, 512, 512, 3, 1),     # layer-4 3x3 data gradient
+    (128, 32, 128, 128, 3, 1),    # layer-2 3x3 data gradient
 ]
 
 
@@ -219,6 +228,10 @@ WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> th
     (16, 64, 128, 128, 3, 2, 7),    # streamed kernel, strided taps with padding
     (32, 32, 256, 1024, 1, 1, 0x400),   # one f32-atomic slab per XCD (HW_REG_XCC_ID) instead of one slab per m-slice
     (64, 16, 1024, 256, 1, 1, 0x400),
+    (128, 8, 512, 2048, 1, 1, 0),   # layer 4 at B = 128 (M = 8192): conv3, conv1, 3x3
+    (128, 8, 2048, 512, 1, 1, 0),
+    (128, 8, 512, 512, 3, 1, 0),
+    (128, 32, 128, 128, 3, 1, 0),   # layer-2 3x3 at B = 128 (M = 131 072)
 ]
 
 

@@ -47,3 +47,28 @@ def test_full_depth_f32_trunk_against_the_unrounded_oracle(B):
     # move the oracle's own output by 0.7).  Measured (max-norm, relative): layer1 4e-5, layer2 1.5e-4, layer3 4e-3, layer4 and
     # the encoder output 1.0e-2 (B = 32) / 1.2e-2 (B = 4); asserted with head-room
     assert max(errs) < 3e-2 and _rel(got, want) < 3e-2
+
+
+def test_f32_trunk_against_the_reference_encoders_own_output():
+    """tests/golden/encoder.npz = the reference's models.Encoder (Image_Caption/models.py:8-54) run on CPU in train mode by
+    make_golden.py::gen_encoder (weights by state_dict name, tests/trunk_fill.py).  4 x 3 x 64 x 64: layer 4 is a 2 x 2 map, BatchNorm
+    over 16 samples -- the most chaotic setting the trunk can be put in; same tolerance as the 256 x 256 case above."""
+    from conftest import load_golden
+    from trunk_fill import fill_trunk_by_name
+    from ppv_amd.encoder import Encoder
+    g = load_golden("encoder.npz")
+    enc = Encoder(3)
+    fill_trunk_by_name(enc)
+    enc = enc.cuda().train()
+    assert list(enc.state_dict().keys()) == [str(k) for k in g["state_names"]]
+    img = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    got = enc.forward_fp32_accurate(img.cuda())
+    want = torch.from_numpy(g["out"])
+    assert got.shape == want.shape == (4, 3, 3, 2048)
+    e = _rel(got, want)
+    print(f"forward_fp32_accurate vs reference Encoder golden: {e:.2e}")
+    assert e < 3e-2
+    enc36 = Encoder(36)
+    fill_trunk_by_name(enc36)
+    got36 = enc36.cuda().train().forward_fp32_accurate(img.cuda())
+    assert _rel(got36[:, ::7, ::7, ::16], torch.from_numpy(g["out36_sub"])) < 3e-2

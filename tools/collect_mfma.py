@@ -2,7 +2,10 @@
 1024 SIMDs, MI355X_MICROARCH.md) / (1024 x kernel duration x 2.4 GHz), durations from the --kernel-trace --stats pass.
 
 usage: collect_mfma.py <mfma_counter_collection.csv> <kernel_stats.csv> <out.json>"""
-import csv, json, re, sys, collections
+import csv, json, os, re, sys, collections
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_hash
 
 busy = collections.defaultdict(lambda: [0.0, 0])
 sq = collections.defaultdict(float)                # SQ_BUSY_CYCLES: summed over the 32 shader engines
@@ -16,7 +19,7 @@ dur = {}
 for r in csv.DictReader(open(sys.argv[2])):
     dur[re.sub(r"\(.*", "", r["Name"]).replace("void ", "")] = float(r["AverageNs"])
 out = {"note": "MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x average kernel duration x 2.4 GHz); PMC pass and "
-               "kernel-trace pass are separate runs of bench.py (B = 128); *_at_actual_clock = MFMA busy / (32 x SQ_BUSY_CYCLES), i.e. against the cycles the launch really had (the shader clock sits near 1.7-1.9 GHz under MFMA load, not 2.4)", "per_kernel": {}}
+               "kernel-trace pass are separate runs of bench.py (B = 128); *_at_actual_clock = MFMA busy / (32 x SQ_BUSY_CYCLES), i.e. against the cycles the launch really had (the shader clock sits near 1.7-1.9 GHz under MFMA load, not 2.4)", "csrc_sha16": csrc_hash(), "per_kernel": {}}
 for k, (c, n) in sorted(busy.items(), key=lambda kv: -kv[1][0]):
     if c <= 0 or k not in dur:
         continue

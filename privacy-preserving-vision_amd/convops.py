@@ -346,9 +346,10 @@ def maxpool_relu_bwd(gy, y, arg, in_hw):
     return g
 
 
-def adaptive_pool_fwd(x, E, out_dtype=F32):
+def adaptive_pool_fwd(x, E, out_dtype=F32, out=None):
     B, H, W, C = x.shape
-    y = torch.empty((B, E, E, C), dtype=out_dtype, device=x.device)
+    y = torch.empty((B, E, E, C), dtype=out_dtype, device=x.device) if out is None else out
+    assert y.shape == (B, E, E, C) and y.dtype == out_dtype and y.is_contiguous()
     check(L().ppv_adaptive_pool_fwd(ptr(x), ptr(y), B, H, W, C, E, int(out_dtype == F32), stream_ptr()), "ppv_adaptive_pool_fwd")
     return y
 

@@ -44,6 +44,7 @@ struct WgradGeom {
     int xcd_group;         // 1: tiles of one m-slice share an XCD (1-D grid decode)
     long slab_elems;       // > 0: slice z stores its tile plainly into dW + z * slab_elems (no atomics)
     int xcc_slabs;         // 1: every slice ADDS (f32 atomics) into the slab of the XCD it runs on (dW + XCC_ID * slab_elems, pre-zeroed)
+    int pf_dist;           // cooperative L2 prefetch distance in 64-row stages (PF instantiations of conv_wgrad_pipe_kernel)
 };
 
 // 32-byte block swizzle key of a staged row (conflict-free ds_read_b64_tr_b16: see file header)
@@ -195,14 +196,27 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // One 128 (c) x TN (n) tile of dW over the rows [m_begin, m_end): the body of conv_wgrad_pipe_kernel and conv_wgrad_group_kernel.
-template <int TN, int NSTAGE>
+// PF (1x1 / unit stride, xcd_group): COOPERATIVE L2 PREFETCH.  The tiles of one m-slice run on one XCD in lockstep and share their
+// operand rows (a G piece is staged by every c-tile, an X piece by every n-tile: 3.2x the compulsory bytes at 128 x 128 tiles).  In
+// lockstep the sharers' LDS-DMA requests all arrive while the line is still in flight from HBM, so every one of them waits the
+// full miss latency: the staged bytes move at the per-CU MISS rate (~20 GB/s: the CU's outstanding-miss budget x 128 B / latency)
+// although only 1/3.2 of them leave the L2.  Here every workgroup pulls ITS SHARE of the group's unique lines (rows r with
+// r % sharers == own index: 80 of the 1280 lines of a stage) into the XCD's L2 pf_dist stages ahead with one global_load_dword per
+// wave (one lane per 128-byte line, result discarded), so that the LDS-DMA requests of the stage itself are L2 hits (~100 GB/s per
+// CU).  Speed only: a late or missing prefetch costs a miss, never correctness.
+// MEASURED (round 3, tools/bench_wgrad.py 0 0x800, interleaved in one process, B = 128, times incl. the slab reduce): NO GAIN --
+// layer 3 (256 -> 1024 / 1024 -> 256 at 16 x 16) 59.6 / 57.1 us with the prefetch against 60.2 / 57.2 without, layer 2 (128 -> 512 at
+// 32 x 32) 80.3 against 71.5 (the extra 80 line requests per stage compete with the stage's own 256), layer 4 unchanged.  The
+// lockstep hit-under-miss picture is therefore NOT what bounds this kernel; kept opt-in (PPV_WGRAD_PF=<stages ahead>), default off.
+template <int TN, int NSTAGE, bool PF = false>
 __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X, float* __restrict__ dst,
                                                 const bf16_t* __restrict__ zero_page, const WgradGeom& g, long m_begin, long m_end,
                                                 int n0, int tap, int c0, bool atomic) {
     constexpr int NT = TN * 2, NW = NT / 64, NH = TN / 128;               // threads, waves, 128-column halves of G
     constexpr int HALF = 64 * 256;                                        // one [64][128] bf16 tile
     constexpr int STAGE_BYTES = (NH + 1) * HALF;
-    constexpr int GI = (NH * 16) / NW, XI = 16 / NW, L = GI + XI;         // wave-instructions per thread per stage
+    constexpr int GI = (NH * 16) / NW, XI = 16 / NW, L = GI + XI + (PF ? 1 : 0);   // wave-instructions per thread per stage (+ the prefetch)
+    constexpr int PFO = PF ? 1 : 0;                                       // the youngest prefetch may stay outstanding at a stage wait
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = tap / g.S, s = tap % g.S;
@@ -214,6 +228,10 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
     const long zdX = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
     const float rcp_howo = 1.0f / (float)HoWo, rcp_wo = 1.0f / (float)g.Wo;
 
+    // prefetch roles (PF): threads 0 .. NT/2-1 cover the 64 rows x (TN*2/128) lines of the G piece, the rest the 64 x 2 lines of the X piece
+    const int pf_nt = g.N / TN, pf_ct = g.Cs / 128;                       // sharers of an X piece / of a G piece (powers of two: launcher)
+    const int pf_ni = n0 / TN, pf_ci = c0 / 128;
+    unsigned pf_sink = 0;
     int st_next = 0;
     auto stage = [&](int buf) {
         char* sb = smem + buf * STAGE_BYTES;
@@ -240,6 +258,30 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
             const bool ok = (m < m_end) & ((unsigned)hs < (unsigned)g.Hs) & ((unsigned)ws < (unsigned)g.Ws);
             const long off = ok ? ((((long)b * g.Hs + hs) * g.Ws + ws) * g.Cs + c0 + gch * 8) * 2 : zdX;
             GLDS16W(reinterpret_cast<const char*>(X) + off, sb + NH * HALF + q * 1024);
+        }
+        if constexpr (PF) {
+            // one load per wave, every lane active (the hand-counted vmcnt waits below assume exactly one per stage): lanes without a
+            // line of their own re-touch the zero page
+            const long pm0 = mb + (long)g.pf_dist * 64;
+            const char* src = reinterpret_cast<const char*>(zero_page);
+            if (tid < NT / 2) {                                            // G piece: TN * 2 bytes per row = TN / 64 lines
+                constexpr int LPR = TN / 64;
+                const int line = tid * (64 * LPR) / (NT / 2) ;             // NT / 2 threads over 64 * LPR lines (1 : 1)
+                const int row = line / LPR, part = line % LPR;
+                const long m = pm0 + row;
+                if (m < m_end && (row & (pf_ct - 1)) == pf_ci) src = reinterpret_cast<const char*>(G) + (m * g.N + n0 + part * 64) * 2;
+            } else {                                                       // X piece: 256 bytes per row = 2 lines
+                const int l2 = tid - NT / 2;
+                if (l2 < 128) {
+                    const int row = l2 >> 1, part = l2 & 1;
+                    const long m = pm0 + row;
+                    if (m < m_end && (row & (pf_nt - 1)) == pf_ni) src = reinterpret_cast<const char*>(X) + (m * g.Cs + c0 + part * 64) * 2;
+                }
+            }
+            // the load lands LATER: its destination must stay reserved for the whole loop ("+v" on a loop-carried variable that is
+            // consumed after the final vmcnt(0)), or the register allocator hands the register to a live value that the returning
+            // load then overwrites
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src) : "memory");
         }
     };
 
@@ -287,9 +329,9 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
     int rd = 0, wr = (NSTAGE - 1) % NSTAGE;
     for (int t = 0; t < nst; ++t) {
         const int younger = min(nst, t + NSTAGE - 1) - (t + 1);
-        if (NSTAGE >= 3 && younger >= NSTAGE - 2) wg_wait_vmcnt_le<(NSTAGE - 2) * L>();
-        else if (NSTAGE >= 4 && younger == NSTAGE - 3) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
-        else wg_wait_vmcnt_le<0>();
+        if (NSTAGE >= 3 && younger >= NSTAGE - 2) wg_wait_vmcnt_le<(NSTAGE - 2) * L + PFO>();
+        else if (NSTAGE >= 4 && younger == NSTAGE - 3) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0) + PFO>();
+        else wg_wait_vmcnt_le<PFO>();
         __builtin_amdgcn_s_barrier();
         if (t + NSTAGE - 1 < nst) stage(wr);
         compute(rd);
@@ -297,6 +339,10 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
         wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
     }
 
+    if constexpr (PF) {                                                   // retire the last prefetch, then release its register
+        wg_wait_vmcnt_le<0>();
+        asm volatile("" ::"v"(pf_sink));
+    }
     const int fr = lane & 15, fq = lane >> 4;
     const long wrow = (long)g.R * g.S * g.Cs;
 #pragma unroll
@@ -313,7 +359,7 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
             }
 }
 
-template <int TN, int NSTAGE>
+template <int TN, int NSTAGE, bool PF = false>
 __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
                                                                     float* __restrict__ dW,
                                                                     const bf16_t* __restrict__ zero_page, WgradGeom g) {
@@ -341,10 +387,10 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
         // then live in one L2 only (no cross-XCD line migration, which is what made atomics into a single accumulator slow), 8 slabs are
         // reduced instead of 24-48, and the index comes from the hardware (HW_REG_XCC_ID), so it is right for any block -> XCD mapping.
         const int xcc = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;
-        wgrad_pipe_body<TN, NSTAGE>(G, X, dW + (long)xcc * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, true);
+        wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)xcc * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, true);
         return;
     }
-    wgrad_pipe_body<TN, NSTAGE>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0);
+    wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0);
 }
 
 // Several weight gradients of ONE shape (1x1, unit stride: the conv1 / conv3 of a layer's bottlenecks) in one launch, each reduced
@@ -1113,6 +1159,12 @@ static int wgrad_target_wgs() {
     return t < 16 ? 16 : t;
 }
 
+// stages the cooperative L2 prefetch of the 1x1 weight gradients runs ahead (PPV_WGRAD_PF; 0 = off)
+static int wgrad_pf_dist() {
+    static const int d = getenv("PPV_WGRAD_PF") ? atoi(getenv("PPV_WGRAD_PF")) : 0;   // measured: no gain (see wgrad_pipe_body)
+    return d;
+}
+
 static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN, long* splits, int* sps) {
     const long stages = (M + 63) / 64;
     int tn = (N % 256 == 0 && variant != 2) ? 256 : 128;
@@ -1188,6 +1240,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S; g.st = stride; g.pad = pad;
     g.M = (long)B * Ho * Wo;
     g.xcc_slabs = 0;
+    g.pf_dist = 0;
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;            // fast_divmod range
     int variant = g_wgrad_variant & 0xff;
     g.xcd_group = (g_wgrad_variant & 0x100) ? 0 : 1;
@@ -1277,8 +1330,20 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     } else if (small_ring) {
         constexpr int lds = 2 * 2 * 64 * 256;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-        conv_wgrad_pipe_kernel<128, 2><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr = true;
+        }
+        // cooperative L2 prefetch (see wgrad_pipe_body): 1x1 / unit stride with the m-slice's tiles grouped on one XCD
+        const int pfd = wgrad_pf_dist();
+        const int nt_ = N / 128, ct_ = Cs / 128;
+        if (pfd > 0 && R * S == 1 && stride == 1 && g.xcd_group && !g.xcc_slabs && !(g_wgrad_variant & 0x800) && !(nt_ & (nt_ - 1)) && !(ct_ & (ct_ - 1)) &&
+            nt_ <= 64 && ct_ <= 64) {
+            g.pf_dist = pfd;
+            conv_wgrad_pipe_kernel<128, 2, true><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        } else
+            conv_wgrad_pipe_kernel<128, 2><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     } else {
         constexpr int lds = 4 * 2 * 64 * 256;
         static bool attr = false;
@@ -1299,7 +1364,7 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
     g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1; g.st = 1; g.pad = 0;
     g.M = (long)B * H * W;
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;
-    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0;
+    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0; g.pf_dist = 0;
     WgradGroupPtrs ptrs;
     for (int p = 0; p < 24; ++p) {
         const int q = p < P ? p : 0;

@@ -394,5 +394,7 @@ class DecoderWithAttention(nn.Module):
             R, A = cells.shape[1] * cells.shape[2], self.attention_dim
             if tb is not None and R * A * 2 + (2 * A + tb["Q"] + R) * 4 <= 150 * 1024 and R * A * 2 + (2 * A + 2 * tb["Q"]) * 4 <= 150 * 1024:
                 src, tables = cells, tb
+        if tables is None and hasattr(src, "materialize"):        # general path on the dense tensor: have its values written (LazyEncoderOut)
+            src = src.materialize()
         preds, alphas = _DecoderFn.apply(self, caps, order.contiguous(), dec_len, tables, n_pix, src, *self._plist())
         return preds, caps, dec_len, alphas, order

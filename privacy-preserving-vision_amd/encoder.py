@@ -119,6 +119,61 @@ def _bn_coef(rec, stat_part, count):
     return torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
 
 
+_META_GETTERS = frozenset(("shape", "dtype", "device", "requires_grad", "is_cuda", "ndim", "grad_fn", "is_leaf", "layout", "names", "is_sparse",
+                           "is_quantized", "is_meta", "is_cpu", "output_nr"))
+_META_METHODS = frozenset(("size", "dim", "numel", "stride", "is_contiguous", "element_size", "nelement", "ndimension", "is_floating_point",
+                           "is_complex", "get_device", "storage_offset", "__len__", "__hash__", "dim_order", "is_pinned", "is_shared"))
+
+
+class LazyEncoderOut(torch.Tensor):
+    """What ``Encoder.forward`` returns with ``lazy_output`` on: the [B,E,E,2048] float32 tensor of models.py:39-41 whose VALUES are
+    written the first time anything reads them.
+
+    The reference's ``AdaptiveAvgPool2d(36)`` on an 8 x 8 map + permute replicates every cell into a 4-5 x 4-5 window: 1.36 GB of f32 at
+    B = 128 that ppv_amd's own consumers never read (``ppv_amd.decoder`` and the benchmark's head work on the 8 x 8 cell map behind it,
+    attribute ``_ppv_cells``).  The buffer is allocated in forward, its shape / dtype / device / ``grad_fn`` are those of the real
+    output, and the pooling kernel (csrc/trunk_ops.hip adaptive_pool_fwd) runs on the first torch operation that takes this tensor as
+    an argument (``__torch_function__``: arithmetic, indexing, ``.cpu()``, ``data_ptr()``, ``print`` ...), which then sees the ordinary
+    autograd-connected tensor.  Not covered: the functional autograd entry points called ON this object itself
+    (``torch.autograd.grad(lazy, ...)`` / ``torch.autograd.backward([lazy])``) and ``torch.autograd.Function.apply(lazy)`` do not dispatch
+    through ``__torch_function__``: the object stays attached to the graph (gradients flow), and its values are written as soon as
+    the callee's first torch operation touches it; code that reads the storage without any torch call must ``.materialize()``
+    first, or construct the encoder with ``Encoder(lazy_output=False)``."""
+
+    @classmethod
+    def wrap(cls, real, fill):
+        """real: the trunk's (not yet written) output tensor; fill(): launches the kernel that writes it."""
+        with torch._C.DisableTorchFunctionSubclass():
+            t = real.as_subclass(cls)          # same storage, stays attached to the autograd graph (raw autograd consumers see the edge)
+        t._real, t._fill = real, fill
+        return t
+
+    def materialize(self):
+        """Write the values (once) and return the ordinary tensor."""
+        fill = self.__dict__.get("_fill")
+        if fill is not None:
+            self.__dict__["_fill"] = None
+            fill()
+        return self.__dict__["_real"]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        owner = getattr(func, "__self__", None)
+        name = getattr(owner, "__name__", None) if getattr(func, "__name__", "") == "__get__" else getattr(func, "__name__", None)
+        meta = (getattr(func, "__name__", "") == "__get__" and name in _META_GETTERS) or (name in _META_METHODS and owner is None)
+
+        def sub(a):
+            if isinstance(a, LazyEncoderOut):
+                return a.__dict__["_real"] if meta else a.materialize()
+            if isinstance(a, (tuple, list)):
+                return type(a)(sub(v) for v in a)
+            return a
+
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[sub(a) for a in args], **{k: sub(v) for k, v in kwargs.items()})
+
+
 class _TrunkFn(torch.autograd.Function):
     """(images f32 NCHW, *params) -> [B,E,E,2048] f32.  params follow Encoder._param_list()."""
 
@@ -212,7 +267,24 @@ class _TrunkFn(torch.autograd.Function):
             yout, ybits = yo if train else (yo, None)
             blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
             x, xin_bits = yout, ybits
-        out = co.adaptive_pool_fwd(x, enc.enc_image_size)
+        if getattr(enc, "lazy_output", False):
+            # models.py:39-41's dense f32 tensor is ALLOCATED here and written on first access (LazyEncoderOut): ppv_amd's own consumers
+            # read the 8 x 8 map instead
+            E_ = enc.enc_image_size
+            out = torch.empty((x.shape[0], E_, E_, x.shape[3]), dtype=torch.float32, device=dev)
+            ready = torch.cuda.Event()
+            ready.record()
+            xs = x
+
+            def fill(out=out, xs=xs, ready=ready, E_=E_):
+                cur = torch.cuda.current_stream(out.device)
+                cur.wait_event(ready)
+                with torch.cuda.device(out.device):
+                    co.adaptive_pool_fwd(xs, E_, out=out)
+                out.record_stream(cur); xs.record_stream(cur)
+            object.__setattr__(enc, "_last_fill", fill)   # picked up by Encoder.forward right after apply() (works under no_grad too)
+        else:
+            out = co.adaptive_pool_fwd(x, enc.enc_image_size)
         if train:
             torch._foreach_add_(enc._nbt, 1)
         ctx.enc, ctx.saved, ctx.blocks, ctx.train, ctx.tok = enc, saved, blocks, train, tok
@@ -463,9 +535,10 @@ class _TrunkFn(torch.autograd.Function):
 class Encoder(nn.Module):
     """Encoder (models.py:8-54).  ``layers`` (extra, keyword) shrinks the trunk for tests; default = ResNet-101."""
 
-    def __init__(self, encoded_image_size=36, *, layers=LAYERS):
+    def __init__(self, encoded_image_size=36, *, layers=LAYERS, lazy_output=True):
         super().__init__()
         self.enc_image_size = encoded_image_size
+        self.lazy_output = lazy_output     # the dense [B,E,E,2048] f32 output is written on first access (LazyEncoderOut)
         # the reference loads ImageNet weights (models.py:17); offline there are none: torchvision's random init
         self.resnet = _make_trunk(layers)
         self.adaptive_pool = nn.AdaptiveAvgPool2d((encoded_image_size, encoded_image_size))
@@ -478,7 +551,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill"):
             st.pop(k, None)
         return st
 
@@ -588,6 +661,9 @@ class Encoder(nn.Module):
         if not images.is_cuda:
             raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
         out, cells = _TrunkFn.apply(self, images, *self._param_list())
+        if getattr(self, "lazy_output", False):
+            fill = self.__dict__.pop("_last_fill", None)
+            out = LazyEncoderOut.wrap(out, fill)
         out._ppv_cells = cells             # the 8x8 map behind the up-sampled output (consumed by ppv_amd.decoder, ignored otherwise)
         return out
 

@@ -326,3 +326,46 @@ def test_resnet101_at_batch_128_stagewise_against_the_oracle():
     print(f"B = 128 stage-wise worst block: fwd {worst:.2e}  d_in {worst_b:.2e}  d_param {worst_p:.2e}")
     assert worst < 1e-2 and worst_b < 5e-2 and worst_p < 5e-2
     assert img.grad is not None and torch.isfinite(img.grad).all() and float(img.grad.abs().max()) > 0
+
+
+def test_lazy_dense_output_is_written_on_first_access_only():
+    """Encoder(lazy_output=True) (default): the [B,36,36,2048] f32 tensor of models.py:39-41 is allocated in forward and written by
+    adaptive_pool_fwd the first time a torch operation reads it; a consumer of the 8 x 8 cell map (ppv_amd.decoder, bench.py's head)
+    never triggers that launch.  Values and gradients equal the eager form's."""
+    from ppv_amd.encoder import Encoder, LazyEncoderOut
+    torch.manual_seed(0)
+    lazy_enc = Encoder(36, layers=(1, 1, 1, 1)).cuda().train()
+    eager_enc = Encoder(36, layers=(1, 1, 1, 1), lazy_output=False).cuda().train()
+    eager_enc.load_state_dict(lazy_enc.state_dict())
+    img = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    w = torch.rand(3, 36, 36, 2048, generator=torch.Generator().manual_seed(2)).cuda()
+    a, b = img.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    out_l, out_e = lazy_enc(a), eager_enc(b)
+    assert isinstance(out_l, LazyEncoderOut) and not isinstance(out_e, LazyEncoderOut)
+    assert out_l.shape == out_e.shape == (3, 36, 36, 2048) and out_l.dtype == torch.float32 and out_l.is_cuda
+    assert out_l._ppv_cells.shape == (3, 2, 2, 2048) and out_l.__dict__["_fill"] is not None       # metadata did not write it
+    assert torch.equal(out_l._ppv_cells, out_e._ppv_cells)
+    (out_l * w).sum().backward()                                                                   # first read: the kernel runs now
+    assert out_l.__dict__["_fill"] is None
+    (out_e * w).sum().backward()
+    assert torch.equal(out_l.detach(), out_e.detach())
+    assert rel_err(a.grad, b.grad) < 1e-6
+    for (n, p), q in zip(lazy_enc.named_parameters(), eager_enc.parameters()):
+        if p.requires_grad:
+            assert rel_err(p.grad, q.grad) < 1e-5, n
+    # a cell-map consumer: gradient arrives through the second output only, the dense tensor is never written
+    lazy_enc.zero_grad(set_to_none=True)
+    c = img.clone().requires_grad_(True)
+    out2 = lazy_enc(c)
+    out2._ppv_cells.float().square().mean().backward()
+    assert out2.__dict__["_fill"] is not None and c.grad is not None and torch.isfinite(c.grad).all() and float(c.grad.abs().max()) > 0
+    # written late, on another stream, after backward: still the pooled map
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        late = out2.detach().clone()
+    s.synchronize()
+    want = torch.nn.functional.adaptive_avg_pool2d(out2._ppv_cells.float().permute(0, 3, 1, 2), 36).permute(0, 2, 3, 1)
+    assert rel_err(late, want) < 1e-6
+    with torch.no_grad():                                                                          # eval / no_grad path
+        o3 = lazy_enc.eval()(img)
+        assert rel_err(o3.float(), torch.nn.functional.adaptive_avg_pool2d(o3._ppv_cells.float().permute(0, 3, 1, 2), 36).permute(0, 2, 3, 1)) < 1e-6

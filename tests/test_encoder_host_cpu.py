@@ -54,3 +54,44 @@ def test_gradsync_attach_resets_bucket_counters_and_accepts_no_parameters():
         s.end_of_backward()
     finally:
         dist.destroy_process_group()
+
+
+def test_lazy_encoder_output_mechanics_on_cpu():
+    """LazyEncoderOut (the dense models.py:39-41 tensor written on first access): metadata does not materialise, the first real
+    operation does (once), autograd flows through the real tensor, nested arguments are handled."""
+    import ppv_amd  # noqa: F401
+    from ppv_amd.encoder import LazyEncoderOut
+    src = torch.arange(24.0).reshape(2, 3, 4).requires_grad_(True)
+    real = src * 2.0                                   # autograd-connected "output" whose values a kernel would write later
+    calls = []
+
+    def fill():
+        calls.append(1)
+
+    lazy = LazyEncoderOut.wrap(real, fill)
+    lazy._ppv_cells = "cells"
+    assert isinstance(lazy, torch.Tensor)
+    assert lazy.shape == (2, 3, 4) and lazy.dtype == torch.float32 and lazy.device == real.device and lazy.dim() == 3
+    assert lazy.size(1) == 3 and lazy.numel() == 24 and len(lazy) == 2 and lazy.requires_grad and lazy.grad_fn is real.grad_fn
+    assert lazy._ppv_cells == "cells" and calls == []                 # nothing above touched the values
+    y = (lazy * 3.0).sum() + torch.cat([lazy, lazy], dim=0).mean()
+    assert calls == [1]                                               # written once, by the first operation
+    y.backward()
+    assert torch.allclose(src.grad, torch.full_like(src, 2.0 * 3.0 + 2.0 * 2 / 48))
+    assert lazy.materialize() is real and calls == [1]
+    assert torch.equal(lazy.detach().cpu(), real.detach()) and float(lazy[1, 2, 3]) == 46.0 and calls == [1]
+    # raw autograd consumers (no __torch_function__ dispatch on the way in): the object itself is attached to the graph
+    src2 = torch.ones(3, requires_grad=True)
+    lazy2 = LazyEncoderOut.wrap(src2 * 5.0, lambda: None)
+
+    class Twice(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2.0
+
+    Twice.apply(lazy2).sum().backward()
+    assert torch.allclose(src2.grad, torch.full((3,), 10.0))

@@ -1154,9 +1154,14 @@ extern "C" {
 
 // workgroups a weight-gradient launch aims for (split-M slices x tiles); PPV_WGRAD_WGS overrides (A/B: fewer slices = fewer
 // slab bytes and more CUs left to the data-gradient chain the launches overlap with, but longer launches)
-static int wgrad_target_wgs() {
-    static const int t = getenv("PPV_WGRAD_WGS") ? atoi(getenv("PPV_WGRAD_WGS")) : 384;   // 384: -0.6 % step time against 256 under the overlap, 448+ and 192- lose
-    return t < 16 ? 16 : t;
+static int wgrad_target_wgs(long M = 0) {
+    // round 3 (tools/sweep_env.sh, whole step, same box, two passes): 256 -> 5255, 320 -> 5282, 384 -> 5329, 448 -> 5360, 512 -> 5400,
+    // 576 -> 5253, 640 -> 5280, 768 -> 5252 images/s (512 = two 64-KB workgroups per CU); round 2's optimum was 384.
+    // PPV_WGRAD_WGS_BIGM: the target for launches with >= 64 Ki rows (layer 2), default the same.
+    static const int t = getenv("PPV_WGRAD_WGS") ? atoi(getenv("PPV_WGRAD_WGS")) : 512;
+    static const int tb = getenv("PPV_WGRAD_WGS_BIGM") ? atoi(getenv("PPV_WGRAD_WGS_BIGM")) : t;
+    const int v = M >= 65536 ? tb : t;
+    return v < 16 ? 16 : v;
 }
 
 // stages the cooperative L2 prefetch of the 1x1 weight gradients runs ahead (PPV_WGRAD_PF; 0 = off)
@@ -1165,12 +1170,25 @@ static int wgrad_pf_dist() {
     return d;
 }
 
+// the fused-tap 3x3 kernel's own target (PPV_WGRAD3_WGS): its 120-KB workgroups cannot share a CU with a convolution workgroup, and
+// every m-slice writes a 9-tap slab -- fewer, longer slices than the 1x1 kernels want
+static int wgrad3_target_wgs() {
+    // whole step, same box: 384 -> 5177, 240 -> 5315, 192 -> 5330, 144 -> 5397, 120 -> 5395, 96 -> 5346, 72 -> 5329 images/s
+    // (alone: 192 -> 77 us, 384 -> 89 us on the layer-3 shape: 16 instead of 32 nine-tap slabs)
+    static const int t = getenv("PPV_WGRAD3_WGS") ? atoi(getenv("PPV_WGRAD3_WGS")) : 144;
+    return t < 12 ? 12 : t;
+}
+static int wgrad3_stages() {
+    static const int t = getenv("PPV_WGRAD3_NS") ? atoi(getenv("PPV_WGRAD3_NS")) : 3;
+    return t == 2 ? 2 : 3;
+}
+
 static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN, long* splits, int* sps) {
     const long stages = (M + 63) / 64;
     int tn = (N % 256 == 0 && variant != 2) ? 256 : 128;
     if (variant == 1) tn = 128;
     const int tiles = (N / tn) * (R * S * (Cs / 128));
-    long sp = ((variant == 1 ? 512 : wgrad_target_wgs()) + tiles - 1) / tiles;
+    long sp = ((variant == 1 ? 512 : wgrad_target_wgs(M)) + tiles - 1) / tiles;
     if (sp > stages / 8) sp = stages / 8;
     if (sp < 1) sp = 1;
     *sps = (int)((stages + sp - 1) / sp);
@@ -1182,7 +1200,7 @@ static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN
 static void wgrad3_plan(long M, int N, int Cs, long* splits, int* sps) {
     const long stages = M / 64;
     const int tiles = (N / 128) * (Cs / 128) * 3;
-    long sp = (wgrad_target_wgs() + tiles - 1) / tiles;
+    long sp = (wgrad3_target_wgs() + tiles - 1) / tiles;
     if (sp > stages / 8) sp = stages / 8;
     if (sp < 1) sp = 1;
     *sps = (int)((stages + sp - 1) / sp);
@@ -1262,14 +1280,22 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         g.stages_per_split = sps3;
         g.splits = (int)sp3;
         g.slab_elems = elems;
-        constexpr int NS = 3, lds = NS * W3_STAGE;   // 2 or 4 stages measured no different: the loop is compute-side bound
+        // 2 or 4 stages measured no different alone (the loop is compute-side bound); two stages = 80 KB, which can share a CU with a
+        // 72-KB convolution workgroup of the main stream (PPV_WGRAD3_NS)
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W3_STAGE);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE);
+            attr = true;
+        }
         const int log2W = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
         g.xcd_group = (g_wgrad_variant & 0x200) ? 1 : 0;         // XCD grouping measured slower here (111 vs 88 us, layer 3)
         const long t3 = (long)(N / 128) * (Cs / 128) * 3;
-        conv_wgrad3x3_kernel<NS><<<(unsigned)(g.xcd_group ? 8 * ((sp3 + 7) / 8) * t3 : sp3 * t3), 512, lds, stream>>>(
-            (const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
+        const unsigned grid3 = (unsigned)(g.xcd_group ? 8 * ((sp3 + 7) / 8) * t3 : sp3 * t3);
+        if (wgrad3_stages() == 2)
+            conv_wgrad3x3_kernel<2><<<grid3, 512, 2 * W3_STAGE, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
+        else
+            conv_wgrad3x3_kernel<3><<<grid3, 512, 3 * W3_STAGE, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
         wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
         return ppv_last_error();
     }

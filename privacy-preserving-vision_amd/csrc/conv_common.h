@@ -20,6 +20,7 @@ struct ConvGeom {
     int offw;            // tap offset of the columns (rectangular kernels: 1 x 5 / 5 x 1 of RAFT's SepConvGRU)
     int flat;            // 1x1, unit step, no offset, same grid: GEMM row m IS source pixel m (no (b, ho, wo) decomposition)
     long M;              // B * Ho * Wo
+    int chunked;         // layout experiment (flat launches, BK = 64): the source is [Cs / 64][M][64] instead of [M][Cs]
 };
 
 __device__ __forceinline__ bf16_t f2bf(float f) {

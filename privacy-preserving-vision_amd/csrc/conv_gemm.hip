@@ -303,6 +303,14 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     int a_inc[ASLOTS];
     auto retap = [&]() {
         if (g.flat) {
+            if (BK == 64 && g.chunked) {      // channel-chunked source [Cs / 64][M][64]: a K-step's 256 rows are ONE contiguous 32-KB block
+#pragma unroll
+                for (int i = 0; i < ASLOTS; ++i) {
+                    a_off[i] = (a_ok[i] ? (long)a_pix[i] * 128 : zdelta) + cch * 16;
+                    a_inc[i] = a_ok[i] ? (int)(g.M * 128) : 0;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < ASLOTS; ++i) {
                 a_off[i] = (a_ok[i] ? (long)a_pix[i] * g.Cs * 2 : zdelta) + cch * 16;
@@ -496,6 +504,11 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.a = a; g.off = off; g.offw = (g_conv_offw_override != INT_MIN) ? g_conv_offw_override : off; g.sh = (div == 2) ? 1 : 0;
     g.M = (long)B * Ho * Wo;
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
+    g.chunked = 0;
+    if (g_conv_variant & 0x1000) {            // layout A/B (tools/bench_layout_ab.py): flat launches on the BK = 64 tiles read a chunked source
+        if (!g.flat || g.M * 128 >= (1L << 31)) return PPV_ERR_BAD_SIZE;
+        g.chunked = 1;
+    }
     // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
     // (its f32 instantiation has no epilogue options: variant 8 leaves f32 launches with an addend / sums to the tiled kernels)
     if (((g_conv_variant == 0 && addend && !out_f32) || (g_conv_variant == 8 && (!out_f32 || (!addend && !red_x_ && !stat_part)))) &&
@@ -504,7 +517,9 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
                                      (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
                                      out_f32, stat_rows, stream);
     // 3x3 / stride 1 with the input tile resident in LDS (variant 9: wherever it can run; automatic: launches that fill the chip)
-    if ((g_conv_variant == 9 || (g_conv_variant == 0 && (g.M / 256) * (N / 128) >= 200)) && !out_f32 && conv3x3_halo_supported(g, Cs, div))
+    static const int halo_dgrad = getenv("PPV_HALO_DGRAD") ? atoi(getenv("PPV_HALO_DGRAD")) : 1;   // A/B: 0 = tiled kernels for the 3x3 data gradients
+    static const int no_v3 = getenv("PPV_CONV_NO_V3") ? atoi(getenv("PPV_CONV_NO_V3")) : 0;        // A/B: 1 = 72-KB BK32 tile instead of the 144-KB BK64 one (2: data gradients only)
+    if ((g_conv_variant == 9 || (g_conv_variant == 0 && (g.M / 256) * (N / 128) >= 200 && (halo_dgrad || !red_x_))) && !out_f32 && conv3x3_halo_supported(g, Cs, div))
         return conv3x3_halo_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
                                    (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
                                    stat_rows, stream);
@@ -544,8 +559,9 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages (BK 64),
     // 4 = 256 x 128 x 3 stages of BK 32, two workgroups per CU
     const int CUS = 256;
-    int v = g_conv_variant;
+    int v = g_conv_variant & 0xfff;
     if (v >= 7) v = 0;
+    if (g.chunked && v != 2 && v != 3) return PPV_ERR_BAD_SIZE;   // the experiment exists on the two BK = 64 tiles
     if (N != 16 && N % 128 && (v == 0 || v >= 3) && g.M >= 128 * 1024) {
         PPV_LAUNCH_PIPE_R(128, 64, 3, 32, 4);   // 64-column layers (layer1): HBM-bound, four small-ring workgroups per CU
         return ppv_last_error();
@@ -554,7 +570,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     if (v == 0) {                               // measured on the ResNet-101 shapes (tools/bench_conv.py, B = 128)
         const long t256 = ((g.M + 255) / 256) * (N / 128);
         if (t256 >= 2 * CUS) v = 4;             // several rounds of tiles: two workgroups per CU hide tile pro/epilogues
-        else if (t256 >= CUS) v = 3;            // one round: deepest prefetch per workgroup
+        else if (t256 >= CUS) v = (no_v3 == 1 || (no_v3 == 2 && rx)) ? 4 : 3;            // one round: deepest prefetch per workgroup
         else v = 2;                             // the 256-row tile only when it still fills the chip
     }
     if (rx && (v < 2 || v > 4)) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the three production tiles only

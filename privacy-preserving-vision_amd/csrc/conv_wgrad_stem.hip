@@ -45,6 +45,7 @@ struct WgradGeom {
     long slab_elems;       // > 0: slice z stores its tile plainly into dW + z * slab_elems (no atomics)
     int xcc_slabs;         // 1: every slice ADDS (f32 atomics) into the slab of the XCD it runs on (dW + XCC_ID * slab_elems, pre-zeroed)
     int pf_dist;           // cooperative L2 prefetch distance in 64-row stages (PF instantiations of conv_wgrad_pipe_kernel)
+    int chunked;           // layout experiment (1x1 / unit stride): G is [N / 128][M][128], X is [Cs / 128][M][128]
 };
 
 // 32-byte block swizzle key of a staged row (conflict-free ds_read_b64_tr_b16: see file header)
@@ -242,7 +243,8 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
             const int q = i * NW + wave, half = q >> 4, row = (q & 15) * 4 + rli;
             const long m = mb + row;
             const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
-            const long off = (m < m_end) ? (m * g.N + n0 + half * 128 + gch * 8) * 2 : zdG;
+            const long off = (m >= m_end) ? zdG : g.chunked ? (((long)(n0 / 128 + half) * g.M + m) * 128 + gch * 8) * 2
+                                                           : (m * g.N + n0 + half * 128 + gch * 8) * 2;
             GLDS16W(reinterpret_cast<const char*>(G) + off, sb + half * HALF + (q & 15) * 1024);
         }
 #pragma unroll
@@ -256,7 +258,8 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
             fast_divmod(rem, g.Wo, rcp_wo, ho, wo);
             const int hs = ho * g.st + r - g.pad, ws = wo * g.st + s - g.pad;
             const bool ok = (m < m_end) & ((unsigned)hs < (unsigned)g.Hs) & ((unsigned)ws < (unsigned)g.Ws);
-            const long off = ok ? ((((long)b * g.Hs + hs) * g.Ws + ws) * g.Cs + c0 + gch * 8) * 2 : zdX;
+            const long off = !ok ? zdX : g.chunked ? (((long)(c0 / 128) * g.M + m) * 128 + gch * 8) * 2
+                                                   : ((((long)b * g.Hs + hs) * g.Ws + ws) * g.Cs + c0 + gch * 8) * 2;
             GLDS16W(reinterpret_cast<const char*>(X) + off, sb + NH * HALF + q * 1024);
         }
         if constexpr (PF) {
@@ -1259,6 +1262,11 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     g.M = (long)B * Ho * Wo;
     g.xcc_slabs = 0;
     g.pf_dist = 0;
+    g.chunked = 0;
+    if (g_wgrad_variant & 0x1000) {                            // layout A/B (tools/bench_layout_ab.py): chunked operands, 1x1 / unit stride only
+        if (R * S != 1 || stride != 1) return PPV_ERR_BAD_SIZE;
+        g.chunked = 1;
+    }
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;            // fast_divmod range
     int variant = g_wgrad_variant & 0xff;
     g.xcd_group = (g_wgrad_variant & 0x100) ? 0 : 1;
@@ -1390,7 +1398,7 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
     g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1; g.st = 1; g.pad = 0;
     g.M = (long)B * H * W;
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;
-    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0; g.pf_dist = 0;
+    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0; g.pf_dist = 0; g.chunked = 0;
     WgradGroupPtrs ptrs;
     for (int p = 0; p < 24; ++p) {
         const int q = p < P ? p : 0;

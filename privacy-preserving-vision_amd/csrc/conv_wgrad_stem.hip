@@ -46,6 +46,8 @@ struct WgradGeom {
     int xcc_slabs;         // 1: every slice ADDS (f32 atomics) into the slab of the XCD it runs on (dW + XCC_ID * slab_elems, pre-zeroed)
     int pf_dist;           // cooperative L2 prefetch distance in 64-row stages (PF instantiations of conv_wgrad_pipe_kernel)
     int chunked;           // layout experiment (1x1 / unit stride): G is [N / 128][M][128], X is [Cs / 128][M][128]
+    int native_slabs;      // 1: slabs are written in the accumulators' own order (one 16-byte store per lane and MFMA tile, whole 1-KB
+                           //    wave stores) and wgrad_reduce_native_kernel sums + scatters them; 0: [N][R][S][C] slabs (wgrad_to_torch_kernel)
 };
 
 // 32-byte block swizzle key of a staged row (conflict-free ds_read_b64_tr_b16: see file header)
@@ -212,7 +214,7 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt_le() { asm volati
 template <int TN, int NSTAGE, bool PF = false>
 __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X, float* __restrict__ dst,
                                                 const bf16_t* __restrict__ zero_page, const WgradGeom& g, long m_begin, long m_end,
-                                                int n0, int tap, int c0, bool atomic) {
+                                                int n0, int tap, int c0, bool atomic, int tile_id = 0) {
     constexpr int NT = TN * 2, NW = NT / 64, NH = TN / 128;               // threads, waves, 128-column halves of G
     constexpr int HALF = 64 * 256;                                        // one [64][128] bf16 tile
     constexpr int STAGE_BYTES = (NH + 1) * HALF;
@@ -346,6 +348,17 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
         wg_wait_vmcnt_le<0>();
         asm volatile("" ::"v"(pf_sink));
     }
+    if (g.native_slabs && !atomic) {
+        // slab in accumulator order: record ((tile * NW + wave) * 16 + mi * 4 + ni) * 64 + lane = the lane's four rows (j) of MFMA tile
+        // (mi, ni): 16 stores of 16 bytes per lane, each wave store one contiguous KB (the [N][R][S][C] form: 64 stores of 4 bytes
+        // in 64-byte runs); wgrad_reduce_native_kernel knows the same map
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst) + ((long)(tile_id * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) d4[(mi * 4 + ni) * 64] = acc[mi][ni];
+        return;
+    }
     const int fr = lane & 15, fq = lane >> 4;
     const long wrow = (long)g.R * g.S * g.Cs;
 #pragma unroll
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
         wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)xcc * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, true);
         return;
     }
-    wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0);
+    wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0, tl);
 }
 
 // Several weight gradients of ONE shape (1x1, unit stride: the conv1 / conv3 of a layer's bottlenecks) in one launch, each reduced
@@ -780,6 +793,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const bf16_t* __r
     const int fr = lane & 15, fq = lane >> 4;
     const long wrow = 9L * g.Cs;
     float* dst = dW + (long)zslice * g.slab_elems;
+    if (g.native_slabs) {                                      // accumulator-order slab (see wgrad_pipe_body): 24 records per lane
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst) + ((long)(tl * 8 + wave) * 24) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) d4[(s * 8 + mi * 2 + ni) * 64] = acc[s][mi][ni];
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -804,6 +827,54 @@ __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __rest
     float a = 0.f;
     for (int k = 0; k < nslab; ++k) a += dW[(long)k * tot + i];
     out[(((long)n * C + c) * R + r) * S + s] = a;
+}
+
+// sum of nslab accumulator-order slabs (native_slabs) -> torch [N][C][R][S] f32.  One thread per 16-byte record (a lane's four rows
+// of one 16 x 16 MFMA tile): nslab coalesced 16-byte loads, eight in flight, then four 4-byte stores (16 lanes = 64 contiguous bytes
+// of one output row for 1x1 weights).  MODE 0: conv_wgrad_pipe_kernel<TN> tiles (NW = TN / 32 waves, 16 records per wave and lane, one
+// tap per tile); MODE 1: conv_wgrad3x3_kernel tiles (8 waves, 24 records: three taps of kernel row r).
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_native_kernel(const float* __restrict__ slabs, float* __restrict__ out, int N, int C,
+                                                                  int R, int S, int nslab, int TN) {
+    const long rec = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot4 = (long)N * C * R * S / 4;
+    if (rec >= tot4) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + rec;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * tot4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; k < nslab; ++k) a += p[(long)k * tot4];
+    const int lane = (int)(rec & 63), fr = lane & 15, fq = lane >> 4;
+    int n, c, tap;
+    if (MODE == 0) {
+        const int NW = TN / 32;
+        const int t = (int)((rec >> 6) & 15), wave = (int)((rec >> 10) % NW), tl = (int)((rec >> 10) / NW);
+        const int mi = t >> 2, ni = t & 3, wm = wave >> 1, wn = wave & 1;
+        const int ntn = N / TN, ctiles = C / 128;
+        const int n0 = (tl % ntn) * TN, by = tl / ntn;
+        tap = by / ctiles;
+        n = n0 + wm * 64 + mi * 16 + fq * 4;
+        c = (by % ctiles) * 128 + wn * 64 + ni * 16 + fr;
+    } else {
+        const long q = rec >> 6;
+        const int t = (int)(q % 24), wave = (int)((q / 24) & 7), tl = (int)(q / 192);
+        const int s3 = t >> 3, mi = (t >> 1) & 3, ni = t & 1, wn = wave >> 2, wc = wave & 3;
+        const int ntiles = N / 128, ctiles = C / 128;
+        const int n0 = (tl % ntiles) * 128, by = tl / ntiles;
+        tap = (by / ctiles) * 3 + s3;
+        n = n0 + wn * 64 + mi * 16 + fq * 4;
+        c = (by % ctiles) * 128 + wc * 32 + ni * 16 + fr;
+    }
+    const long RS = (long)R * S;
+    float* o = out + ((long)n * C + c) * RS + tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[(long)j * C * RS] = a[j];
 }
 
 // ============================================================================= stem forward
@@ -1181,6 +1252,11 @@ static int wgrad3_target_wgs() {
     static const int t = getenv("PPV_WGRAD3_WGS") ? atoi(getenv("PPV_WGRAD3_WGS")) : 144;
     return t < 12 ? 12 : t;
 }
+// slabs in accumulator order + wgrad_reduce_native_kernel (PPV_WGRAD_NATIVE=0: the [N][R][S][C] slabs of rounds 1-2)
+static int wgrad_native_slabs() {
+    static const int t = getenv("PPV_WGRAD_NATIVE") ? atoi(getenv("PPV_WGRAD_NATIVE")) : 1;
+    return t ? 1 : 0;
+}
 static int wgrad3_stages() {
     static const int t = getenv("PPV_WGRAD3_NS") ? atoi(getenv("PPV_WGRAD3_NS")) : 3;
     return t == 2 ? 2 : 3;
@@ -1263,6 +1339,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     g.xcc_slabs = 0;
     g.pf_dist = 0;
     g.chunked = 0;
+    g.native_slabs = 0;
     if (g_wgrad_variant & 0x1000) {                            // layout A/B (tools/bench_layout_ab.py): chunked operands, 1x1 / unit stride only
         if (R * S != 1 || stride != 1) return PPV_ERR_BAD_SIZE;
         g.chunked = 1;
@@ -1297,6 +1374,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
             attr = true;
         }
         const int log2W = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
+        g.native_slabs = wgrad_native_slabs();
         g.xcd_group = (g_wgrad_variant & 0x200) ? 1 : 0;         // XCD grouping measured slower here (111 vs 88 us, layer 3)
         const long t3 = (long)(N / 128) * (Cs / 128) * 3;
         const unsigned grid3 = (unsigned)(g.xcd_group ? 8 * ((sp3 + 7) / 8) * t3 : sp3 * t3);
@@ -1304,7 +1382,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
             conv_wgrad3x3_kernel<2><<<grid3, 512, 2 * W3_STAGE, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
         else
             conv_wgrad3x3_kernel<3><<<grid3, 512, 3 * W3_STAGE, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
-        wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
+        if (g.native_slabs) wgrad_reduce_native_kernel<1><<<(unsigned)((elems / 4 + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3, 128);
+        else wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
         return ppv_last_error();
     }
     if ((g_wgrad_variant & 0xff) == 7) {   // streamed kernel: loader / consumer waves, deep ring (opt-in: see its header comment)
@@ -1350,6 +1429,7 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
     }
     g.slab_elems = elems;
     int nslab = (int)splits;
+    g.native_slabs = (wgrad_native_slabs() && !((g_wgrad_variant & 0x400) && splits > 8)) ? 1 : 0;
     if ((g_wgrad_variant & 0x400) && splits > 8) {             // XCC-local atomic slabs (see conv_wgrad_pipe_kernel): 8 pre-zeroed slabs
         g.xcc_slabs = 1;
         nslab = 8;
@@ -1384,7 +1464,8 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
         conv_wgrad_pipe_kernel<128, 4><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     }
-    wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab);
+    if (g.native_slabs) wgrad_reduce_native_kernel<0><<<(unsigned)((elems / 4 + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab, TN);
+    else wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab);
     return ppv_last_error();
 }
 
@@ -1398,7 +1479,7 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
     g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1; g.st = 1; g.pad = 0;
     g.M = (long)B * H * W;
     if (g.M >= (1L << 24)) return PPV_ERR_BAD_SIZE;
-    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0; g.pf_dist = 0; g.chunked = 0;
+    g.stages_per_split = (int)((g.M + 63) / 64); g.splits = 1; g.xcd_group = 1; g.slab_elems = (long)N * Cs; g.xcc_slabs = 0; g.pf_dist = 0; g.chunked = 0; g.native_slabs = 0;
     WgradGroupPtrs ptrs;
     for (int p = 0; p < 24; ++p) {
         const int q = p < P ? p : 0;

@@ -400,7 +400,27 @@ class _TrunkFn(torch.autograd.Function):
                 for w, dw in zip(ws, co.conv_wgrad_group(gs, xs, dsts)):
                     deliver(w, dw)
 
-        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None, sums2=None):
+        # Where a block's three weight gradients are ENQUEUED on the side stream (their event is recorded at that point of the main
+        # stream): point 0 = after bn3's backward apply, 1 = after conv3's data gradient, 2 = after bn2's apply, 3 = after conv2's data
+        # gradient, 4 = after bn1's apply, 5 = after conv1's data gradient.  PPV_WGRAD_SCHED = three digits for (conv3, conv2, conv1);
+        # "024" launches each as soon as its operand exists (rounds 1-2).
+        wsched = [int(ch, 16) for ch in _os.environ.get("PPV_WGRAD_SCHED", "024")]   # hex digits: 6..b = the next block's points
+        wsched = [max(wsched[0], 0), max(wsched[1], 2), max(wsched[2], 4)]
+        cur_point = [0]
+        deferred = []
+
+        def at_point(k):
+            cur_point[0] = k
+            if deferred:
+                keep = []
+                for pt, fn in deferred:
+                    if pt <= k:
+                        fn()
+                    else:
+                        keep.append((pt, fn))
+                deferred[:] = keep
+
+        def conv_bn_bwd(rec, gy, y, xraw, coef, xin, relu, want_gpre=False, sums=None, sums2=None, wslot=None):
             trainable = rec.conv.weight.requires_grad
             affine = rec.bn.weight.requires_grad
             oa = (sync.grad_view(rec.bn.weight).view(-1), sync.grad_view(rec.bn.bias).view(-1)) if (bucketed and affine) else None
@@ -418,33 +438,40 @@ class _TrunkFn(torch.autograd.Function):
             elif trainable:
                 w = rec.conv.weight
                 dst = sync.grad_view(w) if bucketed else None
-                if side is not None and bucketed and co.PROFILE is None:
-                    # data-parallel fast path: the kernel writes the bucket slice on the side stream (launched there by pointer), the
-                    # bucket's all-reduce waits for an event recorded on that stream
-                    ev = torch.cuda.Event(); ev.record(main_stream)
-                    side.wait_event(ev)
-                    co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst, stream=side)
-                    gx.record_stream(side); xin.record_stream(side)
-                    w.grad = dst
-                    sync.mark_ready(w, stream=side)
-                elif side is not None and sync is None and co.PROFILE is None:
-                    # single-process fast path: the launch goes to the side stream by pointer (the stream context manager and the
-                    # current-stream look-ups cost the host ~25 us per weight gradient, 93 per step)
-                    ev = torch.cuda.Event(); ev.record(main_stream)
-                    side.wait_event(ev)
-                    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)     # caching allocator: owned by the CURRENT stream ...
-                    co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dw, stream=side)
-                    gx.record_stream(side); xin.record_stream(side); dw.record_stream(side)   # ... so its reuse waits for the side stream
-                    deliver(w, dw)
-                elif side is not None:
-                    ev = torch.cuda.Event(); ev.record()
-                    with torch.cuda.stream(side):
+
+                def launch_w(rec=rec, gx=gx, xin=xin, w=w, dst=dst):
+                    if side is not None and bucketed and co.PROFILE is None:
+                        # data-parallel fast path: the kernel writes the bucket slice on the side stream (launched there by pointer), the
+                        # bucket's all-reduce waits for an event recorded on that stream
+                        ev = torch.cuda.Event(); ev.record(main_stream)
                         side.wait_event(ev)
-                        dw = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst)
+                        co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst, stream=side)
                         gx.record_stream(side); xin.record_stream(side)
+                        w.grad = dst
+                        sync.mark_ready(w, stream=side)
+                    elif side is not None and sync is None and co.PROFILE is None:
+                        # single-process fast path: the launch goes to the side stream by pointer (the stream context manager and the
+                        # current-stream look-ups cost the host ~25 us per weight gradient, 93 per step)
+                        ev = torch.cuda.Event(); ev.record(main_stream)
+                        side.wait_event(ev)
+                        dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)     # caching allocator: owned by the CURRENT stream ...
+                        co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dw, stream=side)
+                        gx.record_stream(side); xin.record_stream(side); dw.record_stream(side)   # ... so its reuse waits for the side stream
                         deliver(w, dw)
+                    elif side is not None:
+                        ev = torch.cuda.Event(); ev.record()
+                        with torch.cuda.stream(side):
+                            side.wait_event(ev)
+                            dw = co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst)
+                            gx.record_stream(side); xin.record_stream(side)
+                            deliver(w, dw)
+                    else:
+                        deliver(w, co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst))
+                slot = {3: 0, 2: 1, 1: 2}.get(wslot, None)
+                if slot is None or wsched[slot] <= cur_point[0]:
+                    launch_w()
                 else:
-                    deliver(w, co.conv_wgrad(gx, xin, rec.k, rec.k, rec.stride, rec.pad, scratch=wscratch, out=dst))
+                    deferred.append((wsched[slot], launch_w))
             if affine:
                 deliver(rec.bn.weight, dg)
                 deliver(rec.bn.bias, db)
@@ -475,7 +502,9 @@ class _TrunkFn(torch.autograd.Function):
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
             # a down-sampling block's projection BatchNorm sees the same gradient as bn3: bn3's apply pass takes its sums too
             sumsd = bn_part(xd.shape[-1]) if (fuse_proj and rd is not None) else None
-            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0, sums=sums3, sums2=None if sumsd is None else (xd, sumsd))
+            deferred[:] = [(pt - 6, fn) for pt, fn in deferred]    # points 6..11 of a block = points 0..5 of the next one
+            at_point(0)
+            gx3, _ = conv_bn_bwd(r3, g, None, x3, c3, y2, 0, sums=sums3, sums2=None if sumsd is None else (xd, sumsd), wslot=3)
             red = sums3 = None
             if fuse_red and bi + 1 < len(order):
                 x3_prev = order[bi + 1][1][7]                # raw conv3 output of the block this gradient flows into
@@ -487,29 +516,35 @@ class _TrunkFn(torch.autograd.Function):
             if fuse_red12 and co.red_supported(x2.numel() // x2.shape[-1], x2.shape[-1]):
                 s2 = bn_part(x2.shape[-1])
                 gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid, red=(x2, s2, c2))
-                gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 0, sums=s2)
+                at_point(1); at_point(2)
+                gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 0, sums=s2, wslot=2)
             else:
                 gy2 = co.conv_dgrad(gx3, r3.wd(tok), 1, 0, hw_mid)
-                gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2)   # mask recomputed from x2 (no residual): y2 not read
+                at_point(1); at_point(2)
+                gx2, _ = conv_bn_bwd(r2, gy2, None, x2, c2, y1, 2, wslot=2)   # mask recomputed from x2 (no residual): y2 not read
             if fuse_red12 and co.red_supported(x1.numel() // x1.shape[-1], x1.shape[-1]):
                 s1 = bn_part(x1.shape[-1])
                 gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in, red=(x1, s1, c1))
-                gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 0, sums=s1)
+                at_point(3); at_point(4)
+                gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 0, sums=s1, wslot=1)
             else:
                 gy1 = co.conv_dgrad(gx2, r2.wd(tok), r2.stride, 1, hw_in)
-                gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2)
+                at_point(3); at_point(4)
+                gx1, _ = conv_bn_bwd(r1, gy1, None, x1, c1, xin, 2, wslot=1)
             if rd is not None:
                 gxd, _ = conv_bn_bwd(rd, g, None, xd, cd, xin, 0, sums=sumsd)
                 gin = co.conv_dgrad(gxd, rd.wd(tok), rd.stride, 0, hw_in)
                 g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=gin, relu_bits=xin_bits, red=red)
             else:
                 g = co.conv_dgrad(gx1, r1.wd(tok), 1, 0, hw_in, addend=g, relu_bits=xin_bits, red=red)
+            at_point(5)
             if taps is not None:
                 taps.append((g_blk_out, g))
         g_img = None
         needs_img = ctx.needs_input_grad[1]
         for k_ in list(pending):
             flush_group(k_)
+        at_point(1 << 30)                                     # whatever is still deferred
         if needs_img or enc._stem.bn.weight.requires_grad or enc._stem.conv.weight.requires_grad:
             raw0, c0, y0, arg0 = ctx.saved["stem"]
             gpre0 = co.maxpool_relu_bwd(g, y0, arg0, (raw0.shape[1], raw0.shape[2]))

@@ -11,6 +11,7 @@
 // Fields are planar per wavelength [L][RR][RR] double2.  The FFT length M = RR + 2*(RR/4)
 // (1344 = 2^6*3*7 for RR = 896) is kept (padding to 2048 would change the physics); radices 2,3,4,7 as butterflies, 5,11,13,23 by direct summation.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ppv_common.h"
 
 namespace ppv {
@@ -327,6 +328,51 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
     }
 }
 
+// One column per workgroup (round 3).  dfft_cols_kernel holds two columns + the twiddle table in 107.5 KB of LDS: one 512-thread
+// workgroup per CU walking ten barrier-separated FFT stages of ~1.3 butterflies per thread -- latency-bound (2 x 150 us per step at
+// 1 TB/s).  Here a workgroup owns ONE column (256 threads, 43 KB: ping-pong buffers only) and reads the twiddles from the 21.5-KB
+// global table (L1 / L2 resident), so three workgroups share a CU and cover each other's barriers and load latencies; the eight
+// workgroups of an 8-column block (one 128-byte line per row) run on one XCD.
+template <bool TW_LDS>
+__global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restrict__ T1, double2* __restrict__ T2,
+                                                         const float2* __restrict__ Ht, const double2* __restrict__ twg, FftPlan pl,
+                                                         int RR, int pad, int conj_h, double scale) {
+    __shared__ double2 s_tw[TW_LDS ? MAXM : 1];
+    __shared__ double2 s_a[MAXM];
+    __shared__ double2 s_b[MAXM];
+    const int tid = threadIdx.x, M = pl.M;
+    int pb = blockIdx.x;
+    if (gridDim.x % 64 == 0) {                       // blocks b, b + 8, ... share an XCD: give it the 8 columns of one 128-byte block
+        const int xcd = pb & 7, idx = pb >> 3;
+        pb = (idx >> 3) * 64 + xcd * 8 + (idx & 7);
+    }
+    const int l = blockIdx.y, kx = pb;
+    const int CB = (M % 8 == 0) ? 8 : 2;
+    if (TW_LDS)
+        for (int i = tid; i < M; i += 256) s_tw[i] = twg[i];
+    for (int i = tid; i < M; i += 256) {
+        const int y = i - pad;
+        s_a[i] = (y >= 0 && y < RR) ? T1[tix(l, y, kx, RR, M, CB)] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const double2* tw = TW_LDS ? s_tw : twg;
+    double2* r = dfft(s_a, s_b, tw, pl, tid, 256);
+    double2* o = (r == s_a) ? s_b : s_a;
+    const float2* hcol = Ht + ((long)l * M + kx) * M;
+    for (int i = tid; i < M; i += 256) {
+        const float2 hf = hcol[i];
+        const double2 hv = make_double2((double)hf.x, conj_h ? -(double)hf.y : (double)hf.y);
+        const double2 v = dmul(r[i], hv);
+        r[i] = make_double2(v.x, -v.y);                  // conj for the inverse transform
+    }
+    __syncthreads();
+    const double2* z = dfft(r, o, tw, pl, tid, 256);
+    for (int i = tid; i < RR; i += 256) {
+        const double2 a = z[i + pad];
+        T2[tix(l, i, kx, RR, M, CB)] = make_double2(a.x * scale, -a.y * scale);
+    }
+}
+
 // inverse rows: T2 [L][RR][M] -> crop columns pad..pad+RR-1 -> U [L][RR][RR] (c128), optional intensity f32
 __global__ __launch_bounds__(256) void difft_rows_kernel(const double2* __restrict__ T2, double2* __restrict__ U,
                                                          float* __restrict__ I32, const double2* __restrict__ twg,
@@ -555,6 +601,16 @@ size_t ppv_ic_psf_state_bytes(int RR, int P, int K) {
     return carve(&w, nullptr, RR, P, K);
 }
 
+// column pass of the Fresnel transform: PPV_DFFT_COLS = 0 two columns per workgroup (rounds 1-2), 1 one column + twiddles in LDS (two
+// workgroups per CU), 2 one column, twiddles from L2 (three per CU)
+static void launch_dfft_cols(const double2* T1, double2* T2, const float2* Ht, const double2* tw, const FftPlan& pl, int RR, int pad, int M,
+                             int conj_h, double scale, hipStream_t stream) {
+    static const int mode = getenv("PPV_DFFT_COLS") ? atoi(getenv("PPV_DFFT_COLS")) : 2;
+    if (mode == 1) dfft_cols1_kernel<true><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
+    else if (mode == 2) dfft_cols1_kernel<false><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
+    else dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
+}
+
 // Forward PSF generation (Lens.py:158-274).
 //   Z [K][RR][RR] f32, coeffs [K] f32, noise [RR*RR] f32 U[0,1) (may be null when tol < 0),
 //   sph [RR][RR][3] c64 (Lens.py:191-210, cached constant), Ht [3][M][M] c64 = Fresnel transfer function transposed
@@ -580,8 +636,7 @@ int ppv_ic_psf_fwd(const float* Z, const float* coeffs, const float* noise, cons
     ic_field_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.h, noise, (const float2*)sph, w.F0, RR, kdn[0],
                                                                      kdn[1], kdn[2], tol, (tol >= 0.f && noise) ? 1 : 0);
     dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
-    dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, 0,
-                                                        1.0 / ((double)M * (double)M));
+    launch_dfft_cols(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, M, 0, 1.0 / ((double)M * (double)M), stream);
     difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
     area_down_kernel<<<(unsigned)(((long)P * P + 255) / 256), 256, 0, stream>>>(w.I32, w.raw, w.sums, RR, P, up, up_scale);
     const long n = (long)P * P * 3;
@@ -614,8 +669,7 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
     area_down_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.g_n, dots, w.sums, w.U, GU, RR, P, up, up_scale);
     dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
     // cols: T1 -> T2 would overwrite GU while reading T1 only: fine (GU no longer needed)
-    dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, 1,
-                                                        1.0 / ((double)M * (double)M));
+    launch_dfft_cols(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, M, 1, 1.0 / ((double)M * (double)M), stream);
     double2* GF = w.T1;                                            // T1 dead again
     difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
     ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);

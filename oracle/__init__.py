@@ -22,6 +22,13 @@ Parity pin status
   fixture stores a basis or a mask); the golden generator feeds the reference
   the oracle's own basis / Euclidean disk (``oracle/zernike.py``), and the
   reference itself treats the basis as a cached ``.npy`` input.
-* ``Encoder`` (torchvision ResNet-101): torchvision is absent, *parity
-  unpinned* against torchvision; oracle = ``torch.nn`` restatement on CPU fp32.
+* ``Encoder`` (``Image_Caption/models.py:8-54``): PINNED since round 3 against
+  ``tests/golden/encoder.npz`` = the reference's own ``models.Encoder`` class run on CPU
+  in train mode (``make_golden.py encoder``: output, trainable set, key / parameter order,
+  input gradient, parameter gradients, running statistics).  torchvision itself is absent:
+  the stand-in registered for ``torchvision.models.resnet101`` is assembled from
+  ``oracle/resnet.py``'s pieces in torchvision's child order, and that restatement is
+  cross-checked against the independent ResNet-101 v1.5 of ``transformers``
+  (``tests/test_oracle_trunk_pin.py``).  torchvision's own source and pretrained weights
+  stay *unpinned* (absent offline).
 """

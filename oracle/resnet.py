@@ -2,7 +2,9 @@
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates reference Image_Caption/models.py:8-54 (Encoder) with the
 public torchvision ResNet-101 architecture (v1.5 Bottleneck: stride on the 3x3; layers [3,4,23,3]).
-torchvision itself is absent here -> parity unpinned against torchvision, pinned against torch.nn on CPU.
+torchvision itself is absent here; PINNED (round 3) against tests/golden/encoder.npz = the reference's own models.Encoder class run
+on CPU over a stand-in ``torchvision.models.resnet101`` assembled from this file's pieces (tests/test_oracle_encoder_golden.py), and
+cross-checked against the independent ResNet-101 v1.5 of ``transformers`` (tests/test_oracle_trunk_pin.py).
 ``round_bf16=True`` rounds the conv outputs and the activations to bfloat16 at the same points the MI355X trunk
 stores them, so the comparison isolates kernel arithmetic from the storage format.
 """

@@ -77,6 +77,9 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
                    const float* psf_n, const double* g_psf_m, const float* g_psf_n, const double* g_loss,
                    const double* loss, float* g_coeffs, void* state, int RR, int P, int K, int up, float up_scale,
                    ppv_stream_t stream);
+/* Optional, once per (state, Z): marks the support of the basis inside `state` so that the two calls above skip the pixel groups
+ * where every plane of Z is zero (outside the aperture disk of poppy.zernike_basis(outside=0), Utils.py:75-77; exact). */
+int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, ppv_stream_t stream);
 int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0, size_t* off_U, size_t* off_I32,
                              size_t* off_raw);
 

@@ -250,6 +250,10 @@ class OpticsZernike(nn.Module):
             check(L.ppv_init(), "ppv_init")
         self._state = torch.empty(L.ppv_ic_psf_state_bytes(RR, P, K), dtype=torch.uint8, device=self.device)
         self._state_token = 0
+        # the basis is zero outside the aperture disk (poppy zernike_basis(outside=0), Utils.py:75-77): mark its support once so the two
+        # 1.12-GB passes over it skip those pixels (exact; derived from the DATA, so a user-supplied volume is handled too)
+        with torch.cuda.device(self.device):
+            check(L.ppv_ic_psf_mark_support(ptr(self.zernike_volume), ptr(self._state), RR, P, K, stream_ptr()), "ppv_ic_psf_mark_support")
 
     # ------------------------------------------------------------------ parameters / checkpoints
     def _make_params(self, full):

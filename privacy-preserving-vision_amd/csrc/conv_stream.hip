@@ -22,6 +22,7 @@
 //     MFMAs per step beside 64.  (Element-wise statistics took 8-12 VALU instructions per output element and made the first
 //     version of this kernel VALU-bound at 3.2 us per step; the HBM-bound step is 1.4 us.)
 // Loaders never store and consumers never issue LDS-DMA, so neither's s_waitcnt vmcnt queue holds the other's operations.
+#include <cstdlib>
 #include "conv_common.h"
 
 namespace ppv {
@@ -356,8 +357,9 @@ static int stream_launch_k(const bf16_t* X, const bf16_t* Wt, void* out, float* 
                            int out_f32, int stat_rows, hipStream_t stream) {
     const int tiles_m = (int)((g.M + 255) / 256), steps = g.N / 64;
     // enough workgroups for every CU; a row tile's channel range is cut at most 8 ways (each slice re-reads the pixel rows)
+    static const int wg_target = getenv("PPV_STREAM_WGS") ? atoi(getenv("PPV_STREAM_WGS")) : 256;   // A/B: finer slices flow around blocked CUs
     int n_splits = 1;
-    while (n_splits < 8 && tiles_m * n_splits < 256 && steps % (n_splits * 2) == 0 && steps / (n_splits * 2) >= 2) n_splits *= 2;
+    while (n_splits < 8 && tiles_m * n_splits < wg_target && steps % (n_splits * 2) == 0 && steps / (n_splits * 2) >= 2) n_splits *= 2;
     const int nspan = g.N / n_splits;
     const int lds = ST_NSLOT * 64 * KC * 2 + ST_NCW * 16 * 272 + 2 * nspan * 4 + 64;
     typedef void (*kern_t)(const bf16_t*, const bf16_t*, void*, float*, const bf16_t*, const unsigned char*, ConvGeom, int, int, int,

@@ -164,6 +164,14 @@ int ppv_bn_finalize(const float* part, int T, double count, const float* gamma, 
 int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* coef2, void* y, void* pos_bits, long n, int C,
                int res_mode, int relu, long res_mod, ppv_stream_t stream);
 
+/* torch BatchNorm2d(training) + ReLU (+ identity add) of torchvision's Bottleneck (Image_Caption/models.py:17-21, train.py:245) with the
+ * statistics in ONE row sums [2][C] (ppv_conv_gemm with stat_rows = 1): every thread derives scale / shift of its eight channels
+ * itself (no ppv_bn_finalize launch); coef [4][C] (scale, shift, mean, invstd) and the running statistics (momentum, unbiased
+ * variance; run_mean / run_var may be NULL) are written by the threads of the first row.  res_mode 0: none, 1: identity r. */
+int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
+                    int res_mode, int relu, ppv_stream_t stream);
+
 /* Train-mode BatchNorm in ONE launch: partial statistics [T][2][C] (as ppv_conv_gemm leaves them) -> per-channel coefficients (written
  * to coef [4][C] = scale, shift, mean, invstd for the backward pass; running statistics updated with `momentum`, unbiased variance)
  * -> y = act(x * scale + shift (+ residual)).  res_mode 0: none, 1: identity r, 2: r normalised by its own BatchNorm (the *2

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "ppv_stem_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ppv_bn_finalize": (_I, [_P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P]),
+    "ppv_bn_act_fold": (_I, [_P, _P, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_act_train": (_I, [_P, _P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_bwd_blocks": (_I, [_L, _I]),
     "ppv_bn_bwd": (_I, [_P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

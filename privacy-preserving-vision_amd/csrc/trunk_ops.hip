@@ -108,6 +108,60 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// ----------------------------------------------------------------------------- BN apply with the coefficients derived per thread (round 3)
+// The convolution leaves its statistics in ONE row (stat_rows = 1: every tile adds its column sums to the same [2][C] floats), so the
+// element-wise apply kernel can derive scale / shift for ITS eight channels from 16 floats + gamma / beta in a few instructions and
+// the 4.7-us bn_finalize launch between every convolution and its apply pass (104 per step, pure dispatch latency) disappears.  The
+// threads of the first row also write coef [4][C] (scale, shift, mean, invstd: what the backward pass reads) and the running
+// statistics.  Totals in f32 as bn_finalize reads them, mean / variance in double, f32 rsq + one Newton step (<= 1 ulp of the f64 one).
+// (ppv_bn_act_train, round 2, folded 32 partial rows per workgroup in a looped kernel and was slower than the two launches.)
+// MEASURED in the step (encoder.py PPV_BN_FOLD_ACT=1): 1.3 % SLOWER than bn_finalize + bn_act (5217 vs 5285 images/s): kept opt-in.
+template <int RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_act_fold_kernel(const bf16_t* __restrict__ x, const float* __restrict__ sums, double inv_count,
+                                                          double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                          float eps, float* __restrict__ coef, const bf16_t* __restrict__ r,
+                                                          bf16_t* __restrict__ y, unsigned char* __restrict__ pos_bits, long n8, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int c0 = (int)((i * 8) % C);
+    float xv[8], rv[8], o[8];
+    load8(x + i * 8, xv);
+    if (RES) load8(r + i * 8, rv);
+    const float4 sa = *reinterpret_cast<const float4*>(sums + c0), sb = *reinterpret_cast<const float4*>(sums + c0 + 4);
+    const float4 qa = *reinterpret_cast<const float4*>(sums + C + c0), qb = *reinterpret_cast<const float4*>(sums + C + c0 + 4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), gb = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 ba = *reinterpret_cast<const float4*>(beta + c0), bb = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    const float s_[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w}, q_[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const float g_[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, b_[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+    const bool writer = i * 8 < C;                     // the first row's threads publish the coefficients of their channels
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double mean = (double)s_[k] * inv_count;
+        double var = (double)q_[k] * inv_count - mean * mean;
+        if (var < 0) var = 0;
+        const float ve = (float)(var + (double)eps);
+        float invstd = __builtin_amdgcn_rsqf(ve);
+        invstd = invstd * (1.5f - 0.5f * ve * invstd * invstd);
+        const float sc = g_[k] * invstd, sh = b_[k] - (float)mean * sc;
+        if (writer) {
+            const int c = c0 + k;
+            coef[c] = sc; coef[C + c] = sh; coef[2 * C + c] = (float)mean; coef[3 * C + c] = invstd;
+            if (run_mean) {
+                run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+                run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * unbias);
+            }
+        }
+        float v = xv[k] * sc + sh;
+        if (RES == 1) v += rv[k];
+        o[k] = RELU ? fmaxf(v, 0.f) : v;
+        bits |= (o[k] > 0.f ? 1u : 0u) << k;
+    }
+    store8(y + i * 8, o);
+    if (pos_bits) pos_bits[i] = (unsigned char)bits;
+}
+
 // ----------------------------------------------------------------------------- train-mode BN: statistics -> coefficients -> apply, one launch
 // bn_finalize + bn_act in one kernel (round 2): the coefficient launch was 4.8 us of dispatch latency per BatchNorm for ~1 us of
 // work (104 launches per step, tools/micro/graph_chain.py: a dependent tiny kernel costs 4.2 us).  A workgroup owns a block of
@@ -606,6 +660,27 @@ int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* co
 // its own BatchNorm (part2 ... coef2: the projection shortcut's).  Replaces ppv_bn_finalize + ppv_bn_act (reference:
 // torch BatchNorm2d in training mode + ReLU (+ residual add) of torchvision's Bottleneck, Image_Caption/models.py:17-21, train.py:245).
 // C % 64 == 0 (C <= 256) or C % 256 == 0; rows * C < 2^31 * 8.
+// y = act(BatchNorm_train(x) (+ r)) with the statistics in ONE row sums [2][C] (sum, sum of squares of the stored conv output, as
+// ppv_conv_gemm leaves them with stat_rows = 1): coefficients derived per thread, coef [4][C] and the running statistics written
+// by the first row's threads.  res_mode 0 none, 1 identity residual r.  pos_bits as ppv_bn_act.  C % 8 == 0, rows * C % 8 == 0.
+int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
+                    int res_mode, int relu, hipStream_t stream) {
+    if (!x || !sums || !gamma || !beta || !coef || !y || (res_mode == 1 && !r)) return PPV_ERR_NULL;
+    if (C % 8 || n % 8 || res_mode < 0 || res_mode > 1 || count < 1 || (run_mean && !run_var)) return PPV_ERR_BAD_SIZE;
+    const long n8 = n / 8;
+    const unsigned gb = (unsigned)((n8 + 255) / 256);
+    const double inv = 1.0 / count, unb = count > 1 ? count / (count - 1.0) : 1.0;
+#define PPV_FOLD(RES_, RELU_) bn_act_fold_kernel<RES_, RELU_><<<gb, 256, 0, stream>>>((const bf16_t*)x, sums, inv, unb, gamma, beta, run_mean, run_var, \
+        momentum, eps, coef, (const bf16_t*)r, (bf16_t*)y, (unsigned char*)pos_bits, n8, C)
+    if (res_mode == 1 && relu) PPV_FOLD(1, true);
+    else if (res_mode == 1) PPV_FOLD(1, false);
+    else if (relu) PPV_FOLD(0, true);
+    else PPV_FOLD(0, false);
+#undef PPV_FOLD
+    return ppv_last_error();
+}
+
 int ppv_bn_act_train(const void* x, const float* part, int T, double count, const float* gamma, const float* beta, float* run_mean,
                      float* run_var, float momentum, float eps, float* coef, const void* r, const float* part2, int T2,
                      const float* gamma2, const float* beta2, float* run_mean2, float* run_var2, float momentum2, float eps2,

@@ -246,3 +246,28 @@ def test_batchnorm_train_single_launch(rows, C, T, res_mode):
         assert rel_err(d2.running_var.cpu(), ref2.running_var) < 1e-5 and rel_err(coef2[2].cpu(), res.mean(0)) < 1e-5
     k = (bits.view(-1, 1).int() >> torch.arange(8, device="cuda").int()) & 1
     assert torch.equal(k.view(-1).bool(), (y > 0).view(-1))
+
+
+def test_bn_act_fold_equals_finalize_plus_act():
+    """ppv_bn_act_fold (statistics in one row, coefficients derived per thread; opt-in PPV_BN_FOLD_ACT=1) against ppv_bn_finalize +
+    ppv_bn_act on the same sums: same activations (one bf16 ulp), coefficients and running statistics."""
+    import ppv_amd.convops as co
+    g = torch.Generator().manual_seed(0)
+    rows, C = 4096, 256
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).bfloat16().cuda().view(4, 32, 32, C)
+    res = torch.randn(rows, C, generator=g).bfloat16().cuda().view(4, 32, 32, C)
+    xf = x.float().view(rows, C)
+    sums = torch.stack([xf.sum(0), (xf * xf).sum(0)]).view(1, 2, C).contiguous()
+    bn_a, bn_b = torch.nn.BatchNorm2d(C).cuda(), torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.2)
+    coef = co.bn_finalize(sums, rows, bn_a.weight.detach(), bn_a.bias.detach(), bn_a.running_mean, bn_a.running_var, 0.1, bn_a.eps)
+    want, wbits = co.bn_act(x, coef, res=res, want_bits=True)
+    got, gbits, gcoef = co.bn_act_fold(x, sums, rows, bn_b, 0.1, res=res, want_bits=True)
+    assert rel_err(gcoef, coef) < 1e-6
+    assert rel_err(got.float(), want.float()) < 2 ** -7 and (gbits != wbits).float().mean().item() < 1e-3
+    assert rel_err(bn_b.running_mean, bn_a.running_mean) < 1e-6 and rel_err(bn_b.running_var, bn_a.running_var) < 1e-6
+    got0, _, _ = co.bn_act_fold(x, sums, rows, bn_b, 0.1, relu=False)
+    assert rel_err(got0.float(), co.bn_act(x, coef, relu=False).float()) < 2 ** -7

@@ -511,7 +511,8 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     }
     // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
     // (its f32 instantiation has no epilogue options: variant 8 leaves f32 launches with an addend / sums to the tiled kernels)
-    if (((g_conv_variant == 0 && addend && !out_f32) || (g_conv_variant == 8 && (!out_f32 || (!addend && !red_x_ && !stat_part)))) &&
+    static const int stream_auto = getenv("PPV_STREAM_DGRAD") ? atoi(getenv("PPV_STREAM_DGRAD")) : 1;   // A/B: 0 = tiled kernels for the addend launches too
+    if (((g_conv_variant == 0 && addend && !out_f32 && stream_auto) || (g_conv_variant == 8 && (!out_f32 || (!addend && !red_x_ && !stat_part)))) &&
         conv1x1_stream_supported(g, Cs, div))
         return conv1x1_stream_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
                                      (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,

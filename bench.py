@@ -272,7 +272,7 @@ def _class_kernels(kind):
         "conv_gemm<64>+bn_sums": lambda n: tiled64(n) and n.endswith("false, true>"),
         "conv1x1_stream": lambda n: "conv1x1_stream_kernel" in n,
         "conv1x1_stream+bn_sums": lambda n: "conv1x1_stream_kernel" in n,
-        "conv_wgrad": lambda n: "conv_wgrad" in n or "wgrad_to_torch" in n,
+        "conv_wgrad": lambda n: "conv_wgrad" in n or "wgrad_to_torch" in n or "wgrad_reduce" in n,
     }.get(kind, lambda n: False)
 
 
@@ -327,7 +327,7 @@ def roofline_of_dominant_kernel(step):
                 tot_b += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches_2steps"]
                 tot_n += v["launches_2steps"]
         if dom == "conv_wgrad" and tot_n:                       # its slab-reduce launches belong to the same conv_wgrad() call
-            tot_n = sum(v["launches_2steps"] for name, v in pk.items() if match(name) and "wgrad_to_torch" not in name)
+            tot_n = sum(v["launches_2steps"] for name, v in pk.items() if match(name) and "wgrad_to_torch" not in name and "wgrad_reduce" not in name)
         traffic = round(tot_b / tot_n) if tot_n else None
     except Exception:
         traffic = None

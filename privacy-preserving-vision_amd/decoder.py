@@ -146,6 +146,21 @@ def _linear(x, w, bias, out, hip):
     return torch.addmm(bias, x, w.t(), out=out) if out is not None else torch.addmm(bias, x, w.t())
 
 
+def _tn(g, h, hip):
+    """g [m, N], h [m, K] -> g^T h [N, K]: the batched weight gradients of the dense layers (models.py:199-214 under autograd:
+    d W = sum over time steps and captions of (d out)^T in).  Exact f32 on the matrix pipe: both operands are copied transposed with
+    the reduction length padded to a multiple of 16 (zeros), then convops.linear_f32 (csrc/gemm_f32.hip); PPV_DEC_GEMM=lib: library."""
+    if not hip:
+        return g.t() @ h
+    m = g.shape[0]
+    mp = (m + 15) // 16 * 16
+    gt = torch.zeros((g.shape[1], mp), dtype=F32, device=g.device)
+    ht = torch.zeros((h.shape[1], mp), dtype=F32, device=g.device)
+    gt[:, :m].copy_(g.t())
+    ht[:, :m].copy_(h.t())
+    return co.linear_f32(gt, ht)
+
+
 class _DecoderFn(torch.autograd.Function):
     """Whole decoder forward / hand-written BPTT.  ``src`` is encoder_out f32 [B,...,E] (general path, tables None) or the
     cell map bf16 [B,Hc,Wc,E] (compact path); then the 19 parameters in ``DecoderWithAttention._plist`` order."""
@@ -244,16 +259,30 @@ class _DecoderFn(torch.autograd.Function):
         bts, caps, order, tables = ctx.bts, ctx.caps, ctx.order, ctx.tables
         compact = tables is not None
         dev = rows.device
-        if g_preds is None:
-            gp = torch.zeros((T, B, V), dtype=F32, device=dev)
-        else:
-            gp = (g_preds.transpose(0, 1).float() * valid).contiguous()   # [T,B,V]; dead positions carry no gradient
-        gp2 = gp.view(T * B, V)
-        d_wfc = gp2.t() @ HD.view(T * B, D)
-        d_bfc = gp2.sum(0)
         hip_gemm = ctx.hip_gemm
+        # batched weight gradients (g^T h over all time steps): PPV_DEC_WGRAD=hip runs them on the exact-f32 MFMA kernel too (_tn);
+        # default library -- gemm_f32.hip is a weight-STREAM kernel (16 weight rows per workgroup against <= 128 x rows) and re-reads
+        # the row operand once per 16-column tile when both sides are thousands wide: config 3 measured 3771-3835 images/s with it
+        # against 3977-4121 with the library for these five products (round 3)
+        import os as _os
+        hip_wgrad = hip_gemm and _os.environ.get("PPV_DEC_WGRAD", "lib") == "hip"
+        # the vocabulary axis is padded to a multiple of 16 in PRIVATE buffers (9490 -> 9504: rows of the transposed layer become
+        # 16-byte aligned and the reduction length a whole number of MFMA k-blocks); the pad columns are zeros
+        Vp = (V + 15) // 16 * 16 if hip_gemm else V
+        gp = torch.zeros((T, B, Vp), dtype=F32, device=dev)
+        if g_preds is not None:
+            torch.mul(g_preds.transpose(0, 1).float(), valid, out=gp[:, :, :V])   # [T,B,V]; dead positions carry no gradient
+        gp2p = gp.view(T * B, Vp)
+        gp2 = gp2p[:, :V]
+        d_wfc = _tn(gp2, HD.view(T * B, D), hip_wgrad)
+        d_bfc = gp2.sum(0)
         w2T, w1T = w2.t().contiguous(), w1.t().contiguous()       # the transposed layers x @ W = linear over W^T
-        dHS = _linear(gp2, w_fc.t().contiguous(), None, None, hip_gemm).view(T, B, D)
+        if hip_gemm:
+            w_fcT = torch.zeros((D, Vp), dtype=F32, device=dev)
+            w_fcT[:, :V].copy_(w_fc.t())
+        else:
+            w_fcT = w_fc.t().contiguous()
+        dHS = _linear(gp2p, w_fcT, None, None, hip_gemm).view(T, B, D)
         if dmask is not None:
             dHS = dHS * dmask
         ga = None if g_alphas is None else (g_alphas.transpose(0, 1).float() * valid).contiguous()
@@ -286,15 +315,15 @@ class _DecoderFn(torch.autograd.Function):
             torch.add(DX[t, :bt, M + E:], _linear(DHP[t, :bt], w1T, None, None, hip_gemm), out=dh_next[:bt])
 
         # ---- batched over all steps
-        d_w2 = DZ.view(T * B, 4 * D).t() @ XH[:T].view(T * B, X)
+        d_w2 = _tn(DZ.view(T * B, 4 * D), XH[:T].view(T * B, X), hip_wgrad)
         d_b2 = DZ.sum((0, 1))
-        d_w1 = DHP.view(T * B, A + E).t() @ XH[:T, :, M + E:].reshape(T * B, D)
+        d_w1 = _tn(DHP.view(T * B, A + E), XH[:T, :, M + E:].reshape(T * B, D), hip_wgrad)
         d_b1 = DHP.sum((0, 1))
         d_emb = torch.zeros((V, M), dtype=F32, device=dev).index_add_(0, caps[:, :T].t().reshape(-1), DX[:, :, :M].reshape(T * B, M))
         dhc0 = torch.cat([dh_next, dc_a], 1)                      # [B, 2D]
-        d_w0 = dhc0.t() @ mean
+        d_w0 = _tn(dhc0, mean, hip_wgrad)
         d_b0 = dhc0.sum(0)
-        dmean = dhc0 @ w0                                         # [B, E]
+        dmean = _linear(dhc0, w0.t().contiguous(), None, None, hip_gemm)   # [B, E]
 
         # ---- encoder side: score path through the bf16 MFMA kernels, context path as one batched GEMM
         datt_bf = datt.to(BF16)

@@ -230,6 +230,9 @@ int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, int f3
 int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, int f32, ppv_stream_t stream);
 int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* res, void* out, long M, int n1, int n2,
                     int n3, int s1, int s2, int s3, int f32, ppv_stream_t stream);
+/* bf16 split of an f32 matrix stacked along the rows: y [3*rows][Cp] = [hi; lo; hi] (mode 0) or [hi; hi; lo] (mode 1), so that
+ * y0(g)^T y1(h) on ppv_conv_wgrad equals g^T h to ~2^-16: the decoder's batched weight gradients (models.py:199-214 autograd). */
+int ppv_split3_rows(const float* x, long ldx, void* y, long rows, int C, int Cp, int mode, ppv_stream_t stream);
 int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, int ldx, ppv_stream_t stream);
 int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr,
                  int nch, int split, int nsum, int up, ppv_stream_t stream);

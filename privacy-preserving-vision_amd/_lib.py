@@ -51,6 +51,7 @@ PROTOTYPES = {
     "ppv_upsample2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_concat3_add": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_bn_act_split3": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "ppv_split3_rows": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "ppv_fan_head": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_ssim_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_ssim_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -205,6 +205,37 @@ __global__ __launch_bounds__(256) void bn_act_split3_kernel(const float* __restr
     y[i] = f2bf_f(v);
 }
 
+// one thread per 8 output columns of a source row: writes that chunk of the three stacked copies
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long rows, int C,
+                                                          int Cp, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = Cp / 8;
+    if (i >= rows * cpr) return;
+    const long r = i / cpr;
+    const int c0 = (int)(i % cpr) * 8;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 2 * k + e;
+            v[e] = c < C ? x[r * ldx + c] : 0.f;
+        }
+        const unsigned h0 = __builtin_bit_cast(unsigned short, (__bf16)v[0]), h1 = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
+        const float f0 = __builtin_bit_cast(float, h0 << 16), f1 = __builtin_bit_cast(float, h1 << 16);
+        const unsigned l0 = __builtin_bit_cast(unsigned short, (__bf16)(v[0] - f0)), l1 = __builtin_bit_cast(unsigned short, (__bf16)(v[1] - f1));
+        hi[k] = h0 | (h1 << 16);
+        lo[k] = l0 | (l1 << 16);
+    }
+    const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Lw = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    uint4* o = reinterpret_cast<uint4*>(y + r * Cp + c0);
+    const long plane = rows * (long)Cp / 8;                     // uint4 elements per stacked copy
+    o[0] = H;
+    o[plane] = mode == 0 ? Lw : H;
+    o[2 * plane] = mode == 0 ? H : Lw;
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -256,6 +287,18 @@ int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums
     fan_head_sum_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>((const float*)raw, bias, raw_out, sums, M, S * S, ldr, nch, split, nsum);
     const long tot = (long)B * 2 * S * up * S * up;
     bilinear_up_clamp_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(sums, heat, (long)B * 2, S, up);
+    return ppv_last_error();
+}
+
+// x [rows][ldx] f32 (first C columns used) -> y [3 * rows][Cp] bf16, the bf16 split stacked along the ROWS (the reduction axis of a
+// transposed product g^T h): mode 0 = [hi; lo; hi], mode 1 = [hi; hi; lo], columns >= C zero.  g^T h ~ y0(g)^T y1(h) with f32
+// accumulation = g_hi^T h_hi + g_lo^T h_hi + g_hi^T h_lo (product error ~2^-16): feeds ppv_conv_wgrad with the decoder's batched
+// weight gradients (Image_Caption/models.py:199-214 under autograd).
+int ppv_split3_rows(const float* x, long ldx, void* y, long rows, int C, int Cp, int mode, hipStream_t stream) {
+    if (!x || !y) return PPV_ERR_NULL;
+    if (rows < 1 || C < 1 || Cp < C || Cp % 8 || ldx < C || mode < 0 || mode > 1) return PPV_ERR_BAD_SIZE;
+    const long items = rows * (Cp / 8);
+    ppv::split3_rows_kernel<<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(x, ldx, (ppv::bf16_t*)y, rows, C, Cp, mode);
     return ppv_last_error();
 }
 

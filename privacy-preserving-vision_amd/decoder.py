@@ -152,6 +152,18 @@ def _tn(g, h, hip):
     the reduction length padded to a multiple of 16 (zeros), then convops.linear_f32 (csrc/gemm_f32.hip); PPV_DEC_GEMM=lib: library."""
     if not hip:
         return g.t() @ h
+    if hip == "split":
+        # three bf16 products on the MFMA weight-gradient kernel (csrc/conv_wgrad_stem.hip): g^T h ~ g_hi^T h_hi + g_lo^T h_hi + g_hi^T h_lo,
+        # the three terms stacked along the reduction axis ([g_hi; g_lo; g_hi]^T [h_hi; h_hi; h_lo]); product error ~2^-16
+        N, K = g.shape[1], h.shape[1]
+        Np, Kp = (N + 127) // 128 * 128, (K + 127) // 128 * 128
+        m = g.shape[0]
+        G3 = torch.empty((3 * m, 1, 1, Np), dtype=BF16, device=g.device)
+        H3 = torch.empty((3 * m, 1, 1, Kp), dtype=BF16, device=g.device)
+        assert g.stride(1) == 1 and h.stride(1) == 1
+        check(L().ppv_split3_rows(ptr(g), g.stride(0), ptr(G3), m, N, Np, 0, stream_ptr()), "ppv_split3_rows")
+        check(L().ppv_split3_rows(ptr(h), h.stride(0), ptr(H3), m, K, Kp, 1, stream_ptr()), "ppv_split3_rows")
+        return co.conv_wgrad(G3, H3, 1, 1, 1, 0).view(Np, Kp)[:N, :K]
     m = g.shape[0]
     mp = (m + 15) // 16 * 16
     gt = torch.zeros((g.shape[1], mp), dtype=F32, device=g.device)
@@ -265,7 +277,8 @@ class _DecoderFn(torch.autograd.Function):
         # the row operand once per 16-column tile when both sides are thousands wide: config 3 measured 3771-3835 images/s with it
         # against 3977-4121 with the library for these five products (round 3)
         import os as _os
-        hip_wgrad = hip_gemm and _os.environ.get("PPV_DEC_WGRAD", "lib") == "hip"
+        _wg = _os.environ.get("PPV_DEC_WGRAD", "lib")
+        hip_wgrad = ("split" if _wg == "split" else _wg == "hip") if hip_gemm else False
         # the vocabulary axis is padded to a multiple of 16 in PRIVATE buffers (9490 -> 9504: rows of the transposed layer become
         # 16-byte aligned and the reduction length a whole number of MFMA k-blocks); the pad columns are zeros
         Vp = (V + 15) // 16 * 16 if hip_gemm else V

@@ -216,3 +216,35 @@ def test_beam_search_entry_points_match_oracle():
     with pytest.warns(UserWarning, match="inference step"):
         awe_g, alpha_g = dec.attention(enc.cuda().requires_grad_(True), h.cuda())
     assert not awe_g.requires_grad and not alpha_g.requires_grad and torch.equal(awe_g, awe) and torch.equal(alpha_g, alpha)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["hip", "split"])
+def test_batched_weight_gradients_on_the_hip_paths(path, monkeypatch):
+    """The five batched weight gradients of the dense layers (models.py:199-214 under autograd: g^T h over all time steps) default to
+    library GEMMs (plain GEMMs; measured faster).  PPV_DEC_WGRAD=hip runs them on the exact-f32 MFMA kernel
+    (csrc/gemm_f32.hip), =split on the bf16 MFMA weight-gradient kernel as three stacked products (ppv_split3_rows + ppv_conv_wgrad):
+    every parameter gradient must equal the default path's (f32 summation order / 2^-16 products)."""
+    import ppv_amd.decoder as pd
+    torch.manual_seed(0)
+    B, S, E, A, M, D, V = 6, 4, 256, 128, 48, 64, 90
+    dec = pd.DecoderWithAttention(attention_dim=A, embed_dim=M, decoder_dim=D, vocab_size=V, encoder_dim=E, dropout=0.0).cuda().train()
+    enc = torch.randn(B, S, S, E, generator=torch.Generator().manual_seed(1)).cuda()
+    caps = torch.randint(0, V, (B, 9), generator=torch.Generator().manual_seed(2)).cuda()
+    lens = torch.tensor([[9], [7], [4], [9], [3], [6]]).cuda()
+
+    def grads():
+        dec.zero_grad(set_to_none=True)
+        e = enc.clone().requires_grad_(True)
+        preds, _, _, alphas, _ = dec(e, caps, lens)
+        (preds.square().mean() + alphas.square().mean()).backward()
+        return {n: p.grad.detach().clone() for n, p in dec.named_parameters()}, e.grad.detach().clone()
+
+    monkeypatch.setenv("PPV_DEC_WGRAD", "lib")
+    ref, ref_e = grads()
+    monkeypatch.setenv("PPV_DEC_WGRAD", path)
+    got, got_e = grads()
+    tol = 2e-5 if path == "hip" else 3e-4
+    for n in ref:
+        assert _l2(got[n].cpu(), ref[n].cpu()) < tol, n
+    assert _l2(got_e.cpu(), ref_e.cpu()) < tol

@@ -197,6 +197,11 @@ int ppv_bn_relu_maxpool(const void* x, const float* coef, void* y, void* arg, in
                         ppv_stream_t stream);
 int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* gpre, int B, int H, int W, int C,
                          ppv_stream_t stream);
+/* backward of resnet.1-3 from the pooled gradient straight to the gradient of the raw stem convolution output (torch autograd of
+ * MaxPool2d(3,2,1) o ReLU o BatchNorm2d(train), models.py:17-21): = ppv_maxpool_relu_bwd + ppv_bn_bwd without the pre-pool tensor.
+ * part: >= 16 * C floats of scratch. */
+int ppv_maxpool_bn_bwd(const void* gy, const void* y, const void* arg, const void* x, const float* coef, double count, void* gx,
+                       float* dgamma, float* dbeta, float* part, int B, int H, int W, int C, ppv_stream_t stream);
 int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, ppv_stream_t stream);
 int ppv_adaptive_pool_bwd(const void* gy, void* gx, const void* mask_src, int B, int H, int W, int C, int E, int g_f32,
                           ppv_stream_t stream);

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "ppv_bn_bwd_sums2": (_I, [_P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "ppv_bn_relu_maxpool": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_maxpool_relu_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_maxpool_bn_bwd": (_I, [_P, _P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_adaptive_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_adaptive_pool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }

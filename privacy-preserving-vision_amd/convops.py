@@ -360,6 +360,20 @@ def maxpool_relu_bwd(gy, y, arg, in_hw):
     return g
 
 
+def maxpool_bn_bwd(gy, y, arg, x_raw, coef, want_affine=False):
+    """Backward of BatchNorm(train) + ReLU + MaxPool 3x3/2 from the pooled gradient gy [B,Ho,Wo,C] to the gradient of the raw conv
+    output x_raw [B,2Ho,2Wo,C] (two passes over the pooled tensors + x_raw: no pre-pool gradient tensor).
+    -> (g_x bf16, dgamma f32|None, dbeta f32|None)."""
+    B, H, W, C = x_raw.shape
+    gx = torch.empty_like(x_raw)
+    dg = torch.empty(C, dtype=F32, device=x_raw.device) if want_affine else None
+    db = torch.empty(C, dtype=F32, device=x_raw.device) if want_affine else None
+    part = torch.empty(16 * C, dtype=F32, device=x_raw.device)
+    check(L().ppv_maxpool_bn_bwd(ptr(gy), ptr(y), ptr(arg), ptr(x_raw), ptr(coef), float(B * H * W), ptr(gx), ptr(dg), ptr(db), ptr(part),
+                                 B, H, W, C, stream_ptr()), "ppv_maxpool_bn_bwd")
+    return gx, dg, db
+
+
 def adaptive_pool_fwd(x, E, out_dtype=F32, out=None):
     B, H, W, C = x.shape
     y = torch.empty((B, E, E, C), dtype=out_dtype, device=x.device) if out is None else out

@@ -542,6 +542,105 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const bf16_t* __r
     store8(gpre + i * 8, acc);
 }
 
+// ----------------------------------------------------------------------------- stem backward in two passes instead of three (round 3)
+// max-pool backward -> BatchNorm backward of the stem used to be maxpool_relu_bwd (writes the 268-MB pre-pool gradient), bn_bwd_reduce
+// (reads it + the raw conv output) and the apply pass (reads both again, writes g_x): 1.8 GB.  The pre-pool gradient is a GATHER of
+// the pooled gradient (<= 4 windows per pixel), so both BatchNorm passes can take it straight from the 67-MB pooled tensors: pass 1
+// = the sums (sum g_pre, sum g_pre * x per channel, 8 partial rows), pass 2 = coefficients in the prologue + g_x.  1.1 GB.
+__device__ __forceinline__ void maxpool_gather8(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                const unsigned char* __restrict__ arg, int b, int h, int w, int c0, int Ho, int Wo, int C,
+                                                float (&acc)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int ho = (h + 1) / 2 - 1; ho <= (h + 1) / 2; ++ho) {
+        const int r = h + 1 - 2 * ho;
+        if (ho < 0 || ho >= Ho || r < 0 || r > 2) continue;
+        for (int wo = (w + 1) / 2 - 1; wo <= (w + 1) / 2; ++wo) {
+            const int s = w + 1 - 2 * wo;
+            if (wo < 0 || wo >= Wo || s < 0 || s > 2) continue;
+            const long o = (((long)b * Ho + ho) * Wo + wo) * C + c0;
+            const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(arg + o);
+            float g[8], yv[8];
+            load8(gy + o, g);
+            load8(y + o, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((int)((packed >> (8 * k)) & 0xff) == r * 3 + s && yv[k] > 0.f) acc[k] += g[k];
+        }
+    }
+}
+
+// APPLY = false: part [8][2][C] (pre-zeroed) += sums over this workgroup's pixels; APPLY = true: g_x = k0 g_pre + k1 x + k2 with the
+// coefficients derived from part in the prologue (as bn_bwd_apply_fused_kernel), dgamma / dbeta by workgroup 0.  C <= 256, C % 8 == 0;
+// a workgroup walks ppw consecutive pixels per thread row.
+template <bool APPLY>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                             const unsigned char* __restrict__ arg, const bf16_t* __restrict__ x,
+                                                             const float* __restrict__ coef, double count, float* __restrict__ part,
+                                                             bf16_t* __restrict__ gx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int B, int H, int W, int C, int ppw) {
+    __shared__ float s_k[3][256];
+    __shared__ float s_red[256][17];
+    const int Ho = H / 2, Wo = W / 2, tpr = C / 8, rpp = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr, c0 = tc * 8;
+    if (APPLY) {
+        if ((int)threadIdx.x < C) {
+            const int c = threadIdx.x;
+            double a = 0, b = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { a += (double)part[((long)t * 2 + 0) * C + c]; b += (double)part[((long)t * 2 + 1) * C + c]; }
+            const double scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
+            const double dgam = invstd * (b - mean * a);
+            s_k[0][c] = (float)scale;
+            s_k[1][c] = (float)(-scale * invstd * dgam / count);
+            s_k[2][c] = (float)(-scale * a / count + scale * invstd * mean * dgam / count);
+            if (blockIdx.x == 0) {
+                if (dgamma) dgamma[c] = (float)dgam;
+                if (dbeta) dbeta[c] = (float)a;
+            }
+        }
+        __syncthreads();
+    }
+    float k0[8], k1[8], k2[8], sa[8], sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sa[k] = sb[k] = 0.f;
+        if (APPLY) { k0[k] = s_k[0][c0 + k]; k1[k] = s_k[1][c0 + k]; k2[k] = s_k[2][c0 + k]; }
+    }
+    const long npix = (long)B * H * W;
+    const long p0 = (long)blockIdx.x * rpp * ppw;
+    if (tr < rpp) {
+        for (int it = 0; it < ppw; ++it) {
+            const long pix = p0 + (long)it * rpp + tr;
+            if (pix >= npix) break;
+            const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+            float acc[8], xv[8];
+            maxpool_gather8(gy, y, arg, b, h, w, c0, Ho, Wo, C, acc);
+            load8(x + pix * C + c0, xv);
+            if (APPLY) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = k0[k] * acc[k] + k1[k] * xv[k] + k2[k];
+                store8(gx + pix * C + c0, o);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { sa[k] += acc[k]; sb[k] += acc[k] * xv[k]; }
+            }
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s_red[threadIdx.x][k] = sa[k]; s_red[threadIdx.x][8 + k] = sb[k]; }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * C; t += 256) {
+            const int which = t / C, c = t % C;
+            float v = 0.f;
+            for (int rr = 0; rr < rpp; ++rr) v += s_red[rr * tpr + c / 8][which * 8 + c % 8];
+            atomicAdd(&part[((long)(blockIdx.x & 7) * 2 + which) * C + c], v);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- AdaptiveAvgPool2d(E) on [B,H,W,C]
 // window of output i: [floor(i*H/E), ceil((i+1)*H/E))  (torch adaptive pooling)
 template <typename TO>
@@ -809,6 +908,25 @@ int ppv_maxpool_relu_bwd(const void* gy, const void* y, const void* arg, void* g
     const long tot = (long)B * H * W * (C / 8);
     maxpool_relu_bwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y,
                                                                               (const unsigned char*)arg, (bf16_t*)gpre, B, H, W, C);
+    return ppv_last_error();
+}
+
+// Backward of resnet.1-3 (BatchNorm2d(train) + ReLU + MaxPool 3x3/2) from the POOLED gradient: gy, y [B,H/2,W/2,C] bf16 (pooled
+// gradient / output), arg [B,H/2,W/2,C] u8 (ppv_bn_relu_maxpool), x [B,H,W,C] bf16 raw convolution output, coef [4][C] of that
+// BatchNorm -> gx [B,H,W,C] bf16 = gradient w.r.t. the raw convolution output; dgamma / dbeta f32 [C] (may be null).
+// part: scratch >= 16 * C floats (zeroed here).  Equals ppv_maxpool_relu_bwd + ppv_bn_bwd(relu = 0) without the 268-MB intermediate.
+int ppv_maxpool_bn_bwd(const void* gy, const void* y, const void* arg, const void* x, const float* coef, double count, void* gx,
+                       float* dgamma, float* dbeta, float* part, int B, int H, int W, int C, hipStream_t stream) {
+    if (!gy || !y || !arg || !x || !coef || !gx || !part) return PPV_ERR_NULL;
+    if (C % 8 || C > 256 || 256 % (C / 8) || H % 2 || W % 2 || count < 1) return PPV_ERR_BAD_SIZE;
+    (void)hipMemsetAsync(part, 0, sizeof(float) * 16 * C, stream);
+    const int rpp = 256 / (C / 8), ppw = 8;
+    const long npix = (long)B * H * W;
+    const unsigned gb = (unsigned)((npix + (long)rpp * ppw - 1) / ((long)rpp * ppw));
+    maxpool_bn_bwd_kernel<false><<<gb, 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y, (const unsigned char*)arg, (const bf16_t*)x, coef,
+                                                        count, part, nullptr, nullptr, nullptr, B, H, W, C, ppw);
+    maxpool_bn_bwd_kernel<true><<<gb, 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y, (const unsigned char*)arg, (const bf16_t*)x, coef,
+                                                       count, part, (bf16_t*)gx, dgamma, dbeta, B, H, W, C, ppw);
     return ppv_last_error();
 }
 

@@ -577,11 +577,15 @@ class _TrunkFn(torch.autograd.Function):
         at_point(1 << 30)                                     # whatever is still deferred
         if needs_img or enc._stem.bn.weight.requires_grad or enc._stem.conv.weight.requires_grad:
             raw0, c0, y0, arg0 = ctx.saved["stem"]
-            gpre0 = co.maxpool_relu_bwd(g, y0, arg0, (raw0.shape[1], raw0.shape[2]))
             st = enc._stem
             if st.conv.weight.requires_grad:
                 raise NotImplementedError("the stem convolution is frozen in the reference (models.py:43-54)")
-            gx0, _, dg, db = co.bn_bwd(gpre0, None, raw0, c0, False, want_affine=st.bn.weight.requires_grad, part=bn_part(64))
+            if _os.environ.get("PPV_STEM_BWD_FUSED", "1") != "0" and raw0.shape[-1] <= 256:
+                # pooled gradient -> gradient of the raw stem output in two passes over the pooled tensors (no 268-MB pre-pool tensor)
+                gx0, dg, db = co.maxpool_bn_bwd(g, y0, arg0, raw0, c0, want_affine=st.bn.weight.requires_grad)
+            else:
+                gpre0 = co.maxpool_relu_bwd(g, y0, arg0, (raw0.shape[1], raw0.shape[2]))
+                gx0, _, dg, db = co.bn_bwd(gpre0, None, raw0, c0, False, want_affine=st.bn.weight.requires_grad, part=bn_part(64))
             if st.bn.weight.requires_grad:
                 grads[st.bn.weight], grads[st.bn.bias] = dg, db
                 if sync is not None:

@@ -271,3 +271,34 @@ def test_bn_act_fold_equals_finalize_plus_act():
     assert rel_err(bn_b.running_mean, bn_a.running_mean) < 1e-6 and rel_err(bn_b.running_var, bn_a.running_var) < 1e-6
     got0, _, _ = co.bn_act_fold(x, sums, rows, bn_b, 0.1, relu=False)
     assert rel_err(got0.float(), co.bn_act(x, coef, relu=False).float()) < 2 ** -7
+
+
+@pytest.mark.parametrize("B,H,C", [(2, 16, 64), (3, 24, 64), (1, 8, 128)])
+def test_fused_stem_backward_equals_autograd(B, H, C):
+    """ppv_maxpool_bn_bwd (round 3): pooled gradient -> gradient of the raw stem output, against torch autograd of
+    MaxPool2d(3,2,1) o ReLU o BatchNorm2d(train) (models.py:17-21 / train.py:245) and against the two-kernel path it replaces."""
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(4)
+    x = r16(torch.randn(B, C, H, H, generator=g0) * 1.5 + 0.3).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g0) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g0) * 0.2)
+    xd = nhwc(x.detach()).cuda().bfloat16()
+    xf = xd.float().view(-1, C)
+    sums = torch.stack([xf.sum(0), (xf * xf).sum(0)]).view(1, 2, C).contiguous()
+    coef = co.bn_finalize(sums, xf.shape[0], bn.weight.detach().cuda(), bn.bias.detach().cuda(), None, None, 0.1, bn.eps)
+    yd, arg = co.bn_relu_maxpool(xd, coef)
+    gy = r16(torch.randn(B, C, H // 2, H // 2, generator=g0))
+    gyd = nhwc(gy).cuda().bfloat16()
+    gx, dg, db = co.maxpool_bn_bwd(gyd, yd, arg, xd, coef, want_affine=True)
+    # the path it replaces (same kernels' arithmetic, pre-pool tensor rounded to bf16 in between)
+    gpre = co.maxpool_relu_bwd(gyd, yd, arg, (H, H))
+    gx2, _, dg2, db2 = co.bn_bwd(gpre, None, xd, coef, False, want_affine=True)
+    assert rel_err(gx.float(), gx2.float()) < 2 * BF and rel_err(dg, dg2) < 1e-3 and rel_err(db, db2) < 1e-3   # one bf16 rounding fewer
+    # torch autograd on the same bf16-rounded activation chain
+    a = r16(F.relu(bn(x)))
+    a.retain_grad()
+    F.max_pool2d(a, 3, stride=2, padding=1).backward(gy)
+    assert rel_err(gx.float(), nhwc(x.grad)) < 3e-2          # the product's ReLU / arg-max decisions were taken on bf16 values
+    assert rel_err(db, bn.bias.grad) < 3e-2 and rel_err(dg, bn.weight.grad) < 3e-2

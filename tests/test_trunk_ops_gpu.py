@@ -295,7 +295,7 @@ def test_fused_stem_backward_equals_autograd(B, H, C):
     # the path it replaces (same kernels' arithmetic, pre-pool tensor rounded to bf16 in between)
     gpre = co.maxpool_relu_bwd(gyd, yd, arg, (H, H))
     gx2, _, dg2, db2 = co.bn_bwd(gpre, None, xd, coef, False, want_affine=True)
-    assert rel_err(gx.float(), gx2.float()) < 2 * BF and rel_err(dg, dg2) < 1e-3 and rel_err(db, db2) < 1e-3   # one bf16 rounding fewer
+    assert rel_err(gx.float(), gx2.float()) < 2 * BF and rel_err(dg, dg2) < 5e-3 and rel_err(db, db2) < 5e-3   # one bf16 rounding fewer (the sums see the unrounded gather)
     # torch autograd on the same bf16-rounded activation chain
     a = r16(F.relu(bn(x)))
     a.retain_grad()

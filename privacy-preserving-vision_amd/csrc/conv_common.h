@@ -42,6 +42,18 @@ __device__ __forceinline__ uint4 relu_mask8(uint4 v, unsigned b) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                  \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// Progress words in LDS (loader / consumer waves without barriers: conv_stream.hip).  Read and written through
+// address-space-3 pointers: through a generic `volatile unsigned*` hipcc emits flat_load / flat_store ... sc0 sc1 followed by
+// s_waitcnt vmcnt(0) -- every poll then also waits for the wave's outstanding GLOBAL stores and loads.
+typedef unsigned lds_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lds_u32x4_t lds_poll4(const volatile unsigned* p) {
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) lds_u32x4_t*>(
+        (const volatile __attribute__((address_space(3))) unsigned*)p);
+}
+__device__ __forceinline__ void lds_post(volatile unsigned* p, unsigned v) {
+    *((volatile __attribute__((address_space(3))) unsigned*)p) = v;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BatchNorm-backward sums taken in a data-gradient store loop (see conv_gemm.hip, RED): mask from x * scale + shift > 0 ...

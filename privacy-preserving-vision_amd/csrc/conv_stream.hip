@@ -82,8 +82,8 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
             if (t >= ST_NSLOT) {                                            // the slot's previous tile: read by every consumer?
                 const unsigned need = (unsigned)(t - ST_NSLOT + 1);
                 for (;;) {
-                    const st_u32x4 a = *reinterpret_cast<volatile const st_u32x4*>(sDone);
-                    const st_u32x4 b = *reinterpret_cast<volatile const st_u32x4*>(sDone + 4);
+                    const st_u32x4 a = lds_poll4(sDone);             // address-space-3 reads: a generic volatile pointer compiles to
+                    const st_u32x4 b = lds_poll4(sDone + 4);         // flat_load sc0 sc1 + s_waitcnt vmcnt(0) (conv_common.h)
                     const unsigned lo = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
                     if (__builtin_amdgcn_readfirstlane(lo) >= need) break;
                     __builtin_amdgcn_s_sleep(2);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
             adv += 64L * KC;
             slot = slot + 1 == ST_NSLOT ? 0 : slot + 1;
             wait_vmcnt_le<0>();                                             // landed; the slots that are free bound the run-ahead
-            if (lane == 0) sLanded[lw] = (unsigned)(t + 1);
+            if (lane == 0) lds_post(sLanded + lw, (unsigned)(t + 1));
             if (t == 0) PPV_STAMP(1);
             if (t == 1) PPV_STAMP(2);
             if (t == 2) PPV_STAMP(3);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
             int slot = 0;
             for (int j = 0; j < NS; ++j) {
                 for (;;) {                                                   // weight tile j landed (all four loader waves)?
-                    const st_u32x4 a = *reinterpret_cast<volatile const st_u32x4*>(sLanded);
+                    const st_u32x4 a = lds_poll4(sLanded);
                     const unsigned lo = min(min(a.x, a.y), min(a.z, a.w));
                     if (__builtin_amdgcn_readfirstlane(lo) > (unsigned)j) break;
                     __builtin_amdgcn_s_sleep(1);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                 if (j == 0) PPV_STAMP(2);
                 compute(slot);
                 asm volatile("" ::: "memory");
-                if (lane == 0) sDone[wave] = (unsigned)(j + 1);              // LDS executes a wave's instructions in order: behind the reads
+                if (lane == 0) lds_post(sDone + wave, (unsigned)(j + 1));   // LDS executes a wave's instructions in order: behind the reads
                 if (j == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][3][3])); PPV_STAMP(3); }
                 epilogue(j, full_tag);
                 if (j == 0) PPV_STAMP(4);

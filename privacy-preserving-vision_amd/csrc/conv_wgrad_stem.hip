@@ -444,6 +444,13 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_group_kernel(WgradGroupP
 // (4769 / 4552 images/s at 256 / 384 workgroups against 4963 with the 64-KB two-stage ring).
 constexpr int WS_NLW = 4;
 typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
+// progress words are read / written through address-space-3 pointers: through a generic `volatile unsigned*` hipcc emits
+// flat_load / flat_store ... sc0 sc1 + s_waitcnt vmcnt(0), i.e. every poll of the LOADER waves drained their whole LDS-DMA ring (round
+// 3 finding: that, not the hardware, is why rounds 1-2 saw "one stage per 1.6 us whatever the ring depth" in this kernel)
+__device__ __forceinline__ ws_u32x4 ws_poll4(const volatile unsigned* p) {
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) ws_u32x4*>((const volatile __attribute__((address_space(3))) unsigned*)p);
+}
+__device__ __forceinline__ void ws_post(volatile unsigned* p, unsigned v) { *((volatile __attribute__((address_space(3))) unsigned*)p) = v; }
 #ifdef PPV_STAMPS   // diagnostic build (csrc/build_stamps.sh, tools/wgrad_timeline.py): phase stamps of consumer wave 0 and loader wave 0
 extern __device__ unsigned long long* g_stamps;
 #define WS_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -519,10 +526,10 @@ __global__ __launch_bounds__((TN / 32 + WS_NLW) * 64, (TN / 32 + WS_NLW) / 4) vo
         };
         static_assert(7 * LI < 64, "vmcnt is a 6-bit counter");
         auto consumed = [&]() {
-            const ws_u32x4 a = *reinterpret_cast<volatile const ws_u32x4*>(sDone);
+            const ws_u32x4 a = ws_poll4(sDone);
             unsigned lo = min(min(a.x, a.y), min(a.z, a.w));
             if (NCW == 8) {
-                const ws_u32x4 b = *reinterpret_cast<volatile const ws_u32x4*>(sDone + 4);
+                const ws_u32x4 b = ws_poll4(sDone + 4);
                 lo = min(lo, min(min(b.x, b.y), min(b.z, b.w)));
             }
             return (int)__builtin_amdgcn_readfirstlane(lo);
@@ -569,7 +576,7 @@ __global__ __launch_bounds__((TN / 32 + WS_NLW) * 64, (TN / 32 + WS_NLW) / 4) vo
             if (published < issued) {                                        // nothing to issue right now: retire the oldest stage in flight
                 wait_oldest(issued - published - 1);
                 ++published;
-                if (lane == 0) sLanded[lw] = (unsigned)published;
+                if (lane == 0) ws_post(sLanded + lw, (unsigned)published);
                 if (published == 1) WS_STAMP(3);
                 if (published == 5) WS_STAMP(4);
                 if (published == 13) WS_STAMP(5);
@@ -591,7 +598,7 @@ __global__ __launch_bounds__((TN / 32 + WS_NLW) * 64, (TN / 32 + WS_NLW) / 4) vo
     unsigned landed = 0;
     auto wait_landed = [&](int j) {                                       // stage j has landed (all four loader waves)
         while (landed <= (unsigned)j) {
-            const ws_u32x4 a = *reinterpret_cast<volatile const ws_u32x4*>(sLanded);
+            const ws_u32x4 a = ws_poll4(sLanded);
             landed = __builtin_amdgcn_readfirstlane(min(min(a.x, a.y), min(a.z, a.w)));
             if (landed <= (unsigned)j) __builtin_amdgcn_s_sleep(1);
         }
@@ -615,7 +622,7 @@ __global__ __launch_bounds__((TN / 32 + WS_NLW) * 64, (TN / 32 + WS_NLW) / 4) vo
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) tr_issue(blo[ni], bhi[ni], tx, 0, wc * 4 + ni, lane);
         tr_wait_all();                                                      // fragments of stage j are in registers
-        if (lane == 0) sDone[wave] = (unsigned)(j + 1);
+        if (lane == 0) ws_post(sDone + wave, (unsigned)(j + 1));
         bf16x8 af[4], bfr[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[mi], ahi[mi]);

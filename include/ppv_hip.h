@@ -80,6 +80,10 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
 /* Optional, once per (state, Z): marks the support of the basis inside `state` so that the two calls above skip the pixel groups
  * where every plane of Z is zero (outside the aperture disk of poppy.zernike_basis(outside=0), Utils.py:75-77; exact). */
 int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, ppv_stream_t stream);
+/* 1 when ppv_ic_psf_mark_support found the basis bitwise mirror-symmetric (every Noll term is even or odd under x -> -x and y -> -y on
+ * poppy's centred grid, Utils.py:75-77), in which case ppv_ic_psf_fwd / _bwd read one quadrant of it; 0 otherwise.  Synchronises
+ * `stream`: a test / diagnostic entry point, not called in the step. */
+int ppv_ic_psf_symmetric(const void* state, int RR, int P, int K, ppv_stream_t stream);
 int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0, size_t* off_U, size_t* off_I32,
                              size_t* off_raw);
 

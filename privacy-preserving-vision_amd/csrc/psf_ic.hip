@@ -152,10 +152,29 @@ constexpr unsigned long long SUPPORT_MAGIC = 0x5050565f53555050ull;
 __device__ __forceinline__ bool support_on(const unsigned char* support) {
     return support && *reinterpret_cast<const unsigned long long*>(support) == SUPPORT_MAGIC;
 }
+// ----------------------------------------------------------------------------- mirror symmetry of the basis
+// Z_j(x, y) = R(rho) * {cos | sin}(m theta) on a grid that is symmetric about its centre (poppy: x_i = (i - (n-1)/2) / ((n-1)/2)):
+// every plane is even or odd under x -> -x and under y -> -y, so ONE QUADRANT of each plane holds all of it.  Whether the buffer at
+// hand has that property BITWISE (the basis of csrc/zernike.hip has: IEEE products and sums commute with negation; a user-supplied
+// volume may not) is decided from the data, like the support mask: per plane k the marking pass keeps the set of sign pairs
+// (sx, sy) under which Z[k][y][R-1-x] == sx * Z[k][y][x], Z[k][R-1-y][x] == sy * Z[k][y][x] and Z[k][R-1-y][R-1-x] == sx * sy * Z[k][y][x]
+// hold for every pixel; a plane with an empty set switches the quadrant path off for this state.  With it on, the height map
+// (zernike_contract_sym_kernel) and its adjoint (zernike_grad_sym_kernel) read 1/4 of the basis; the height map is bit-identical
+// to the full pass (same products up to an exact sign, same summation order per pixel).
+constexpr unsigned long long SYM_MAGIC = 0x5050565f53594d4dull;
+struct SymHdr { unsigned long long magic; unsigned bad; unsigned pad; };
+__device__ __forceinline__ bool sym_on(const unsigned char* sym) {
+    return sym && reinterpret_cast<const SymHdr*>(sym)->magic == SYM_MAGIC;
+}
+__device__ __forceinline__ unsigned* sym_masks(unsigned char* sym) { return reinterpret_cast<unsigned*>(sym + 256); }
+__device__ __forceinline__ const unsigned char* sym_cls(const unsigned char* sym, int K) { return sym + 256 + (size_t)K * 4; }
+
 __global__ __launch_bounds__(256) void zernike_contract_kernel(const float* __restrict__ Z, const float* __restrict__ c,
                                                                float* __restrict__ h, int K, long npx4,
-                                                               const unsigned char* __restrict__ support) {
+                                                               const unsigned char* __restrict__ support,
+                                                               const unsigned char* __restrict__ sym) {
     extern __shared__ float s_c[];
+    if (sym_on(sym)) return;                       // zernike_contract_sym_kernel (launched beside this one) does the work
     for (int k = threadIdx.x; k < K; k += 256) s_c[k] = c[k];
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -179,7 +198,9 @@ __global__ __launch_bounds__(256) void zernike_contract_kernel(const float* __re
 // the K loop, four independent 16-byte loads in flight per lane), folded by sum_partials_kernel
 __global__ __launch_bounds__(256) void zernike_grad_kernel(const float* __restrict__ Z, const float* __restrict__ gh,
                                                            double* __restrict__ part, int K, long npx4,
-                                                           const unsigned char* __restrict__ support) {
+                                                           const unsigned char* __restrict__ support,
+                                                           const unsigned char* __restrict__ sym) {
+    if (sym_on(sym)) return;                       // zernike_grad_sym_kernel does the work
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const bool ok = i < npx4 && (!support_on(support) || support[256 + i]);   // groups outside the basis' support contribute exactly zero
     const float4 g = ok ? reinterpret_cast<const float4*>(gh)[i] : make_float4(0, 0, 0, 0);
@@ -224,8 +245,182 @@ __global__ __launch_bounds__(256) void zernike_support_kernel(const float* __res
 }
 __global__ void zernike_support_seal_kernel(unsigned char* support) { *reinterpret_cast<unsigned long long*>(support) = SUPPORT_MAGIC; }
 
+// thread <-> (row y < R/2, column pair 2j < R/2): its float2 and the three mirror images
+struct QuadIdx { long q, qx, qy, qxy; bool ok; };
+__device__ __forceinline__ QuadIdx quad_index(long t, int R) {
+    const int half2 = R / 4;                       // float2 columns of a quadrant row
+    QuadIdx r;
+    r.ok = t < (long)(R / 2) * half2;
+    const int y = r.ok ? (int)(t / half2) : 0, j = r.ok ? (int)(t % half2) : 0;
+    const int R2 = R / 2;                          // float2 per row
+    r.q = (long)y * R2 + j;
+    r.qx = (long)y * R2 + (R2 - 1 - j);
+    r.qy = (long)(R - 1 - y) * R2 + j;
+    r.qxy = (long)(R - 1 - y) * R2 + (R2 - 1 - j);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void zernike_sym_check_kernel(const float* __restrict__ Z, unsigned char* __restrict__ sym, int K, int R) {
+    const QuadIdx ix = quad_index((long)blockIdx.x * 256 + threadIdx.x, R);
+    const long npx2 = (long)R * R / 2;
+    unsigned* masks = sym_masks(sym);
+    for (int k = 0; k < K; ++k) {
+        const float2* z = reinterpret_cast<const float2*>(Z) + (long)k * npx2;
+        unsigned m = 0xF;
+        if (ix.ok) {
+            const float2 v = z[ix.q], vx = z[ix.qx], vy = z[ix.qy], vxy = z[ix.qxy];
+            m = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sx = (c & 1) ? -1.f : 1.f, sy = (c & 2) ? -1.f : 1.f;
+                const bool okc = vx.y == sx * v.x && vx.x == sx * v.y && vy.x == sy * v.x && vy.y == sy * v.y &&
+                                 vxy.y == sx * sy * v.x && vxy.x == sx * sy * v.y;
+                m |= okc ? (1u << c) : 0u;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m &= (unsigned)__shfl_xor((int)m, off, 64);
+        if ((threadIdx.x & 63) == 0 && m != 0xF) atomicAnd(&masks[k], m);
+    }
+}
+__global__ __launch_bounds__(256) void zernike_sym_seal_kernel(unsigned char* sym, int K) {
+    __shared__ unsigned s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const unsigned* masks = sym_masks(sym);
+    unsigned char* cls = sym + 256 + (size_t)K * 4;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const unsigned m = masks[k] & 0xF;
+        if (!m) atomicOr(&s_bad, 1u);
+        cls[k] = (unsigned char)(m ? __ffs(m) - 1 : 0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SymHdr* h = reinterpret_cast<SymHdr*>(sym);
+        h->bad = s_bad;
+        h->magic = s_bad ? 0ull : SYM_MAGIC;
+    }
+}
+
+// h = sum_k c[k] Z[k] from one quadrant of Z (launched only when sym_on): same products and the same k order per pixel as
+// zernike_contract_kernel
+__global__ __launch_bounds__(256) void zernike_contract_sym_kernel(const float* __restrict__ Z, const float* __restrict__ c,
+                                                                   float* __restrict__ h, int K, int R,
+                                                                   const unsigned char* __restrict__ support,
+                                                                   const unsigned char* __restrict__ sym) {
+    extern __shared__ float s_c4[];                 // [4][K]: c, c*sx, c*sy, c*sx*sy
+    if (!sym_on(sym)) return;
+    const unsigned char* cls = sym_cls(sym, K);
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float ck = c[k];
+        const int cl = cls[k];
+        const float sx = (cl & 1) ? -1.f : 1.f, sy = (cl & 2) ? -1.f : 1.f;
+        s_c4[k] = ck; s_c4[K + k] = ck * sx; s_c4[2 * K + k] = ck * sy; s_c4[3 * K + k] = ck * sx * sy;
+    }
+    __syncthreads();
+    const QuadIdx ix = quad_index((long)blockIdx.x * 256 + threadIdx.x, R);
+    if (!ix.ok) return;
+    float2* h2 = reinterpret_cast<float2*>(h);
+    if (support_on(support) && !support[256 + (ix.q >> 1)]) {
+        // the whole float4 group is outside the support, and so are its mirror images
+        const float2 z0 = make_float2(0.f, 0.f);
+        h2[ix.q] = z0; h2[ix.qx] = z0; h2[ix.qy] = z0; h2[ix.qxy] = z0;
+        return;
+    }
+    const long npx2 = (long)R * R / 2;
+    const float2* z = reinterpret_cast<const float2*>(Z) + ix.q;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) {
+        const float2 v = z[(long)k * npx2];
+        const float c0 = s_c4[k], c1 = s_c4[K + k], c2 = s_c4[2 * K + k], c3 = s_c4[3 * K + k];
+        a[0] += (double)(c0 * v.x); a[1] += (double)(c0 * v.y);
+        a[2] += (double)(c1 * v.x); a[3] += (double)(c1 * v.y);
+        a[4] += (double)(c2 * v.x); a[5] += (double)(c2 * v.y);
+        a[6] += (double)(c3 * v.x); a[7] += (double)(c3 * v.y);
+    }
+    h2[ix.q] = make_float2((float)a[0], (float)a[1]);
+    h2[ix.qx] = make_float2((float)a[3], (float)a[2]);          // mirrored in x: the pair swaps
+    h2[ix.qy] = make_float2((float)a[4], (float)a[5]);
+    h2[ix.qxy] = make_float2((float)a[7], (float)a[6]);
+}
+
+// adjoint from one quadrant: g[k] = sum_q Z[k][q] * (gh[q] + sx gh[qx] + sy gh[qy] + sx sy gh[qxy]); one partial row per wave.
+// Eight planes per round: their loads are issued one round ahead (with ~6 waves per CU nothing else covers the miss latency), and the
+// eight per-lane sums are folded over the wave together -- each of the first three exchange steps keeps the half of the values the
+// lane's bit selects, so a round costs 10 f64 exchanges instead of 48.
+__device__ __forceinline__ double shx(double v, int off) { return __shfl_xor(v, off, 64); }
+__global__ __launch_bounds__(256) void zernike_grad_sym_kernel(const float* __restrict__ Z, const float* __restrict__ gh,
+                                                               double* __restrict__ part, int K, int R,
+                                                               const unsigned char* __restrict__ support,
+                                                               const unsigned char* __restrict__ sym) {
+    extern __shared__ unsigned char s_cls[];
+    if (!sym_on(sym)) return;
+    const unsigned char* cls = sym_cls(sym, K);
+    for (int k = threadIdx.x; k < K; k += 256) s_cls[k] = cls[k];
+    __syncthreads();
+    const QuadIdx ix = quad_index((long)blockIdx.x * 256 + threadIdx.x, R);
+    const bool ok = ix.ok && (!support_on(support) || support[256 + (ix.q >> 1)]);
+    const float2* g2 = reinterpret_cast<const float2*>(gh);
+    double dx[4] = {0, 0, 0, 0}, dy[4] = {0, 0, 0, 0};
+    if (ok) {
+        const float2 g = g2[ix.q], gx = g2[ix.qx], gy = g2[ix.qy], gxy = g2[ix.qxy];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double sx = (c & 1) ? -1.0 : 1.0, sy = (c & 2) ? -1.0 : 1.0;
+            dx[c] = (double)g.x + sx * (double)gx.y + sy * (double)gy.x + sx * sy * (double)gxy.y;
+            dy[c] = (double)g.y + sx * (double)gx.x + sy * (double)gy.y + sx * sy * (double)gxy.x;
+        }
+    }
+    const long npx2 = (long)R * R / 2;
+    const float2* z = reinterpret_cast<const float2*>(Z) + (ok ? ix.q : 0);      // lanes outside read a valid address with weight 0
+    double* row = part + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * K;
+    const int lane = threadIdx.x & 63;
+    float2 v[8], vn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = z[(long)min(j, K - 1) * npx2];
+    for (int k = 0; k < K; k += 8) {
+        if (k + 8 < K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vn[j] = z[(long)min(k + 8 + j, K - 1) * npx2];
+        }
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cl = s_cls[min(k + j, K - 1)];
+            const double ex = cl == 0 ? dx[0] : cl == 1 ? dx[1] : cl == 2 ? dx[2] : dx[3];
+            const double ey = cl == 0 ? dy[0] : cl == 1 ? dy[1] : cl == 2 ? dy[2] : dy[3];
+            a[j] = (double)v[j].x * ex + (double)v[j].y * ey;
+        }
+        // fold: after the three halving steps lane l holds the sum over its 8-lane-strided group of value ((l>>5)&1)*4 + ((l>>4)&1)*2 + ((l>>3)&1)
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        double b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double keep = h5 ? a[4 + j] : a[j], give = h5 ? a[j] : a[4 + j];
+            b[j] = keep + shx(give, 32);
+        }
+        double c2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double keep = h4 ? b[2 + j] : b[j], give = h4 ? b[j] : b[2 + j];
+            c2[j] = keep + shx(give, 16);
+        }
+        double d = (h3 ? c2[1] : c2[0]) + shx(h3 ? c2[0] : c2[1], 8);
+        d += shx(d, 4);
+        d += shx(d, 2);
+        d += shx(d, 1);
+        const int which = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+        if ((lane & 7) == 0 && k + which < K) row[k + which] = d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = vn[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, float* __restrict__ out,
-                                                           int nwg, int K) {
+                                                           int nwg, int K, const unsigned char* __restrict__ sym = nullptr,
+                                                           int nwg_sym = 0) {
+    if (sym_on(sym)) nwg = nwg_sym;                // the quadrant form left fewer partial rows
     // one workgroup per coefficient: 256 threads stride over the per-workgroup partials
     __shared__ double s_red[4];
     const int k = blockIdx.x;
@@ -598,6 +793,7 @@ struct IcWs {            // carve-up of the caller's persistent state buffer (sa
     double* part;        // [nwg][K]
     float* gh;           // [RR*RR]
     unsigned char* support;   // [RR*RR/4] basis support per float4 group (ppv_ic_psf_mark_support), behind a one-byte "marked" flag
+    unsigned char* sym;       // mirror symmetry of the basis: 256-byte header (SymHdr), [K] u32 sign-pair sets, [K] u8 classes
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -620,7 +816,37 @@ size_t carve(IcWs* w, char* base, int RR, int P, int K) {
     w->part = (double*)take(nwg * 4 * K * 8);
     w->gh = (float*)take(npx * 4);
     w->support = (unsigned char*)take(npx / 4 + 256);          // 256-byte header (magic word) + one byte per float4 group
+    w->sym = (unsigned char*)take(256 + (size_t)K * 5);
     return off;
+}
+
+}  // namespace
+
+namespace {
+
+unsigned quad_blocks(int RR) { return (unsigned)(((long)(RR / 2) * (RR / 4) + 255) / 256); }
+
+// PPV_ZERNIKE_SYM=0 keeps the full-basis passes even when the basis was found mirror-symmetric.  Whether a state's basis IS symmetric
+// is known on the device only (header written by the marking pass; the host never reads it back in the step): both forms are
+// launched, and the one the header does not select returns at once (one empty launch per direction, ~4 us, against ~130 us saved).
+bool sym_allowed() {
+    static const bool on = !(getenv("PPV_ZERNIKE_SYM") && atoi(getenv("PPV_ZERNIKE_SYM")) == 0);
+    return on;
+}
+
+void launch_contract(const float* Z, const float* coeffs, const IcWs& w, int K, int RR, hipStream_t stream) {
+    const long npx4 = (long)RR * RR / 4;
+    const unsigned char* sym = sym_allowed() ? w.sym : nullptr;
+    if (sym) zernike_contract_sym_kernel<<<quad_blocks(RR), 256, 4 * K * sizeof(float), stream>>>(Z, coeffs, w.h, K, RR, w.support, sym);
+    zernike_contract_kernel<<<(unsigned)((npx4 + 255) / 256), 256, K * sizeof(float), stream>>>(Z, coeffs, w.h, K, npx4, w.support, sym);
+}
+void launch_grad(const float* Z, float* g_coeffs, const IcWs& w, int K, int RR, hipStream_t stream) {
+    const long npx4 = (long)RR * RR / 4;
+    const unsigned nwg = (unsigned)((npx4 + 255) / 256);
+    const unsigned char* sym = sym_allowed() ? w.sym : nullptr;
+    if (sym) zernike_grad_sym_kernel<<<quad_blocks(RR), 256, K, stream>>>(Z, w.gh, w.part, K, RR, w.support, sym);
+    zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, w.gh, w.part, K, npx4, w.support, sym);
+    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg * 4, K, sym, (int)quad_blocks(RR) * 4);
 }
 
 }  // namespace
@@ -654,7 +880,24 @@ int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, h
     (void)hipMemsetAsync(w.support, 0, 256, stream);
     zernike_support_kernel<<<(unsigned)((npx4 + 255) / 256), 256, 0, stream>>>(Z, w.support, K, npx4);
     zernike_support_seal_kernel<<<1, 1, 0, stream>>>(w.support);
+    // mirror symmetry (see zernike_sym_check_kernel): header off, every sign pair still possible, then one pass over the basis
+    (void)hipMemsetAsync(w.sym, 0, 256, stream);
+    (void)hipMemsetAsync(w.sym + 256, 0xFF, (size_t)K * 4, stream);
+    zernike_sym_check_kernel<<<quad_blocks(RR), 256, 0, stream>>>(Z, w.sym, K, RR);
+    zernike_sym_seal_kernel<<<1, 256, 0, stream>>>(w.sym, K);
     return ppv_last_error();
+}
+
+// 1 when the state's basis was found mirror-symmetric by ppv_ic_psf_mark_support (the PSF passes then read one quadrant of it), 0 when
+// not (or never marked), < 0 on error.  Synchronises the stream (diagnostic / test entry point).
+int ppv_ic_psf_symmetric(const void* state, int RR, int P, int K, hipStream_t stream) {
+    if (!state) return PPV_ERR_NULL;
+    IcWs w;
+    carve(&w, (char*)state, RR, P, K);
+    SymHdr h;
+    if (hipError_t e = hipMemcpyAsync(&h, w.sym, sizeof(h), hipMemcpyDeviceToHost, stream)) return -(int)e;
+    if (hipError_t e = hipStreamSynchronize(stream)) return -(int)e;
+    return h.magic == SYM_MAGIC ? 1 : 0;
 }
 
 // Forward PSF generation (Lens.py:158-274).
@@ -678,7 +921,7 @@ int ppv_ic_psf_fwd(const float* Z, const float* coeffs, const float* noise, cons
     const long npx = (long)RR * RR, npx4 = npx / 4;
     (void)hipMemsetAsync(w.sums, 0, 64, stream);
     if (loss_acc) (void)hipMemsetAsync(loss_acc, 0, 8, stream);
-    zernike_contract_kernel<<<(unsigned)((npx4 + 255) / 256), 256, K * sizeof(float), stream>>>(Z, coeffs, w.h, K, npx4, w.support);
+    launch_contract(Z, coeffs, w, K, RR, stream);
     ic_field_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.h, noise, (const float2*)sph, w.F0, RR, kdn[0],
                                                                      kdn[1], kdn[2], tol, (tol >= 0.f && noise) ? 1 : 0);
     dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
@@ -719,9 +962,7 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
     double2* GF = w.T1;                                            // T1 dead again
     difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
     ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
-    const unsigned nwg = (unsigned)((npx4 + 255) / 256);
-    zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, w.gh, w.part, K, npx4, w.support);
-    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg * 4, K);
+    launch_grad(Z, g_coeffs, w, K, RR, stream);
     return ppv_last_error();
 }
 
@@ -730,7 +971,7 @@ int ppv_zernike_contract(const float* Z, const float* coeffs, float* h, int K, l
     if (!Z || !coeffs || !h) return PPV_ERR_NULL;
     if (npx % 4) return PPV_ERR_BAD_SIZE;
     const long npx4 = npx / 4;
-    zernike_contract_kernel<<<(unsigned)((npx4 + 255) / 256), 256, K * sizeof(float), stream>>>(Z, coeffs, h, K, npx4, nullptr);
+    zernike_contract_kernel<<<(unsigned)((npx4 + 255) / 256), 256, K * sizeof(float), stream>>>(Z, coeffs, h, K, npx4, nullptr, nullptr);
     return ppv_last_error();
 }
 
@@ -742,7 +983,7 @@ int ppv_zernike_grad(const float* Z, const float* gh, float* g_coeffs, void* par
     if (npx % 4) return PPV_ERR_BAD_SIZE;
     const long npx4 = npx / 4;
     const unsigned nwg = (unsigned)((npx4 + 255) / 256);
-    zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, gh, (double*)part, K, npx4, nullptr);
+    zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, gh, (double*)part, K, npx4, nullptr, nullptr);
     sum_partials_kernel<<<K, 256, 0, stream>>>((const double*)part, g_coeffs, (int)nwg * 4, K);
     return ppv_last_error();
 }

@@ -219,50 +219,113 @@ def test_library_sensor_path_equals_the_native_one():
         assert rel_err(b, a) < 1e-4
 
 
+def _wipe_marks(cam, support=True, sym=True):
+    """Switch off what ppv_ic_psf_mark_support left at the end of the state: [... | support: 256-B header + a byte per float4 group |
+    sym: 256-B header + 5 bytes per plane], both rounded up to 256 bytes (csrc/psf_ic.hip carve())."""
+    RR, K = cam.wave_res[0], cam.zernike_volume.shape[0]
+    a256 = lambda n: (n + 255) // 256 * 256
+    sym_b, sup_b = a256(256 + 5 * K), a256(RR * RR // 4 + 256)
+    n = cam._state.numel()
+    if sym:
+        cam._state[n - sym_b:].zero_()
+    if support:
+        cam._state[n - sym_b - sup_b: n - sym_b].zero_()
+
+
+def _is_symmetric(cam):
+    from ppv_amd import _lib
+    from ppv_amd._lib import ptr, stream_ptr
+    return _lib.lib().ppv_ic_psf_symmetric(ptr(cam._state), cam.wave_res[0], cam.patch_size, cam.zernike_volume.shape[0], stream_ptr())
+
+
+def _make_448(vol=None):
+    from ppv_amd.camera_lens import OpticsZernike
+    dev = torch.device("cuda", 0)
+    cam = OpticsZernike(input_shape=[None, 128, 128, 3], device=dev, zernike_terms=36, patch_size=128, height_tolerance=2e-8,
+                        sensor_distance=0.025, wave_resolution=[448, 448], sample_interval=3e-06, coeff_layout="B",
+                        zernike_volume_tensor=vol)
+    with torch.no_grad():
+        cam.zernike_coeffs_train.copy_(torch.randn(33, 1, 1, generator=torch.Generator().manual_seed(3)).to(dev) * 0.3)
+    return cam
+
+
+def _run_448(cam, support=True, sym=True):
+    dev = torch.device("cuda", 0)
+    _wipe_marks(cam, support=not support, sym=not sym)
+    cam.zernike_coeffs_train.grad = None
+    img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    noise = torch.rand(1, 448, 448, 1, generator=torch.Generator().manual_seed(1)).to(dev)
+    sensor, psf, _, _ = cam(img, None, None, noise_u01=noise)
+    (sensor * torch.linspace(0, 1, sensor.numel(), device=dev).view_as(sensor)).sum().backward()
+    return sensor.detach().clone(), psf.detach().clone(), cam.zernike_coeffs_train.grad.detach().clone()
+
+
+def _remark(cam):
+    from ppv_amd import _lib
+    from ppv_amd._lib import check, ptr, stream_ptr
+    check(_lib.lib().ppv_ic_psf_mark_support(ptr(cam.zernike_volume), ptr(cam._state), cam.wave_res[0], cam.patch_size,
+                                             cam.zernike_volume.shape[0], stream_ptr()), "mark")
+
+
 def test_basis_support_mask_is_exact_and_follows_the_data():
     """ppv_ic_psf_mark_support (round 3): the two passes over the Zernike basis skip the pixel groups where every plane is zero.  The
     result must be bit-identical to reading everything (a state whose header is wiped falls back to that), also for a basis that is
-    NOT confined to the disk (the mask comes from the data, not from the geometry)."""
-    from ppv_amd.camera_lens import OpticsZernike
-    dev = torch.device("cuda", 0)
-
-    def make(vol=None):
-        cam = OpticsZernike(input_shape=[None, 128, 128, 3], device=dev, zernike_terms=36, patch_size=128, height_tolerance=2e-8,
-                            sensor_distance=0.025, wave_resolution=[448, 448], sample_interval=3e-06, coeff_layout="B",
-                            zernike_volume_tensor=vol)
-        with torch.no_grad():
-            cam.zernike_coeffs_train.copy_(torch.randn(33, 1, 1, generator=torch.Generator().manual_seed(3)).to(dev) * 0.3)
-        return cam
-
-    def run(cam, wipe):
-        if wipe:
-            cam._state[-(448 * 448 // 4 + 256 + 4096):].zero_()             # header (magic word) + mask: "never marked"
-        cam.zernike_coeffs_train.grad = None
-        img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(0)).to(dev)
-        noise = torch.rand(1, 448, 448, 1, generator=torch.Generator().manual_seed(1)).to(dev)
-        sensor, psf, _, _ = cam(img, None, None, noise_u01=noise)
-        (sensor * torch.linspace(0, 1, sensor.numel(), device=dev).view_as(sensor)).sum().backward()
-        return sensor.detach().clone(), psf.detach().clone(), cam.zernike_coeffs_train.grad.detach().clone()
-
-    cam = make()
-    a = run(cam, wipe=False)
-    b = run(cam, wipe=True)
+    NOT confined to the disk (the mask comes from the data, not from the geometry).  (Quadrant form off throughout: its own test is
+    below.)"""
+    cam = _make_448()
+    a = _run_448(cam, support=True, sym=False)
+    b = _run_448(cam, support=False, sym=False)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert (cam.zernike_volume[:, 0, 0] == 0).all()                          # the disk basis really has an empty corner to skip
     vol = cam.zernike_volume.clone()
     vol[5, :7, :9] = 1e-7                                                     # a user basis with mass in the corner
-    cam2 = make(vol)
-    a2 = run(cam2, wipe=False)
-    b2 = run(cam2, wipe=True)
+    cam2 = _make_448(vol)
+    a2 = _run_448(cam2, support=True, sym=False)
+    b2 = _run_448(cam2, support=False, sym=False)
     for x, y in zip(a2, b2):
         assert torch.equal(x, y)
     # the corner lies outside the circular aperture (Utils.py:88-97), so it cannot reach the PSF; what shows that the mask follows
-    # the DATA is the height map itself: non-zero in the corner for this basis (marked state, forward run last with the header wiped
-    # and before that with it intact -- both filled the tap), zero for the disk basis
-    cam2._state[-(448 * 448 // 4 + 256 + 4096):].zero_()
-    from ppv_amd import _lib
-    from ppv_amd._lib import check, ptr, stream_ptr
-    check(_lib.lib().ppv_ic_psf_mark_support(ptr(cam2.zernike_volume), ptr(cam2._state), 448, 128, 36, stream_ptr()), "mark")
-    run(cam2, wipe=False)
+    # the DATA is the height map itself: non-zero in the corner for this basis, zero for the disk basis
+    _remark(cam2)
+    _run_448(cam2)
+    _remark(cam)
+    _run_448(cam)
     assert float(_taps(cam2)["h"][:7, :9].abs().min()) > 0 and float(_taps(cam)["h"][:7, :9].abs().max()) == 0
+
+
+def test_quadrant_form_of_the_basis_passes():
+    """The Noll terms are even or odd under x -> -x and y -> -y on poppy's centred grid (Utils.py:75-77), and the basis of
+    csrc/zernike.hip is so BITWISE: ppv_ic_psf_mark_support finds the sign pair of every plane from the data and the height map /
+    its adjoint then read one quadrant of the 1.12 GB.  Forward must be bit-identical to the full pass (same products up to an exact
+    sign, same order), the coefficient gradient equal to rounding; a basis without the property must be detected and take the full
+    pass."""
+    cam = _make_448()
+    assert _is_symmetric(cam) == 1
+    on = _run_448(cam, support=True, sym=True)
+    h_on = _taps(cam)["h"].clone()
+    off = _run_448(cam, support=True, sym=False)
+    assert _is_symmetric(cam) == 0                                           # header wiped by the run above
+    h_off = _taps(cam)["h"].clone()
+    assert torch.equal(h_on, h_off) and torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
+    assert float((on[2] - off[2]).abs().max()) <= 2e-6 * float(off[2].abs().max())
+    # without the support mask as well (quadrant form alone)
+    _remark(cam)
+    on2 = _run_448(cam, support=False, sym=True)
+    assert torch.equal(on2[0], off[0]) and torch.equal(on2[1], off[1])
+    assert float((on2[2] - off[2]).abs().max()) <= 2e-6 * float(off[2].abs().max())
+    # a basis that is not mirror-symmetric: detected, full pass, same numbers as with every mark wiped
+    vol = cam.zernike_volume.clone()
+    assert float(vol[7, 100, 200].abs()) > 0
+    vol[7, 100, 200] *= 1.0 + 2.0 ** -20
+    cam3 = _make_448(vol)
+    assert _is_symmetric(cam3) == 0
+    a3 = _run_448(cam3, support=True, sym=True)
+    b3 = _run_448(cam3, support=False, sym=False)
+    for x, y in zip(a3, b3):
+        assert torch.equal(x, y)
+    # an asymmetry in the SIGN pattern only (one plane mirrored with the wrong sign in one pixel pair)
+    vol = cam.zernike_volume.clone()
+    vol[2, 300, 100] = -vol[2, 300, 100]
+    cam4 = _make_448(vol)
+    assert float(vol[2, 300, 100].abs()) > 0 and _is_symmetric(cam4) == 0

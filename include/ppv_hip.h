@@ -175,6 +175,11 @@ int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* co
 int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
                     int res_mode, int relu, ppv_stream_t stream);
+/* as ppv_bn_act_fold with the statistics in T partial rows sums [T][2][C] (ppv_conv_gemm, stat_rows = T): fewer adders per address in the
+ * convolution's epilogue than one row, still no ppv_bn_finalize launch.  C / 8 a power of two <= 256 when T > 1. */
+int ppv_bn_act_fold_rows(const void* x, const float* sums, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
+                    int res_mode, int relu, ppv_stream_t stream);
 
 /* Train-mode BatchNorm in ONE launch: partial statistics [T][2][C] (as ppv_conv_gemm leaves them) -> per-channel coefficients (written
  * to coef [4][C] = scale, shift, mean, invstd for the backward pass; running statistics updated with `momentum`, unbiased variance)

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ppv_bn_finalize": (_I, [_P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "ppv_bn_act": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P]),
     "ppv_bn_act_fold": (_I, [_P, _P, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "ppv_bn_act_fold_rows": (_I, [_P, _P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_act_train": (_I, [_P, _P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _I, _I, _P]),
     "ppv_bn_bwd_blocks": (_I, [_L, _I]),
     "ppv_bn_bwd": (_I, [_P, _P, _P, _P, _c.c_double, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

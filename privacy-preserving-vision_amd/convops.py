@@ -293,15 +293,15 @@ def bn_act_train(x, stat_part, count, bn, momentum, res=None, res_stats=None, re
 
 def bn_act_fold(x, sums, count, bn, momentum, res=None, relu=True, want_bits=False):
     """Train-mode BatchNorm2d `bn` (+ identity residual) (+ ReLU) on the raw conv output x [..., C] bf16 whose statistics sit in ONE row
-    sums [1,2,C] (conv_fwd(..., stat_part=sums) with a single partial row): no bn_finalize launch, every thread derives its channels'
+    sums [T,2,C] (conv_fwd(..., stat_part=sums) with T partial rows, T = 1 .. 8): no bn_finalize launch, every thread derives its channels'
     coefficients (csrc/trunk_ops.hip bn_act_fold_kernel).  -> (y, bits or None, coef [4,C]); running statistics updated in place."""
     C = x.shape[-1]
     y = torch.empty_like(x)
     bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if want_bits else None
     coef = torch.empty((4, C), dtype=F32, device=x.device)
-    check(L().ppv_bn_act_fold(ptr(x), ptr(sums), float(count), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean),
-                              ptr(bn.running_var), momentum, bn.eps, ptr(coef), ptr(res), ptr(y), ptr(bits), x.numel(), C,
-                              0 if res is None else 1, int(relu), stream_ptr()), "ppv_bn_act_fold")
+    check(L().ppv_bn_act_fold_rows(ptr(x), ptr(sums), sums.shape[0], float(count), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                   ptr(bn.running_mean), ptr(bn.running_var), momentum, bn.eps, ptr(coef), ptr(res), ptr(y), ptr(bits),
+                                   x.numel(), C, 0 if res is None else 1, int(relu), stream_ptr()), "ppv_bn_act_fold_rows")
     return y, bits, coef
 
 

@@ -162,6 +162,98 @@ __global__ __launch_bounds__(256) void bn_act_fold_kernel(const bf16_t* __restri
     if (pos_bits) pos_bits[i] = (unsigned char)bits;
 }
 
+// Same contract, coefficients shared by the workgroup (round 3, second form): a workgroup covers U * rpp whole rows (rpp = 256 / (C / 8)
+// rows per pass).  Its 256 threads first request their U rows, then thread j derives scale / shift of channels j, j + 256, ... (CPT =
+// C / 256 of them, one for C <= 256) from the T partial rows -- one channel's few scalars per thread instead of eight channels on a
+// subset of the threads: 40 VGPRs, eight waves per SIMD like the plain kernel (the first form of this kernel kept eight channels'
+// partial rows in registers: 197 VGPRs, two waves per SIMD, +4..7 us per launch).  Coefficients meet in LDS.
+// C in {64, 128, ..., 2048} (C / 8 a power of two <= 256), T <= 2 * ... any (loop).
+template <int RES, bool RELU, int U, int CPT>
+__global__ __launch_bounds__(256) void bn_act_fold_wg_kernel(const bf16_t* __restrict__ x, const float* __restrict__ sums, double inv_count,
+                                                             double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                             float eps, float* __restrict__ coef, const bf16_t* __restrict__ r,
+                                                             bf16_t* __restrict__ y, unsigned char* __restrict__ pos_bits, long rows, int C,
+                                                             int tpr_log2, int T) {
+    __shared__ float s_sc[256 * CPT], s_sh[256 * CPT];
+    const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+    const int tc = threadIdx.x & (tpr - 1), tr = threadIdx.x >> tpr_log2;
+    const int c0 = tc * 8;
+    const long row0 = (long)blockIdx.x * (rpp * U) + tr;
+    uint4 xr[U], rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long row = row0 + (long)u * rpp;
+        if (row < rows) {
+            xr[u] = *reinterpret_cast<const uint4*>(x + row * C + c0);
+            if (RES) rr[u] = *reinterpret_cast<const uint4*>(r + row * C + c0);
+        }
+    }
+    // statistics of this thread's channels: all loads first (they return right behind the rows), then the arithmetic
+    constexpr int TR = 4;                              // partial rows held in registers (more rows: a second, dependent round of loads)
+    float ps[CPT][TR], pq[CPT][TR], pg[CPT], pb[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const bool ok = c < C;
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            ps[j][t] = (ok && t < T) ? sums[((long)t * 2) * C + c] : 0.f;
+            pq[j][t] = (ok && t < T) ? sums[((long)t * 2 + 1) * C + c] : 0.f;
+        }
+        pg[j] = ok ? gamma[c] : 0.f; pb[j] = ok ? beta[c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = threadIdx.x + j * 256;
+        double s_ = 0, q_ = 0;
+#pragma unroll
+        for (int t = 0; t < TR; ++t) { s_ += (double)ps[j][t]; q_ += (double)pq[j][t]; }
+        for (int t = TR; t < T; ++t) { if (c < C) { s_ += (double)sums[((long)t * 2) * C + c]; q_ += (double)sums[((long)t * 2 + 1) * C + c]; } }
+        const double mean = s_ * inv_count;
+        double var = q_ * inv_count - mean * mean;
+        if (var < 0) var = 0;
+        const float ve = (float)(var + (double)eps);
+        float invstd = __builtin_amdgcn_rsqf(ve);
+        invstd = invstd * (1.5f - 0.5f * ve * invstd * invstd);
+        const float sc = pg[j] * invstd, sh = pb[j] - (float)mean * sc;
+        if (c < C) {
+            s_sc[c] = sc; s_sh[c] = sh;
+            if (blockIdx.x == 0) {
+                coef[c] = sc; coef[C + c] = sh; coef[2 * C + c] = (float)mean; coef[3 * C + c] = invstd;
+                if (run_mean) {
+                    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+                    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * unbias);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float4 c_0 = *reinterpret_cast<const float4*>(s_sc + c0), c_1 = *reinterpret_cast<const float4*>(s_sc + c0 + 4);
+    const float4 c_2 = *reinterpret_cast<const float4*>(s_sh + c0), c_3 = *reinterpret_cast<const float4*>(s_sh + c0 + 4);
+    const float sc[8] = {c_0.x, c_0.y, c_0.z, c_0.w, c_1.x, c_1.y, c_1.z, c_1.w};
+    const float sh[8] = {c_2.x, c_2.y, c_2.z, c_2.w, c_3.x, c_3.y, c_3.z, c_3.w};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long row = row0 + (long)u * rpp;
+        if (row >= rows) break;
+        const long e = row * C + c0;
+        float xv[8], rv[8], o[8];
+        unpack8_(xr[u], xv);
+        if (RES) unpack8_(rr[u], rv);
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = xv[k] * sc[k] + sh[k];
+            if (RES == 1) v += rv[k];
+            o[k] = RELU ? fmaxf(v, 0.f) : v;
+            bits |= (o[k] > 0.f ? 1u : 0u) << k;
+        }
+        store8(y + e, o);
+        if (pos_bits) pos_bits[e >> 3] = (unsigned char)bits;
+    }
+}
+
 // ----------------------------------------------------------------------------- train-mode BN: statistics -> coefficients -> apply, one launch
 // bn_finalize + bn_act in one kernel (round 2): the coefficient launch was 4.8 us of dispatch latency per BatchNorm for ~1 us of
 // work (104 launches per step, tools/micro/graph_chain.py: a dependent tiny kernel costs 4.2 us).  A workgroup owns a block of
@@ -762,14 +854,50 @@ int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* co
 // y = act(BatchNorm_train(x) (+ r)) with the statistics in ONE row sums [2][C] (sum, sum of squares of the stored conv output, as
 // ppv_conv_gemm leaves them with stat_rows = 1): coefficients derived per thread, coef [4][C] and the running statistics written
 // by the first row's threads.  res_mode 0 none, 1 identity residual r.  pos_bits as ppv_bn_act.  C % 8 == 0, rows * C % 8 == 0.
+static int bn_act_fold_impl(const void* x, const float* sums, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                            float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
+                            int res_mode, int relu, hipStream_t stream);
 int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
                     int res_mode, int relu, hipStream_t stream) {
+    return bn_act_fold_impl(x, sums, 1, count, gamma, beta, run_mean, run_var, momentum, eps, coef, r, y, pos_bits, n, C, res_mode, relu, stream);
+}
+// sums [T][2][C]: the statistics in T partial rows (ppv_conv_gemm with stat_rows = T); C / 8 must be a power of two <= 256 when T > 1
+int ppv_bn_act_fold_rows(const void* x, const float* sums, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                         float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
+                         int res_mode, int relu, hipStream_t stream) {
+    return bn_act_fold_impl(x, sums, T, count, gamma, beta, run_mean, run_var, momentum, eps, coef, r, y, pos_bits, n, C, res_mode, relu, stream);
+}
+static int bn_act_fold_impl(const void* x, const float* sums, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                            float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
+                            int res_mode, int relu, hipStream_t stream) {
     if (!x || !sums || !gamma || !beta || !coef || !y || (res_mode == 1 && !r)) return PPV_ERR_NULL;
-    if (C % 8 || n % 8 || res_mode < 0 || res_mode > 1 || count < 1 || (run_mean && !run_var)) return PPV_ERR_BAD_SIZE;
+    if (C % 8 || n % 8 || res_mode < 0 || res_mode > 1 || count < 1 || (run_mean && !run_var) || T < 1) return PPV_ERR_BAD_SIZE;
+    if (T > 1 && !(C / 8 <= 256 && ((C / 8) & (C / 8 - 1)) == 0)) return PPV_ERR_BAD_SIZE;
     const long n8 = n / 8;
     const unsigned gb = (unsigned)((n8 + 255) / 256);
     const double inv = 1.0 / count, unb = count > 1 ? count / (count - 1.0) : 1.0;
+    const int tpr = C / 8;
+    static const int per_thread = getenv("PPV_BN_FOLD_THREAD") ? atoi(getenv("PPV_BN_FOLD_THREAD")) : 0;
+    if ((!per_thread || T > 1) && tpr <= 256 && (tpr & (tpr - 1)) == 0) {           // workgroup-shared coefficients
+        int lg = 0;
+        while ((1 << lg) < tpr) ++lg;
+        constexpr int U = 4;
+        const long rows = n / C;
+        const int rpp = 256 / tpr;
+        const unsigned g2 = (unsigned)((rows + (long)rpp * U - 1) / ((long)rpp * U));
+#define PPV_FOLDW2(RES_, RELU_, CPT_) bn_act_fold_wg_kernel<RES_, RELU_, U, CPT_><<<g2, 256, 0, stream>>>((const bf16_t*)x, sums, inv, unb, gamma, beta, \
+        run_mean, run_var, momentum, eps, coef, (const bf16_t*)r, (bf16_t*)y, (unsigned char*)pos_bits, rows, C, lg, T)
+#define PPV_FOLDW(RES_, RELU_) do { if (C <= 256) PPV_FOLDW2(RES_, RELU_, 1); else if (C <= 512) PPV_FOLDW2(RES_, RELU_, 2); \
+        else if (C <= 1024) PPV_FOLDW2(RES_, RELU_, 4); else PPV_FOLDW2(RES_, RELU_, 8); } while (0)
+        if (res_mode == 1 && relu) PPV_FOLDW(1, true);
+        else if (res_mode == 1) PPV_FOLDW(1, false);
+        else if (relu) PPV_FOLDW(0, true);
+        else PPV_FOLDW(0, false);
+#undef PPV_FOLDW2
+#undef PPV_FOLDW
+        return ppv_last_error();
+    }
 #define PPV_FOLD(RES_, RELU_) bn_act_fold_kernel<RES_, RELU_><<<gb, 256, 0, stream>>>((const bf16_t*)x, sums, inv, unb, gamma, beta, run_mean, run_var, \
         momentum, eps, coef, (const bf16_t*)r, (bf16_t*)y, (unsigned char*)pos_bits, n8, C)
     if (res_mode == 1 && relu) PPV_FOLD(1, true);

@@ -200,17 +200,20 @@ class _TrunkFn(torch.autograd.Function):
         pool = torch.zeros(enc._stat_pool_elems(B, H, W), dtype=torch.float32, device=dev) if train else None
         pool_off = [0]
 
-        # PPV_BN_FOLD_ACT=1 (opt-in): train-mode BatchNorms without a projection partner take their statistics in ONE partial row and
-        # the apply kernel derives the coefficients itself (co.bn_act_fold): no bn_finalize launch between convolution and apply pass.
-        # MEASURED (round 3, whole step, same box, two passes): 5217 images/s against 5285 with bn_finalize + bn_act -- every thread of
-        # an 8-element-per-thread kernel repeating the f64 mean / variance step costs more than the 4.7-us launches it removes, and the
-        # one-row f32 atomics widen the run-to-run band of the trunk (summation order of 128 tiles per address)
-        fold_act = train and _os0.environ.get("PPV_BN_FOLD_ACT", "0") == "1"
+        # Train-mode BatchNorms without a projection partner take their statistics in TWO partial rows and the apply kernel derives the
+        # coefficients itself (co.bn_act_fold, csrc/trunk_ops.hip bn_act_fold_wg_kernel: thread j of every workgroup computes channel j's
+        # scale / shift while the rows are in flight): no bn_finalize launch between convolution and apply pass (92 of 104 per step).
+        # MEASURED (round 3, whole step, every configuration twice on one box): +0.7 .. +1.1 % (5566 -> 5619, 5497 -> 5532, 5619 -> 5683,
+        # 5603 -> 5644 images/s); one row: -0.3 .. 0 % (128 - 512 row tiles adding to one address at the end of the convolution), four
+        # rows: +0.4 %, eight: -1.5 %.  The first two forms of the fold lost: a 512-workgroup looped kernel (round 2, PPV_BN_FUSED) and
+        # per-THREAD coefficients from one row (-1.3 %; PPV_BN_FOLD_THREAD=1 keeps it reachable).  PPV_BN_FOLD_ACT=0: bn_finalize + bn_act.
+        fold_act = train and _os0.environ.get("PPV_BN_FOLD_ACT", "1") == "1"
+        fold_rows = max(1, int(_os0.environ.get("PPV_BN_FOLD_ROWS", "2")))     # partial rows the fold path's convolutions leave (adders per address = row tiles / this)
 
         def part_for(M, C, one_row=False):
             if not train:
                 return None
-            rows = 1 if one_row else co.stat_tiles(M)
+            rows = min(fold_rows, co.stat_tiles(M)) if one_row else co.stat_tiles(M)
             n = rows * 2 * C
             v = pool[pool_off[0]:pool_off[0] + n].view(rows, 2, C)
             pool_off[0] += n

@@ -81,6 +81,7 @@ def test_resnet101_stagewise_forward_backward():
     pblocks = [b for li in range(4, 8) for b in enc.resnet[li]]
     assert len(oblocks) == 33 == len(fn.blocks) == len(taps)
     worst_f = worst_b = worst_p = 0.0
+    worst_where = None
     for ob, pb, sv, (g_out_blk, g_in_blk) in zip(oblocks, pblocks, fn.blocks, taps):
         xin, yout = sv[0], sv[11]
         xo = _nchw(xin).requires_grad_(True)
@@ -98,11 +99,17 @@ def test_resnet101_stagewise_forward_backward():
         po = dict(ob.named_parameters())
         for n, p in pb.named_parameters():
             if p.requires_grad:
-                worst_p = max(worst_p, _l2(p.grad, po[n].grad))
+                e_ = _l2(p.grad, po[n].grad)
+                if e_ > worst_p:
+                    worst_p, worst_where = e_, (n, tuple(xin.shape))
             else:
                 assert p.grad is None
-    print(f"stage-wise worst: fwd {worst_f:.2e}  d_in {worst_b:.2e}  d_param {worst_p:.2e}")
-    assert worst_f < 1e-2 and worst_b < 5e-2 and worst_p < 5e-2
+    print(f"stage-wise worst: fwd {worst_f:.2e}  d_in {worst_b:.2e}  d_param {worst_p:.2e} at {worst_where}")
+    # d_param: the worst entries are always BatchNorm bias gradients of layers 3 / 4 at THIS size (sums of a bf16 gradient over 64 / 16
+    # samples: cancellation); with the statistics folded by f32 atomics in two partial rows (default since round 3) the run-to-run
+    # band of that maximum is 2.6e-2 .. 5.2e-2 (bn_finalize path: 2.9e-2, deterministic at this size).  The B = 128 test below keeps
+    # 5e-2 on every parameter.
+    assert worst_f < 1e-2 and worst_b < 5e-2 and worst_p < 8e-2
     # ---- head: adaptive pool (2x2 -> 36x36) and its gradient
     last = fn.blocks[-1][11]
     assert rel_err(out, _nhwc(F.adaptive_avg_pool2d(_nchw(last), 36))) < 1e-6
@@ -164,6 +171,9 @@ def test_fused_bn_backward_sums_agree_with_the_separate_reduce(fine_tune, monkey
     (PPV_DGRAD_BNRED=0): same gradients up to the summation order; also covers the all-frozen trunk (fine_tune(False))."""
     from ppv_amd.encoder import Encoder
     torch.manual_seed(0)
+    # one adder per address in the forward statistics (as many partial rows as row tiles): the two runs then see the SAME forward and
+    # differ in the backward sums only (with the default two rows the f32 atomics' order varies, and a random-init trunk amplifies that)
+    monkeypatch.setenv("PPV_BN_FOLD_ROWS", "32")
     enc = Encoder(layers=(1, 2, 1, 1)).cuda().train()
     enc.fine_tune(fine_tune)
     img = torch.rand(3, 3, 128, 128, generator=torch.Generator().manual_seed(3)).cuda()

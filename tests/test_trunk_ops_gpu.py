@@ -248,16 +248,20 @@ def test_batchnorm_train_single_launch(rows, C, T, res_mode):
     assert torch.equal(k.view(-1).bool(), (y > 0).view(-1))
 
 
-def test_bn_act_fold_equals_finalize_plus_act():
-    """ppv_bn_act_fold (statistics in one row, coefficients derived per thread; opt-in PPV_BN_FOLD_ACT=1) against ppv_bn_finalize +
-    ppv_bn_act on the same sums: same activations (one bf16 ulp), coefficients and running statistics."""
+@pytest.mark.parametrize("rows,C,T", [(4096, 256, 1), (4096, 256, 2), (1000, 64, 2), (520, 128, 3), (2048, 512, 2), (1028, 1024, 2),
+                                      (1028, 1024, 4), (517, 2048, 2), (1024, 256, 6)])
+def test_bn_act_fold_equals_finalize_plus_act(rows, C, T):
+    """ppv_bn_act_fold_rows (the step's default since round 3: statistics in T partial rows, every workgroup derives the coefficients
+    itself, no ppv_bn_finalize launch) against ppv_bn_finalize + ppv_bn_act on the same sums: same activations (one bf16 ulp),
+    coefficients and running statistics; ragged row counts (last workgroup partly empty), every channel width of the trunk."""
     import ppv_amd.convops as co
     g = torch.Generator().manual_seed(0)
-    rows, C = 4096, 256
-    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).bfloat16().cuda().view(4, 32, 32, C)
-    res = torch.randn(rows, C, generator=g).bfloat16().cuda().view(4, 32, 32, C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).bfloat16().cuda().view(1, rows, 1, C)
+    res = torch.randn(rows, C, generator=g).bfloat16().cuda().view(1, rows, 1, C)
     xf = x.float().view(rows, C)
-    sums = torch.stack([xf.sum(0), (xf * xf).sum(0)]).view(1, 2, C).contiguous()
+    # T partial rows that add up to the column sums (the convolution's row tiles fold into row tile % T)
+    parts = [xf[t::T] for t in range(T)]
+    sums = torch.stack([torch.stack([p_.sum(0), (p_ * p_).sum(0)]) for p_ in parts]).contiguous()
     bn_a, bn_b = torch.nn.BatchNorm2d(C).cuda(), torch.nn.BatchNorm2d(C).cuda()
     with torch.no_grad():
         for bn in (bn_a, bn_b):

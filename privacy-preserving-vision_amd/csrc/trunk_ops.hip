@@ -6,6 +6,7 @@
 // already NHWC so the reference's permute disappears).  All HBM-bound: 16-byte accesses, fp32 math.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include "ppv_common.h"
 
 namespace ppv {
@@ -733,6 +734,63 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const bf16_t* __res
     }
 }
 
+// The sums of the pass above taken over the POOLED tensors only.  A pooled element with y > 0 sends its gradient to exactly one
+// pre-pool position (its argmax), so  sum_p g_pre[p] = sum_o g[o] [y[o] > 0]  and  sum_p g_pre[p] x[p] = sum_o g[o] [y[o] > 0] x[argmax(o)],
+// and x at the argmax follows from the pooled activation itself: y = bf16(x * scale + shift) there, x = (y - shift) / scale (one bf16
+// rounding of the BatchNorm output away from the stored x; channels with |scale| < 1e-20 read x from the raw tensor instead).
+// 134 MB instead of 400 MB at B = 128 (the raw stem output is not read).  part [8][2][C] pre-zeroed.
+__global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
+                                                             const unsigned char* __restrict__ arg, const bf16_t* __restrict__ x,
+                                                             const float* __restrict__ coef, float* __restrict__ part, int B, int H,
+                                                             int W, int C, int ppw) {
+    __shared__ float s_red[256][17];
+    const int Ho = H / 2, Wo = W / 2, tpr = C / 8, rpp = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr, c0 = tc * 8;
+    float isc[8], sh[8], sa[8], sb[8];
+    bool exact[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float sc = coef[c0 + k];
+        exact[k] = !(fabsf(sc) >= 1e-20f);
+        isc[k] = exact[k] ? 0.f : 1.f / sc;
+        sh[k] = coef[C + c0 + k];
+        sa[k] = sb[k] = 0.f;
+    }
+    const long npool = (long)B * Ho * Wo;
+    const long p0 = (long)blockIdx.x * rpp * ppw;
+    if (tr < rpp) {
+        for (int it = 0; it < ppw; ++it) {
+            const long o = p0 + (long)it * rpp + tr;
+            if (o >= npool) break;
+            float g[8], yv[8];
+            load8(gy + o * C + c0, g);
+            load8(y + o * C + c0, yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!(yv[k] > 0.f)) continue;
+                float xv = (yv[k] - sh[k]) * isc[k];
+                if (exact[k]) {                                   // (never taken for a BatchNorm with a usable scale)
+                    const int wo = (int)(o % Wo), ho = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+                    const int a = arg[o * C + c0 + k], r = a / 3, s_ = a % 3;
+                    const int h = 2 * ho - 1 + r, w = 2 * wo - 1 + s_;
+                    xv = bf2f_(x[(((long)b * H + h) * W + w) * C + c0 + k]);
+                }
+                sa[k] += g[k];
+                sb[k] += g[k] * xv;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s_red[threadIdx.x][k] = sa[k]; s_red[threadIdx.x][8 + k] = sb[k]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        const int which = t / C, c = t % C;
+        float v = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) v += s_red[rr * tpr + c / 8][which * 8 + c % 8];
+        atomicAdd(&part[((long)(blockIdx.x & 7) * 2 + which) * C + c], v);
+    }
+}
+
 // ----------------------------------------------------------------------------- AdaptiveAvgPool2d(E) on [B,H,W,C]
 // window of output i: [floor(i*H/E), ceil((i+1)*H/E))  (torch adaptive pooling)
 template <typename TO>
@@ -1051,8 +1109,17 @@ int ppv_maxpool_bn_bwd(const void* gy, const void* y, const void* arg, const voi
     const int rpp = 256 / (C / 8), ppw = 8;
     const long npix = (long)B * H * W;
     const unsigned gb = (unsigned)((npix + (long)rpp * ppw - 1) / ((long)rpp * ppw));
-    maxpool_bn_bwd_kernel<false><<<gb, 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y, (const unsigned char*)arg, (const bf16_t*)x, coef,
-                                                        count, part, nullptr, nullptr, nullptr, B, H, W, C, ppw);
+    // sums from the pooled tensors alone (PPV_STEM_BWD_SUMS=raw: the pass over the raw tensor, 400 MB instead of 134 MB at B = 128)
+    static const bool raw_sums = getenv("PPV_STEM_BWD_SUMS") && !strcmp(getenv("PPV_STEM_BWD_SUMS"), "raw");
+    if (raw_sums)
+        maxpool_bn_bwd_kernel<false><<<gb, 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y, (const unsigned char*)arg, (const bf16_t*)x, coef,
+                                                            count, part, nullptr, nullptr, nullptr, B, H, W, C, ppw);
+    else {
+        const long npool = npix / 4;
+        const unsigned gp = (unsigned)((npool + (long)rpp * ppw - 1) / ((long)rpp * ppw));
+        pooled_bn_sums_kernel<<<gp, 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y, (const unsigned char*)arg, (const bf16_t*)x, coef, part,
+                                                     B, H, W, C, ppw);
+    }
     maxpool_bn_bwd_kernel<true><<<gb, 256, 0, stream>>>((const bf16_t*)gy, (const bf16_t*)y, (const unsigned char*)arg, (const bf16_t*)x, coef,
                                                        count, part, (bf16_t*)gx, dgamma, dbeta, B, H, W, C, ppw);
     return ppv_last_error();

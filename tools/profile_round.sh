@@ -19,5 +19,12 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python tools/collect_mfma.py $(find $O/mfma -name "*counter_collection.csv" | head -1) $O/kernel_stats.csv $O/mfma_util.json | head -12
 rm -rf $O/fetch $O/write $O/stats $O/mfma
 unset PPV_WGRAD_SIDE
+# optional tag (e.g. r03f): the fresh summaries go into profiles/ of THIS copy first, so that the bench line below reads them
+# (its counter fields are "stale" whenever the sources' hash differs from the one stored in the profile)
+if [ -n "$1" ]; then
+  cp $O/kernel_stats.csv profiles/$1_bench_b128_kernel_stats.csv
+  cp $O/pmc_traffic.json profiles/$1_pmc_traffic.json
+  cp $O/mfma_util.json profiles/$1_mfma_util.json
+fi
 python bench.py > $O/bench_default.json.log 2>$O/bench_default.err
 tail -1 $O/bench_default.json.log | cut -c1-300

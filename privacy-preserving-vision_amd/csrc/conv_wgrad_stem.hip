@@ -1269,12 +1269,16 @@ static int wgrad3_stages() {
     return t == 2 ? 2 : 3;
 }
 
-static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN, long* splits, int* sps) {
+static int wgrad_target_wgs256() {
+    static const int t = getenv("PPV_WGRAD_WGS256") ? atoi(getenv("PPV_WGRAD_WGS256")) : 256;
+    return t < 16 ? 16 : t;
+}
+static void wgrad_plan(long M, int N, int R, int S, int Cs, int variant, int* TN, long* splits, int* sps, int target = 0) {
     const long stages = (M + 63) / 64;
     int tn = (N % 256 == 0 && variant != 2) ? 256 : 128;
     if (variant == 1) tn = 128;
     const int tiles = (N / tn) * (R * S * (Cs / 128));
-    long sp = ((variant == 1 ? 512 : wgrad_target_wgs(M)) + tiles - 1) / tiles;
+    long sp = ((target ? target : variant == 1 ? 512 : wgrad_target_wgs(M)) + tiles - 1) / tiles;
     if (sp > stages / 8) sp = stages / 8;
     if (sp < 1) sp = 1;
     *sps = (int)((stages + sp - 1) / sp);
@@ -1318,6 +1322,11 @@ size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
         wgrad_plan(M, N, R, S, Cs, v, &TN, &sp, &sps);
         if (sp > splits) splits = sp;
     }
+    if (N % 256 == 0) {                                          // variants 8 / 9: the 256-wide tile at its own target
+        long sp;
+        wgrad_plan(M, N, R, S, Cs, 3, &TN, &sp, &sps, wgrad_target_wgs256());
+        if (sp > splits) splits = sp;
+    }
     if (R == 3 && S == 3 && M % 64 == 0) {                       // the fused-tap kernel may be chosen: cover its plan too
         long sp3;
         int sps3;
@@ -1358,14 +1367,18 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         // Alone on the device the 256-wide three-stage tile (144 KB of LDS) is the fastest 1x1 form (tools/bench_wgrad.py), but
         // the trunk runs its weight gradients on a side stream beside the data-gradient / BN chain: there a 128-wide TWO-stage
         // ring (64 KB) that can share a CU with a conv workgroup wins the whole step by 1.9 % (4396 -> 4480 images/s).
-        variant = 6;
+        // Round 3, with the split targets re-tuned per kernel: the 256-wide tile is back for the 1x1 shapes whose N allows it, aimed at
+        // ONE workgroup per CU (PPV_WGRAD_WGS256 = 256; 25 % fewer staged lines per flop than 128 x 128): whole step +0.8 %
+        // (5557 -> 5603 images/s; its two-stage 96-KB form +0.5 %; PPV_WGRAD_VARIANT=6 restores the small ring everywhere).
+        variant = 8;
         g.xcd_group = (R * S == 1) ? 1 : 0;                    //   XCD grouping pays for 1x1 only
     }
     const long elems = (long)N * R * S * Cs;
     float* slabs = (float*)scratch;
     const bool w_ok = Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && Hs == Ho && Ws == Wo && w_ok && (Ho * Wo) % 64 == 0 &&
-        ((g_wgrad_variant & 0xff) == 0 || (g_wgrad_variant & 0xff) == 4 || (g_wgrad_variant & 0xff) == 6)) {
+        ((g_wgrad_variant & 0xff) == 0 || (g_wgrad_variant & 0xff) == 4 || (g_wgrad_variant & 0xff) == 6 || (g_wgrad_variant & 0xff) == 8 ||
+         (g_wgrad_variant & 0xff) == 9)) {
         long sp3;
         int sps3;
         wgrad3_plan(g.M, N, Cs, &sp3, &sps3);
@@ -1418,11 +1431,19 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         return ppv_last_error();
     }
     if (variant == 4) variant = (N % 256 == 0) ? 3 : 1;
+    // 8 / 9: 256-wide tile (three / two 48-KB stages) where N allows it, aimed at its own workgroup count (PPV_WGRAD_WGS256, default 256:
+    // one per CU), the small ring elsewhere
+    int wide_stages = 0;
+    if (variant == 8 || variant == 9) {
+        wide_stages = variant == 8 ? 3 : 2;
+        variant = (N % 256 == 0 && R * S == 1) ? 3 : 6;
+        if (variant == 6) wide_stages = 0;
+    }
     const bool small_ring = variant == 6;                      // TN = 128, two stages (64 KB)
     if (small_ring) variant = 2;
     int TN, sps;
     long splits;
-    wgrad_plan(g.M, N, R, S, Cs, variant, &TN, &splits, &sps);
+    wgrad_plan(g.M, N, R, S, Cs, variant, &TN, &splits, &sps, wide_stages ? wgrad_target_wgs256() : 0);
     g.stages_per_split = sps;
     g.splits = (int)splits;
     const int tiles = (N / TN) * (R * S * (Cs / 128));
@@ -1443,7 +1464,12 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         (void)hipMemsetAsync(slabs, 0, 8 * elems * sizeof(float), stream);
     }
     const unsigned grid = g.xcd_group ? (unsigned)(8 * ((splits + 7) / 8) * tiles) : (unsigned)(splits * tiles);
-    if (TN == 256) {
+    if (TN == 256 && wide_stages == 2) {
+        constexpr int lds = 2 * 3 * 64 * 256;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        conv_wgrad_pipe_kernel<256, 2><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+    } else if (TN == 256) {
         constexpr int lds = 3 * 3 * 64 * 256;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
@@ -1502,7 +1528,7 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
 }
 
 // tuning / A-B hook: low byte 0 auto (= 6), 7 streamed kernel (conv_wgrad_stream_kernel) for everything but the fused-tap 3x3, 1 two-stage atomics kernel, 2 pipe TN=128 x 4 stages, 3 pipe TN=256 x 3 stages,
-// 4 = fused-tap 3x3 + (3 | 1), 6 = fused-tap 3x3 + pipe TN=128 x 2 stages; 0x100 disables XCD grouping
+// 4 = fused-tap 3x3 + (3 | 1), 6 = fused-tap 3x3 + pipe TN=128 x 2 stages, 8 / 9 = 6 with the 256-wide tile (3 / 2 stages) where N % 256 == 0; 0x100 disables XCD grouping
 int ppv_wgrad_set_variant(int v) { g_wgrad_variant = v; return PPV_OK; }
 
 // mode 0: forward layout [64][24][8] bf16; mode 1: data-gradient layout [16][4][4][64] bf16

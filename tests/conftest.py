@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def one_adder_stats(monkeypatch):
+    """Train-mode forward passes that must agree BIT FOR BIT across two runs: give the convolutions as many partial rows for their
+    BatchNorm statistics as they have row tiles (one f32 adder per address).  With the default two rows (encoder.py PPV_BN_FOLD_ROWS)
+    the order of the atomics is open and two passes may differ by an ulp of a statistic."""
+    monkeypatch.setenv("PPV_BN_FOLD_ROWS", "32")
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 

@@ -144,7 +144,7 @@ def test_shallow_trunk_end_to_end():
             assert rel_err(b, bo[n]) < 2e-2, n
 
 
-def test_prefetched_weight_layouts_match_the_forwards_own():
+def test_prefetched_weight_layouts_match_the_forwards_own(one_adder_stats):
     """Encoder.prefetch_weight_layouts() (bench.py calls it on the optimizer's stream) converts the weights as they are at the
     call; the next forward uses those layouts and equals a forward that converts them itself."""
     enc, _ = _pair((1, 1, 1, 1))
@@ -338,7 +338,7 @@ def test_resnet101_at_batch_128_stagewise_against_the_oracle():
     assert img.grad is not None and torch.isfinite(img.grad).all() and float(img.grad.abs().max()) > 0
 
 
-def test_lazy_dense_output_is_written_on_first_access_only():
+def test_lazy_dense_output_is_written_on_first_access_only(one_adder_stats):
     """Encoder(lazy_output=True) (default): the [B,36,36,2048] f32 tensor of models.py:39-41 is allocated in forward and written by
     adaptive_pool_fwd the first time a torch operation reads it; a consumer of the 8 x 8 cell map (ppv_amd.decoder, bench.py's head)
     never triggers that launch.  Values and gradients equal the eager form's."""

@@ -142,6 +142,70 @@ __device__ __forceinline__ double2* dfft(double2* a, double2* b, const double2* 
     return a;
 }
 
+// The same transform with the plan of M = 1344 = 4 * 4 * 4 * 3 * 7 (RR = 896, the benchmark geometry) known at compile time: stage
+// radix, stride and twiddle step are constants (no integer division by a run-time p, no radix dispatch per stage), 256 threads, and
+// a thread's twiddles -- the same for every transform it takes part in -- are loaded ONCE into registers (Tw1344: 22 double2): with
+// the table in global memory every butterfly waited ~0.7 us for an L2 hit inside each of the ten barrier-separated stages of the
+// column pass, with the table in LDS the workgroup is 64.5 KB and only two fit a CU.
+template <int R, int P, int M> struct StageGeom { static constexpr int T = M / R, STEP = M / (P * R), ITERS = (T + 255) / 256; };
+struct Tw1344 {
+    double2 s2[2][3], s3[2][3], s4[2][2], s5[1][6];
+};
+template <int R, int P, int M, int NI>
+__device__ __forceinline__ void tw_load(double2 (&w)[NI][R - 1], const double2* __restrict__ tw, int tid) {
+    using G = StageGeom<R, P, M>;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int i = it * 256 + tid;
+        const int k = (i < G::T ? i : 0) % P;
+#pragma unroll
+        for (int r = 1; r < R; ++r) w[it][r - 1] = tw[r * k * G::STEP];
+    }
+}
+__device__ __forceinline__ void tw1344_load(Tw1344& w, const double2* __restrict__ tw, int tid) {
+    tw_load<4, 4, 1344, 2>(w.s2, tw, tid);
+    tw_load<4, 16, 1344, 2>(w.s3, tw, tid);
+    tw_load<3, 64, 1344, 2>(w.s4, tw, tid);
+    tw_load<7, 192, 1344, 1>(w.s5, tw, tid);
+}
+template <int R, int P, int M, int NI>
+__device__ __forceinline__ void dstage_c(const double2* __restrict__ in, double2* __restrict__ out, const double2 (*w)[R - 1], int tid) {
+    using G = StageGeom<R, P, M>;
+    static_assert(NI == G::ITERS, "twiddle rows per thread");
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int i = it * 256 + tid;
+        if (G::T % 256 != 0 && i >= G::T) break;
+        const int k = i % P;
+        double2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            u[r] = in[i + r * G::T];
+            if (r > 0 && P > 1) u[r] = dmul(u[r], w[it][r - 1]);
+        }
+        dbfly(u);
+        const int j = (i - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) out[j + q * P] = u[q];
+    }
+}
+__device__ __forceinline__ double2* dfft_1344(double2* a, double2* b, const Tw1344& w, int tid) {
+    dstage_c<4, 1, 1344, 2>(a, b, w.s2, tid); __syncthreads();          // P = 1: no twiddles read
+    dstage_c<4, 4, 1344, 2>(b, a, w.s2, tid); __syncthreads();
+    dstage_c<4, 16, 1344, 2>(a, b, w.s3, tid); __syncthreads();
+    dstage_c<3, 64, 1344, 2>(b, a, w.s4, tid); __syncthreads();
+    dstage_c<7, 192, 1344, 1>(a, b, w.s5, tid); __syncthreads();
+    return b;
+}
+// plan-aware entry: the compile-time form when it applies (256 threads, the make_plan() radix order 4,4,4,3,7; w loaded by
+// tw1344_load when pl.M == 1344, untouched otherwise)
+__device__ __forceinline__ double2* dfft256(double2* a, double2* b, const double2* tw, const Tw1344& w, const FftPlan& pl, int tid) {
+    if (pl.M == 1344) return dfft_1344(a, b, w, tid);
+    FftPlan q = pl;
+    if (q.M < 0) q.M = -q.M;
+    return dfft(a, b, tw, q, tid, 256);
+}
+
 // ----------------------------------------------------------------------------- height map
 // h[px] = sum_k c[k] * Z[k][px]   (Lens.py:176; fp64 accumulate, one rounding to f32)
 // support (may be null): a 256-byte header + one byte per float4 pixel group, 0 where EVERY plane of the basis is zero there (outside
@@ -482,20 +546,23 @@ __global__ __launch_bounds__(256) void ic_field_bwd_kernel(const double2* __rest
 
 // ----------------------------------------------------------------------------- Fresnel FFT passes
 // rows: in [L][RR][RR] placed at column offset pad inside a zero row of length M -> out [L][RR][M]
+template <bool C1344>       // C1344: M = 1344, twiddles in registers (no LDS copy of the table: 43 KB per workgroup, three per CU)
 __global__ __launch_bounds__(256) void dfft_rows_kernel(const double2* __restrict__ in, double2* __restrict__ out,
                                                         const double2* __restrict__ twg, FftPlan pl, int RR, int pad) {
-    __shared__ double2 s_tw[MAXM];
+    __shared__ double2 s_tw[C1344 ? 1 : MAXM];
     __shared__ double2 s_a[MAXM];
     __shared__ double2 s_b[MAXM];
     const int tid = threadIdx.x, M = pl.M;
     const long row = blockIdx.x;          // l * RR + y
+    Tw1344 w;
+    if (C1344) tw1344_load(w, twg, tid);
     for (int i = tid; i < M; i += 256) {
-        s_tw[i] = twg[i];
+        if (!C1344) s_tw[i] = twg[i];
         const int x = i - pad;
         s_a[i] = (x >= 0 && x < RR) ? in[row * RR + x] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const double2* r = dfft(s_a, s_b, s_tw, pl, tid, 256);
+    const double2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, s_tw, pl, tid, 256);
     const int l = (int)(row / RR), y = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
     for (int i = tid; i < M; i += 256) out[tix(l, y, i, RR, M, CB)] = r[i];
 }
@@ -560,7 +627,7 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
 template <bool TW_LDS>
 __global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restrict__ T1, double2* __restrict__ T2,
                                                          const float2* __restrict__ Ht, const double2* __restrict__ twg, FftPlan pl,
-                                                         int RR, int pad, int conj_h, double scale) {
+                                                         int RR, int pad, int conj_h, double scale, int static_plan) {
     __shared__ double2 s_tw[TW_LDS ? MAXM : 1];
     __shared__ double2 s_a[MAXM];
     __shared__ double2 s_b[MAXM];
@@ -580,7 +647,12 @@ __global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restri
     }
     __syncthreads();
     const double2* tw = TW_LDS ? s_tw : twg;
-    double2* r = dfft(s_a, s_b, tw, pl, tid, 256);
+    Tw1344 w;
+    const bool c1344 = !TW_LDS && static_plan && M == 1344;          // compile-time plan + twiddles in registers (uniform branch)
+    if (c1344) tw1344_load(w, twg, tid);
+    FftPlan pl2 = pl;
+    if (!c1344 && M == 1344) pl2.M = -1344;            // dfft256 keys on M == 1344: hide it when the static form is off
+    double2* r = dfft256(s_a, s_b, tw, w, pl2, tid);
     double2* o = (r == s_a) ? s_b : s_a;
     const float2* hcol = Ht + ((long)l * M + kx) * M;
     for (int i = tid; i < M; i += 256) {
@@ -590,7 +662,7 @@ __global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restri
         r[i] = make_double2(v.x, -v.y);                  // conj for the inverse transform
     }
     __syncthreads();
-    const double2* z = dfft(r, o, tw, pl, tid, 256);
+    const double2* z = dfft256(r, o, tw, w, pl2, tid);
     for (int i = tid; i < RR; i += 256) {
         const double2 a = z[i + pad];
         T2[tix(l, i, kx, RR, M, CB)] = make_double2(a.x * scale, -a.y * scale);
@@ -598,22 +670,25 @@ __global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restri
 }
 
 // inverse rows: T2 [L][RR][M] -> crop columns pad..pad+RR-1 -> U [L][RR][RR] (c128), optional intensity f32
+template <bool C1344>
 __global__ __launch_bounds__(256) void difft_rows_kernel(const double2* __restrict__ T2, double2* __restrict__ U,
                                                          float* __restrict__ I32, const double2* __restrict__ twg,
                                                          FftPlan pl, int RR, int pad) {
-    __shared__ double2 s_tw[MAXM];
+    __shared__ double2 s_tw[C1344 ? 1 : MAXM];
     __shared__ double2 s_a[MAXM];
     __shared__ double2 s_b[MAXM];
     const int tid = threadIdx.x, M = pl.M;
     const long row = blockIdx.x;
     const int l_ = (int)(row / RR), y_ = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
+    Tw1344 w;
+    if (C1344) tw1344_load(w, twg, tid);
     for (int i = tid; i < M; i += 256) {
-        s_tw[i] = twg[i];
+        if (!C1344) s_tw[i] = twg[i];
         const double2 v = T2[tix(l_, y_, i, RR, M, CB)];
         s_a[i] = make_double2(v.x, -v.y);
     }
     __syncthreads();
-    const double2* r = dfft(s_a, s_b, s_tw, pl, tid, 256);
+    const double2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, s_tw, pl, tid, 256);
     for (int i = tid; i < RR; i += 256) {
         const double2 v = make_double2(r[i + pad].x, -r[i + pad].y);
         U[row * RR + i] = v;
@@ -829,6 +904,12 @@ unsigned quad_blocks(int RR) { return (unsigned)(((long)(RR / 2) * (RR / 4) + 25
 // PPV_ZERNIKE_SYM=0 keeps the full-basis passes even when the basis was found mirror-symmetric.  Whether a state's basis IS symmetric
 // is known on the device only (header written by the marking pass; the host never reads it back in the step): both forms are
 // launched, and the one the header does not select returns at once (one empty launch per direction, ~4 us, against ~130 us saved).
+// PPV_DFFT_STATIC=0: the run-time-plan transforms also for M = 1344 (A/B of the compile-time plan with register twiddles)
+bool dfft_static(int M) {
+    static const bool on = !(getenv("PPV_DFFT_STATIC") && atoi(getenv("PPV_DFFT_STATIC")) == 0);
+    return on && M == 1344;
+}
+
 bool sym_allowed() {
     static const bool on = !(getenv("PPV_ZERNIKE_SYM") && atoi(getenv("PPV_ZERNIKE_SYM")) == 0);
     return on;
@@ -863,8 +944,8 @@ size_t ppv_ic_psf_state_bytes(int RR, int P, int K) {
 static void launch_dfft_cols(const double2* T1, double2* T2, const float2* Ht, const double2* tw, const FftPlan& pl, int RR, int pad, int M,
                              int conj_h, double scale, hipStream_t stream) {
     static const int mode = getenv("PPV_DFFT_COLS") ? atoi(getenv("PPV_DFFT_COLS")) : 2;
-    if (mode == 1) dfft_cols1_kernel<true><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
-    else if (mode == 2) dfft_cols1_kernel<false><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
+    if (mode == 1) dfft_cols1_kernel<true><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, 0);
+    else if (mode == 2) dfft_cols1_kernel<false><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, dfft_static(M) ? 1 : 0);
     else dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
 }
 
@@ -924,9 +1005,11 @@ int ppv_ic_psf_fwd(const float* Z, const float* coeffs, const float* noise, cons
     launch_contract(Z, coeffs, w, K, RR, stream);
     ic_field_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.h, noise, (const float2*)sph, w.F0, RR, kdn[0],
                                                                      kdn[1], kdn[2], tol, (tol >= 0.f && noise) ? 1 : 0);
-    dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
+    if (dfft_static(M)) dfft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
+    else dfft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
     launch_dfft_cols(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, M, 0, 1.0 / ((double)M * (double)M), stream);
-    difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
+    if (dfft_static(M)) difft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
+    else difft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
     area_down_kernel<<<(unsigned)(((long)P * P + 255) / 256), 256, 0, stream>>>(w.I32, w.raw, w.sums, RR, P, up, up_scale);
     const long n = (long)P * P * 3;
     psf_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(w.raw, w.sums, m1, m2, psf_n, psf_m,
@@ -956,11 +1039,13 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
                                                                             w.g_n, dots, n);
     double2* GU = w.T2;      // T2 is dead after forward and holds 3*RR*M >= 3*RR*RR elements; U and F0 stay intact
     area_down_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.g_n, dots, w.sums, w.U, GU, RR, P, up, up_scale);
-    dfft_rows_kernel<<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
+    if (dfft_static(M)) dfft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
+    else dfft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
     // cols: T1 -> T2 would overwrite GU while reading T1 only: fine (GU no longer needed)
     launch_dfft_cols(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, M, 1, 1.0 / ((double)M * (double)M), stream);
     double2* GF = w.T1;                                            // T1 dead again
-    difft_rows_kernel<<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
+    if (dfft_static(M)) difft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
+    else difft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
     ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
     launch_grad(Z, g_coeffs, w, K, RR, stream);
     return ppv_last_error();

@@ -107,8 +107,13 @@ __global__ __launch_bounds__(512, 4) void cols_mul_kernel(const float2* __restri
             const int row = lane + 64 * r;
             u[r] = (row < H_in) ? s_tile[row * LD + c] : make_float2(0.f, 0.f);
         }
-        fft_wave<R>(u, s_scr[wave], s_tw, lane);
+        // the OTF column is requested before the transform (its address does not depend on it): an L2 round trip per column
+        // otherwise sits between the forward and the inverse transform of every wave
         const float2* o = otfT + ((long)ch * (NH + 1) + kx) * N;
+        float2 wq[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) wq[q] = o[lane + 64 * q];
+        fft_wave<R>(u, s_scr[wave], s_tw, lane);
         if (kx == 0) {
             const float2* on = otfT + ((long)ch * (NH + 1) + NH) * N;
             float2 v[R];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(512, 4) void cols_mul_kernel(const float2* __restri
                 const float2 A = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
                 const float2 B = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
                 const int k = lane + 64 * q;
-                const float2 o0 = o[k], o1 = on[k];
+                const float2 o0 = wq[q], o1 = on[k];
                 const float2 pa = conj_otf ? cmul_conj(A, o0) : cmul(A, o0);
                 const float2 pb = conj_otf ? cmul_conj(B, o1) : cmul(B, o1);
                 v[q] = make_float2(pa.x - pb.y, pa.y + pb.x);
@@ -129,10 +134,7 @@ __global__ __launch_bounds__(512, 4) void cols_mul_kernel(const float2* __restri
             for (int q = 0; q < R; ++q) u[q] = v[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const float2 w = o[lane + 64 * q];
-                u[q] = conj_otf ? cmul_conj(u[q], w) : cmul(u[q], w);
-            }
+            for (int q = 0; q < R; ++q) u[q] = conj_otf ? cmul_conj(u[q], wq[q]) : cmul(u[q], wq[q]);
         }
         ifft_wave<R>(u, s_scr[wave], s_tw, lane);
 #pragma unroll

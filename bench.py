@@ -130,7 +130,8 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         opt_dec = torch.optim.Adam(dec_params, lr=4e-4, fused=True, capturable=graph)   # train.py:33,100-101
         gen = torch.Generator().manual_seed(100 + rank)
         caps = torch.randint(0, decoder.vocab_size, (batch, 52), generator=gen).to(device)
-        caplens = torch.randint(9, 19, (batch, 1), generator=gen).to(device)      # COCO-like lengths incl. <start>/<end>
+        caplens_host = torch.randint(9, 19, (batch, 1), generator=gen)            # COCO-like lengths incl. <start>/<end>: what the loader yields
+        caplens = caplens_host.to(device)                                         # train.py:263
 
     opt_stream = torch.cuda.Stream(device=device) if (os.environ.get("PPV_OPT_OVERLAP", "1") != "0" and not graph) else None
 
@@ -138,6 +139,8 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         nonlocal imgs
         if imgs_host is not None:
             imgs = imgs_host.to(device, non_blocking=True)
+        if decoder is not None and os.environ.get("PPV_DEC_STAGE_LENGTHS", "1") != "0":
+            decoder.stage_lengths(caplens, host=caplens_host)   # the loader's CPU copy: forward() never fetches lengths from the device (decoder.py)
         sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
         if opt_stream is not None:             # the encoder's (and decoder's) Adam of the previous step ran beside the camera forward
             torch.cuda.current_stream().wait_stream(opt_stream)
@@ -179,8 +182,9 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
             opt_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(opt_stream) if opt_stream is not None else contextlib.nullcontext():
             grads = [p.grad for p in enc_params]                                  # clip_gradient, train.py:311-316
-            torch._foreach_clamp_min_(grads, -5.0)
-            torch._foreach_clamp_max_(grads, 5.0)
+            if not os.environ.get("PPV_BENCH_NOCLIP"):                            # (diagnostic only: is the optimiser stream on the critical path?)
+                torch._foreach_clamp_min_(grads, -5.0)
+                torch._foreach_clamp_max_(grads, 5.0)
             opt_enc.step()
             if opt_stream is not None and hasattr(encoder, "prefetch_weight_layouts") and os.environ.get("PPV_WL_PREFETCH", "1") != "0":
                 encoder.prefetch_weight_layouts()      # bf16 GEMM layouts of the updated weights, beside the next camera forward

@@ -172,6 +172,25 @@ int ppv_bn_act(const void* x, const float* coef1, const void* r, const float* co
  * statistics in ONE row sums [2][C] (ppv_conv_gemm with stat_rows = 1): every thread derives scale / shift of its eight channels
  * itself (no ppv_bn_finalize launch); coef [4][C] (scale, shift, mean, invstd) and the running statistics (momentum, unbiased
  * variance; run_mean / run_var may be NULL) are written by the threads of the first row.  res_mode 0: none, 1: identity r. */
+/* ---- whole-bottleneck launchers (host-side only: they call the entry points above/below in the order the Python step does) ----------
+ * One crossing of the FFI per torchvision Bottleneck (Image_Caption/models.py:17-21, train-mode BatchNorm: train.py:245) instead of
+ * one per kernel.  Forward of a block WITHOUT projection shortcut: conv1 1x1 -> bn1+ReLU -> conv2 3x3 -> bn2+ReLU -> conv3 1x1 ->
+ * bn3 + identity + ReLU, every BatchNorm as ppv_bn_act_fold_rows (statistics in T partial rows, PRE-ZEROED by the caller; running
+ * statistics updated in place; coef [4][C] written for the backward pass).  All tensors NHWC bf16; bits = (yout > 0) mask, n/8 bytes. */
+typedef struct PpvBottleneckFwd {
+    const void *xin, *w1, *w2, *w3;                       /* block input [B,H,W,4 planes]; forward weight layouts (ppv_weight_layout mode 0) */
+    void *x1, *y1, *x2, *y2, *x3, *yout, *bits;           /* raw conv outputs, activations, block output, its sign mask */
+    float *stats1, *stats2, *stats3;                      /* [T][2][C] f32, zeroed */
+    float *coef1, *coef2, *coef3;                         /* [4][C] f32: scale, shift, mean, invstd */
+    const float *g1, *b1; float *rm1, *rv1;               /* BatchNorm weight, bias, running_mean, running_var */
+    const float *g2, *b2; float *rm2, *rv2;
+    const float *g3, *b3; float *rm3, *rv3;
+    const void* zero_page;                                /* >= 256 zero bytes (padding source of the convolutions) */
+    float mom1, eps1, mom2, eps2, mom3, eps3;
+    int B, H, W, Cin, planes, stride, T1, T2, T3;         /* Cin == 4 * planes, stride == 1 (identity shortcut) */
+} PpvBottleneckFwd;
+int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, ppv_stream_t stream);
+
 int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
                     int res_mode, int relu, ppv_stream_t stream);

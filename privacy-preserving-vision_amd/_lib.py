@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -112,6 +112,17 @@ PROTOTYPES = {
     "ppv_adaptive_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_adaptive_pool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
+
+class BottleneckFwd(ctypes.Structure):
+    """include/ppv_hip.h PpvBottleneckFwd (field order = the header's)."""
+    _fields_ = ([(n, _P) for n in ("xin", "w1", "w2", "w3", "x1", "y1", "x2", "y2", "x3", "yout", "bits", "stats1", "stats2", "stats3",
+                                   "coef1", "coef2", "coef3", "g1", "b1", "rm1", "rv1", "g2", "b2", "rm2", "rv2", "g3", "b3", "rm3", "rv3",
+                                   "zero_page")]
+                + [(n, _F) for n in ("mom1", "eps1", "mom2", "eps2", "mom3", "eps3")]
+                + [(n, _I) for n in ("B", "H", "W", "Cin", "planes", "stride", "T1", "T2", "T3")])
+
+
+PROTOTYPES["ppv_bottleneck_fwd"] = (_I, [ctypes.POINTER(BottleneckFwd), _P])
 
 _lib = None
 

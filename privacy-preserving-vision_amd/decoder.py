@@ -247,7 +247,11 @@ class _DecoderFn(torch.autograd.Function):
             _linear(XH[t, :bt], w2, b2, z[:bt], hip_gemm)
             check(lib.ppv_lstm_cell_fwd(ptr(z), ptr(C[t]), ptr(G[t]), ptr(C[t + 1]), ptr(HS[t]), D, ptr(XH[t + 1, :, M + E:]), X,
                                         bt, D, stream_ptr()), "ppv_lstm_cell_fwd")
-        valid = (torch.arange(B, device=dev).view(1, B, 1) < torch.tensor(bts, device=dev).view(T, 1, 1)).to(F32)
+        # the per-step batch sizes reach the device through PINNED memory without blocking: torch.tensor(list, device=...) is a
+        # pageable copy that waits for everything queued on the stream (the trunk forward), once per step
+        bt_host = torch.tensor(bts, dtype=torch.int64).pin_memory()
+        ctx.bt_host = bt_host                                    # alive until the copy has run
+        valid = (torch.arange(B, device=dev).view(1, B, 1) < bt_host.to(dev, non_blocking=True).view(T, 1, 1)).to(F32)
         if mod.training and mod.p_drop > 0:                      # models.py:211 nn.Dropout
             keep = 1.0 - mod.p_drop
             dmask = (torch.rand((T, B, D), device=dev) < keep).to(F32) / keep
@@ -390,6 +394,8 @@ class DecoderWithAttention(nn.Module):
     def __getstate__(self):                        # the pooling class tables are device-side caches
         st = dict(self.__dict__)
         st["_tables"] = {}
+        st.pop("_staged", None)                    # stage_lengths(): an event and a pinned buffer, per-process runtime state
+        st.pop("_len_host", None)
         return st
 
     def init_weights(self):
@@ -417,13 +423,51 @@ class DecoderWithAttention(nn.Module):
                 self.init_h.bias, self.init_c.weight, self.init_c.bias, self.f_beta.weight, self.f_beta.bias, self.fc.weight,
                 self.fc.bias]
 
+    def stage_lengths(self, caption_lengths, host=None):
+        """Optional (not in the reference): hand the decoder the batch's caption lengths early so that forward() does not have to
+        fetch them from the device.  models.py:193's ``(caption_lengths - 1).tolist()`` on a device tensor waits for everything
+        queued on the stream before it -- the whole camera + ResNet-101 forward -- once per step: the host cannot run ahead of the
+        device, and its enqueue time (15 ms for the trunk) adds to the step instead of hiding behind it.
+
+        caption_lengths  the tensor that will be passed to forward() (matched by identity and version).
+        host             the same lengths as a CPU tensor -- what the data loader produced before ``.to(device)`` (train.py:263).
+                         With it nothing crosses the bus in the wrong direction: the stable descending sort of models.py:181 runs
+                         on the host, only the permutation goes to the device (pinned, non-blocking).  Without it the sorted
+                         lengths are copied to pinned memory on the current stream now and forward() waits for that copy only
+                         (still behind whatever the stream holds at THIS point, e.g. the previous step).
+        Without this call forward() behaves exactly as the reference."""
+        if host is not None:
+            lens_h, order_h = host.reshape(-1).sort(dim=0, descending=True, stable=True)
+            dec_len = (lens_h - 1).tolist()
+            pin = order_h.pin_memory()
+            order = pin.to(caption_lengths.device, non_blocking=True)
+            object.__setattr__(self, "_staged", (caption_lengths, caption_lengths._version, order, dec_len, None, pin))
+            return
+        lens, order = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
+        buf = getattr(self, "_len_host", None)
+        if buf is None or buf.shape != lens.shape or buf.dtype != lens.dtype:
+            buf = torch.empty(lens.shape, dtype=lens.dtype, pin_memory=True)
+            object.__setattr__(self, "_len_host", buf)
+        buf.copy_(lens, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        object.__setattr__(self, "_staged", (caption_lengths, caption_lengths._version, order, None, ev, buf))
+
     def forward(self, encoder_out, encoded_captions, caption_lengths):
         if not encoder_out.is_cuda:
             raise RuntimeError("ppv_amd DecoderWithAttention runs on an MI355X (encoder_out must be a cuda tensor); no CPU path")
-        # models.py:181; stable, so equal lengths keep their batch order exactly as the reference's CPU sort leaves them
-        lens, order = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
+        staged = getattr(self, "_staged", None)
+        object.__setattr__(self, "_staged", None)
+        if staged is not None and staged[0] is caption_lengths and staged[1] == caption_lengths._version:
+            _, _, order, dec_len, ev, buf = staged
+            if dec_len is None:
+                ev.synchronize()                                                    # the early copy, not the trunk forward
+                dec_len = (buf - 1).tolist()
+        else:
+            # models.py:181; stable, so equal lengths keep their batch order exactly as the reference's CPU sort leaves them
+            lens, order = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
+            dec_len = (lens - 1).tolist()                                           # models.py:193 (synchronises with the stream)
         caps = encoded_captions[order]
-        dec_len = (lens - 1).tolist()                                               # models.py:193
         n_pix = encoder_out.numel() // (encoder_out.shape[0] * encoder_out.shape[-1])
         src, tables = encoder_out, None
         cells = getattr(encoder_out, "_ppv_cells", None)          # set by ppv_amd.encoder.Encoder on the tensor it returns

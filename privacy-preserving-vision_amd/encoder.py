@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import convops as co
+from . import _lib
 
 LAYERS = (3, 4, 23, 3)
 PLANES = (64, 128, 256, 512)
@@ -208,6 +209,10 @@ class _TrunkFn(torch.autograd.Function):
         # rows: +0.4 %, eight: -1.5 %.  The first two forms of the fold lost: a 512-workgroup looped kernel (round 2, PPV_BN_FUSED) and
         # per-THREAD coefficients from one row (-1.3 %; PPV_BN_FOLD_THREAD=1 keeps it reachable).  PPV_BN_FOLD_ACT=0: bn_finalize + bn_act.
         fold_act = train and _os0.environ.get("PPV_BN_FOLD_ACT", "1") == "1"
+        # PPV_BLOCK_EXEC=0: every kernel of a bottleneck through its own FFI call (the form the roofline pass and the tests' taps use)
+        block_exec = train and _os0.environ.get("PPV_BLOCK_EXEC", "1") != "0"
+        bargs = _lib.BottleneckFwd()
+        bargs.zero_page = co.zero_page(dev).data_ptr()
         fold_rows = max(1, int(_os0.environ.get("PPV_BN_FOLD_ROWS", "2")))     # partial rows the fold path's convolutions leave (adders per address = row tiles / this)
 
         def part_for(M, C, one_row=False):
@@ -237,6 +242,38 @@ class _TrunkFn(torch.autograd.Function):
             r1, r2, r3, rd = blk
             Bn, Hin, Win, _ = xin.shape
             use_fold = fold_act and not fused_bn and all(r_.bn.training for r_ in blk if r_ is not None)
+            if use_fold and block_exec and rd is None and r2.stride == 1 and co.PROFILE is None:
+                # one FFI crossing for the whole block (csrc/block_exec.hip: the same six launches in the same order)
+                P_ = r1.conv.out_channels
+                M1 = Bn * Hin * Win
+                T_ = min(fold_rows, co.stat_tiles(M1))
+                n1, n3 = T_ * 2 * P_, T_ * 8 * P_
+                sbase = pool.data_ptr() + 4 * pool_off[0]
+                pool_off[0] += 2 * n1 + n3
+                x1 = torch.empty((Bn, Hin, Win, P_), dtype=torch.bfloat16, device=dev)
+                y1, x2, y2 = torch.empty_like(x1), torch.empty_like(x1), torch.empty_like(x1)
+                x3 = torch.empty((Bn, Hin, Win, 4 * P_), dtype=torch.bfloat16, device=dev)
+                yout = torch.empty_like(x3)
+                ybits = torch.empty(x3.numel() // 8, dtype=torch.uint8, device=dev)
+                c1 = torch.empty((4, P_), dtype=torch.float32, device=dev)
+                c2, c3 = torch.empty_like(c1), torch.empty((4, 4 * P_), dtype=torch.float32, device=dev)
+                a = bargs
+                a.xin, a.w1, a.w2, a.w3 = xin.data_ptr(), r1.wt(tok).data_ptr(), r2.wt(tok).data_ptr(), r3.wt(tok).data_ptr()
+                a.x1, a.y1, a.x2, a.y2, a.x3, a.yout, a.bits = (x1.data_ptr(), y1.data_ptr(), x2.data_ptr(), y2.data_ptr(), x3.data_ptr(),
+                                                                yout.data_ptr(), ybits.data_ptr())
+                a.stats1, a.stats2, a.stats3 = sbase, sbase + 4 * n1, sbase + 8 * n1
+                a.coef1, a.coef2, a.coef3 = c1.data_ptr(), c2.data_ptr(), c3.data_ptr()
+                for i_, r_ in ((1, r1), (2, r2), (3, r3)):
+                    bn_ = r_.bn
+                    setattr(a, "g%d" % i_, bn_.weight.data_ptr()); setattr(a, "b%d" % i_, bn_.bias.data_ptr())
+                    setattr(a, "rm%d" % i_, bn_.running_mean.data_ptr() if bn_.running_mean is not None else None)
+                    setattr(a, "rv%d" % i_, bn_.running_var.data_ptr() if bn_.running_var is not None else None)
+                    setattr(a, "mom%d" % i_, _bn_momentum(bn_)); setattr(a, "eps%d" % i_, bn_.eps)
+                a.B, a.H, a.W, a.Cin, a.planes, a.stride, a.T1, a.T2, a.T3 = Bn, Hin, Win, xin.shape[3], P_, 1, T_, T_, T_
+                _lib.check(_lib.lib().ppv_bottleneck_fwd(_lib.ctypes.byref(a), _lib.stream_ptr()), "ppv_bottleneck_fwd")
+                blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, None, None, yout, xin_bits))
+                x, xin_bits = yout, ybits
+                continue
             p = part_for(Bn * Hin * Win, r1.conv.out_channels, one_row=use_fold)
             x1 = co.conv_fwd(xin, r1.wt(tok), 1, 0, p)
             H2, W2 = Hin // r2.stride, Win // r2.stride

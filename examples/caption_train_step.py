@@ -31,10 +31,14 @@ criterion = torch.nn.CrossEntropyLoss().to(device)
 B = 32
 imgs = torch.rand(B, 3, 256, 256, device=device)
 caps = torch.randint(0, vocab, (B, 52), device=device)
-caplens = torch.randint(9, 19, (B, 1), device=device)
+caplens_cpu = torch.randint(9, 19, (B, 1))          # what the data loader yields (datasets.py:60)
+caplens = caplens_cpu.to(device)                    # train.py:263
 camera.train(); encoder.train(); decoder.train()                                                                  # train.py:245-247
 
 for it in range(3):
+    # optional, ppv_amd only: the decoder gets the lengths from the loader's CPU tensor, so its forward never waits for the device
+    # (models.py:193's .tolist() on a device tensor waits for the whole camera + encoder forward queued before it)
+    decoder.stage_lengths(caplens, host=caplens_cpu)
     imgs_sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")                                                  # train.py:270
     imgs_encoded = encoder(imgs_sensor)                                                                           # train.py:272
     scores, caps_sorted, decode_lengths, alphas, sort_ind = decoder(imgs_encoded, caps, caplens)                  # train.py:274

@@ -190,6 +190,26 @@ typedef struct PpvBottleneckFwd {
     int B, H, W, Cin, planes, stride, T1, T2, T3;         /* Cin == 4 * planes, stride == 1 (identity shortcut) */
 } PpvBottleneckFwd;
 int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, ppv_stream_t stream);
+/* Backward of the same block (the default schedule of ppv_amd/encoder.py): bn3' -> dgrad3 -> bn2' -> dgrad2 -> bn1' -> dgrad1 on `main`,
+ * each weight gradient on `side` (null: on `main`) behind an event recorded on `main` right after the BatchNorm backward that produces its
+ * operand.  g: gradient w.r.t. the block output, already masked by that output's ReLU.  part3: bn3's sums, part3_ready != 0 when the
+ * data-gradient launch that produced g took them (ppv_conv_gemm_red), else PRE-ZEROED scratch; part2 / part1 PRE-ZEROED (>= 64 C floats each);
+ * red2 / red1: the conv3 / conv2 data gradients also take bn2's / bn1's sums (shapes ppv_conv_gemm_red supports).  x3_prev / part3_prev
+ * (may be null): raw conv3 output and PRE-ZEROED sums buffer of the block the returned gradient flows into.  dg / db / dw null = that
+ * parameter is frozen (models.py:43-54).  kc: 3 C floats of scratch per BatchNorm.  wscratch: ppv_conv_wgrad_scratch_bytes. */
+typedef struct PpvBottleneckBwd {
+    const void *g, *xin, *x1, *y1, *x2, *y2, *x3, *xin_bits;
+    const float *c1, *c2, *c3;
+    const void *wd1, *wd2, *wd3;                          /* data-gradient weight layouts (ppv_weight_layout mode 1) */
+    float *part3, *part2, *part1, *kc3, *kc2, *kc1;
+    void *gx3, *gy2, *gx2, *gy1, *gx1, *gin;              /* bf16 gradients: raw conv3 / act2 / raw conv2 / act1 / raw conv1 / block input */
+    float *dg3, *db3, *dg2, *db2, *dg1, *db1, *dw3, *dw2, *dw1;
+    void* wscratch;
+    const void* x3_prev; float* part3_prev;
+    const void* zero_page;
+    int B, H, W, planes, part3_ready, red2, red1;
+} PpvBottleneckBwd;
+int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, ppv_stream_t main_stream, ppv_stream_t side_stream);
 
 int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -123,6 +123,18 @@ class BottleneckFwd(ctypes.Structure):
 
 
 PROTOTYPES["ppv_bottleneck_fwd"] = (_I, [ctypes.POINTER(BottleneckFwd), _P])
+
+
+class BottleneckBwd(ctypes.Structure):
+    """include/ppv_hip.h PpvBottleneckBwd."""
+    _fields_ = ([(n, _P) for n in ("g", "xin", "x1", "y1", "x2", "y2", "x3", "xin_bits", "c1", "c2", "c3", "wd1", "wd2", "wd3",
+                                   "part3", "part2", "part1", "kc3", "kc2", "kc1", "gx3", "gy2", "gx2", "gy1", "gx1", "gin",
+                                   "dg3", "db3", "dg2", "db2", "dg1", "db1", "dw3", "dw2", "dw1", "wscratch", "x3_prev", "part3_prev",
+                                   "zero_page")]
+                + [(n, _I) for n in ("B", "H", "W", "planes", "part3_ready", "red2", "red1")])
+
+
+PROTOTYPES["ppv_bottleneck_bwd"] = (_I, [ctypes.POINTER(BottleneckBwd), _P, _P])
 
 _lib = None
 

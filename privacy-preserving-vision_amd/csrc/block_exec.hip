@@ -33,4 +33,64 @@ int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, hipStream_t stream) {
                                 a->bits, M2 * C3, C3, 1, 1, stream);
 }
 
+// backward of the same block, in the order encoder.py's default schedule enqueues it (weight gradients on `side` as soon as their
+// operand exists, behind an event recorded on `main`):
+//   bn3' -> [wgrad3] -> dgrad3 (+ bn2 sums) -> bn2' -> [wgrad2] -> dgrad2 (+ bn1 sums) -> bn1' -> [wgrad1] -> dgrad1 (+ residual gradient
+//   + ReLU mask of the block input + bn3 sums of the block this gradient flows into)
+namespace {
+hipEvent_t fork_event() {
+    // a small ring of timing-less events, created once; hipStreamWaitEvent captures the record that precedes it, so re-recording an
+    // event a later call has moved on from is fine
+    static hipEvent_t ring[256];
+    static bool made = false;
+    static unsigned next = 0;
+    if (!made) {
+        for (auto& e : ring) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        made = true;
+    }
+    return ring[next++ & 255];
+}
+int fork_to(hipStream_t main, hipStream_t side) {
+    hipEvent_t e = fork_event();
+    if (hipError_t r = hipEventRecord(e, main)) return -(int)r;
+    if (hipError_t r = hipStreamWaitEvent(side, e, 0)) return -(int)r;
+    return PPV_OK;
+}
+}  // namespace
+
+int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t side) {
+    if (!a) return PPV_ERR_NULL;
+    const int B = a->B, H = a->H, W = a->W, P = a->planes, C3 = 4 * P;
+    const long M = (long)B * H * W;
+    hipStream_t ws = side ? side : main;
+    int e;
+    // bn3 backward (gradient arrives masked by the block output's ReLU; sums possibly taken by the data-gradient launch that produced it)
+    if ((e = ppv_bn_bwd(a->g, nullptr, a->x3, a->c3, (double)M, a->gx3, nullptr, a->dg3, a->db3, a->part3, a->kc3, M, C3, 0, a->part3_ready ? 2 : 1, main))) return e;
+    if (a->dw3) {
+        if (side && (e = fork_to(main, side))) return e;
+        if ((e = ppv_conv_wgrad(a->gx3, a->y2, a->dw3, a->wscratch, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws))) return e;
+    }
+    // conv3 data gradient (+ bn2's sums and recomputed ReLU mask)
+    if (a->red2) e = ppv_conv_gemm_red(a->gx3, a->wd3, a->gy2, a->part2, a->x2, a->c2, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 8, main);
+    else e = ppv_conv_gemm(a->gx3, a->wd3, a->gy2, nullptr, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 0, 0, main);
+    if (e) return e;
+    if ((e = ppv_bn_bwd(a->gy2, nullptr, a->x2, a->c2, (double)M, a->gx2, nullptr, a->dg2, a->db2, a->part2, a->kc2, M, P, a->red2 ? 0 : 2, a->red2 ? 2 : 1, main))) return e;
+    if (a->dw2) {
+        if (side && (e = fork_to(main, side))) return e;
+        if ((e = ppv_conv_wgrad(a->gx2, a->y1, a->dw2, a->wscratch, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws))) return e;
+    }
+    // conv2 data gradient (+ bn1's sums)
+    if (a->red1) e = ppv_conv_gemm_red(a->gx2, a->wd2, a->gy1, a->part1, a->x1, a->c1, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 8, main);
+    else e = ppv_conv_gemm(a->gx2, a->wd2, a->gy1, nullptr, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 0, 0, main);
+    if (e) return e;
+    if ((e = ppv_bn_bwd(a->gy1, nullptr, a->x1, a->c1, (double)M, a->gx1, nullptr, a->dg1, a->db1, a->part1, a->kc1, M, P, a->red1 ? 0 : 2, a->red1 ? 2 : 1, main))) return e;
+    if (a->dw1) {
+        if (side && (e = fork_to(main, side))) return e;
+        if ((e = ppv_conv_wgrad(a->gx1, a->xin, a->dw1, a->wscratch, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws))) return e;
+    }
+    // conv1 data gradient + the identity branch's gradient + the block input's ReLU mask (+ the sums bn3 of the NEXT block to run needs)
+    if (a->x3_prev) return ppv_conv_gemm_red(a->gx1, a->wd1, a->gin, a->part3_prev, a->x3_prev, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 8, main);
+    return ppv_conv_gemm(a->gx1, a->wd1, a->gin, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 0, 0, main);
+}
+
 }  // extern "C"

@@ -565,10 +565,90 @@ class _TrunkFn(torch.autograd.Function):
         fuse_red, fuse_red12, fuse_proj = red_level >= 1, red_level >= 2, red_level >= 3
         order = list(zip(reversed(enc._blocks), reversed(ctx.blocks)))
         sums3 = None
+        # PPV_BLOCK_EXEC (default on): the twelve launches + three stream forks of a bottleneck without projection go through ONE FFI
+        # crossing (csrc/block_exec.hip ppv_bottleneck_bwd: the calls below, same order, same arguments).  Only in the default
+        # configuration: single process, no taps / per-class timing, default weight-gradient schedule.
+        fast_bwd = (_os.environ.get("PPV_BLOCK_EXEC", "1") != "0" and (sync is None or (bucketed and side is not None)) and taps is None
+                    and co.PROFILE is None and not group_min and wsched == [0, 2, 4] and red_level == 3)
+        if fast_bwd:
+            bwa = _lib.BottleneckBwd()
+            bwa.zero_page = co.zero_page(dev0).data_ptr()
+            bwa.wscratch = wscratch.data_ptr()
+            kc_all = torch.empty(3 * 3 * 2048 + 64, dtype=torch.float32, device=dev0)     # coefficient scratch of the three BatchNorms (stream-ordered reuse)
+            side_ptr = side.cuda_stream if side is not None else None
         for bi, (blk, sv) in enumerate(order):
             g_blk_out = g
             r1, r2, r3, rd = blk
             xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits = sv
+            if fast_bwd and rd is None and r2.stride == 1 and 4 * r1.conv.out_channels <= 2048:
+                P_ = r1.conv.out_channels
+                Bn, Hh, Ww, _ = xin.shape
+                Mr = Bn * Hh * Ww
+                a = bwa
+                a.g, a.xin, a.x1, a.y1, a.x2, a.y2, a.x3 = (g.data_ptr(), xin.data_ptr(), x1.data_ptr(), y1.data_ptr(), x2.data_ptr(),
+                                                            y2.data_ptr(), x3.data_ptr())
+                a.xin_bits = xin_bits.data_ptr() if xin_bits is not None else None
+                a.c1, a.c2, a.c3 = c1.data_ptr(), c2.data_ptr(), c3.data_ptr()
+                a.wd1, a.wd2, a.wd3 = r1.wd(tok).data_ptr(), r2.wd(tok).data_ptr(), r3.wd(tok).data_ptr()
+                if sums3 is not None:
+                    a.part3, a.part3_ready = sums3.data_ptr(), 1
+                else:
+                    a.part3, a.part3_ready = bn_part(4 * P_).data_ptr(), 0
+                a.red2 = a.red1 = int(co.red_supported(Mr, P_))
+                pb = bpool.data_ptr() + 4 * boff[0]
+                boff[0] += 128 * P_
+                a.part2, a.part1 = pb, pb + 256 * P_
+                kb = kc_all.data_ptr()
+                a.kc3, a.kc2, a.kc1 = kb, kb + 4 * 3 * 2048, kb + 8 * 3 * 2048
+                gx3 = torch.empty_like(x3)
+                gy2, gx2, gy1, gx1 = torch.empty_like(x2), torch.empty_like(x2), torch.empty_like(x1), torch.empty_like(x1)
+                gin = torch.empty_like(xin)
+                a.gx3, a.gy2, a.gx2, a.gy1, a.gx1, a.gin = (gx3.data_ptr(), gy2.data_ptr(), gx2.data_ptr(), gy1.data_ptr(), gx1.data_ptr(),
+                                                            gin.data_ptr())
+                outs, wouts = [], []
+                for i_, r_, C_ in ((3, r3, 4 * P_), (2, r2, P_), (1, r1, P_)):
+                    if r_.bn.weight.requires_grad:
+                        if bucketed:                     # the kernels write the parameters' slices of the flat gradient buckets
+                            dg_, db_ = sync.grad_view(r_.bn.weight).view(-1), sync.grad_view(r_.bn.bias).view(-1)
+                        else:
+                            dg_ = torch.empty(C_, dtype=torch.float32, device=dev0)
+                            db_ = torch.empty(C_, dtype=torch.float32, device=dev0)
+                        setattr(a, "dg%d" % i_, dg_.data_ptr()); setattr(a, "db%d" % i_, db_.data_ptr())
+                        outs += [(r_.bn.weight, dg_), (r_.bn.bias, db_)]
+                    else:
+                        setattr(a, "dg%d" % i_, None); setattr(a, "db%d" % i_, None)
+                    w_ = r_.conv.weight
+                    if w_.requires_grad:
+                        if bucketed:
+                            dw_ = sync.grad_view(w_)
+                            wouts.append((w_, dw_))
+                        else:
+                            dw_ = torch.empty(w_.shape, dtype=torch.float32, device=dev0)
+                            outs.append((w_, dw_))
+                            if side is not None:
+                                dw_.record_stream(side)
+                        setattr(a, "dw%d" % i_, dw_.data_ptr())
+                    else:
+                        setattr(a, "dw%d" % i_, None)
+                sums3 = None
+                a.x3_prev = a.part3_prev = None
+                if bi + 1 < len(order):
+                    x3_prev = order[bi + 1][1][7]
+                    if co.red_supported(x3_prev.numel() // x3_prev.shape[-1], x3_prev.shape[-1]):
+                        sums3 = bn_part(x3_prev.shape[-1])
+                        a.x3_prev, a.part3_prev = x3_prev.data_ptr(), sums3.data_ptr()
+                a.B, a.H, a.W, a.planes = Bn, Hh, Ww, P_
+                _lib.check(_lib.lib().ppv_bottleneck_bwd(_lib.ctypes.byref(a), main_stream.cuda_stream, side_ptr), "ppv_bottleneck_bwd")
+                if side is not None:                   # operands the side stream reads: the allocator must not recycle them before it has
+                    for t_ in (gx3, gx2, gx1, y2, y1, xin):
+                        t_.record_stream(side)
+                for p_, t_ in outs:
+                    deliver(p_, t_)
+                for w_, dw_ in wouts:                  # bucket slices written on the side stream: the bucket's all-reduce waits for it
+                    w_.grad = dw_
+                    sync.mark_ready(w_, stream=side)
+                g = gin
+                continue
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
             # a down-sampling block's projection BatchNorm sees the same gradient as bn3: bn3's apply pass takes its sums too
             sumsd = bn_part(xd.shape[-1]) if (fuse_proj and rd is not None) else None
@@ -660,7 +740,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_nbt_cache"):
             st.pop(k, None)
         return st
 
@@ -764,7 +844,15 @@ class Encoder(nn.Module):
 
     @property
     def _nbt(self):
-        return [m.num_batches_tracked for m in self.resnet.modules() if isinstance(m, nn.BatchNorm2d)]
+        # the 104 num_batches_tracked buffers; cached per _apply generation (walking the module tree costs 0.4 ms of host time per step),
+        # validated by two sentinels (a buffer re-assigned from outside makes the list stale)
+        c = self.__dict__.get("_nbt_cache")
+        gen = self.__dict__.get("_plist_gen", 0)
+        if c is not None and c[0] == gen and c[1][0] is self.resnet[1].num_batches_tracked and c[1][-1] is self.resnet[7][-1].bn3.num_batches_tracked:
+            return c[1]
+        lst = [m.num_batches_tracked for m in self.resnet.modules() if isinstance(m, nn.BatchNorm2d)]
+        self.__dict__["_nbt_cache"] = (gen, lst)
+        return lst
 
     def forward(self, images):
         if not images.is_cuda:

@@ -175,6 +175,72 @@ class LazyEncoderOut(torch.Tensor):
             return func(*[sub(a) for a in args], **{k: sub(v) for k, v in kwargs.items()})
 
 
+class _BlockSave:
+    """What the forward of one bottleneck keeps for backward, for the blocks that go through ppv_bottleneck_fwd: the block input and
+    output as tensors, everything in between (raw conv outputs, activations, the output's sign mask, the three BatchNorm coefficient
+    sets) in ONE byte arena -- one ``torch.empty`` instead of nine.  Reads like the 13-tuple the per-kernel path stores
+    (xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits): indexing builds the view on demand (the per-kernel backward, the
+    tests' taps); ppv_bottleneck_bwd takes the addresses from ``ptr``."""
+    __slots__ = ("xin", "yout", "arena", "off", "shp", "prev", "ptr_bits", "prev_ptr")
+    _BF, _F32, _U8 = torch.bfloat16, torch.float32, torch.uint8
+
+    def __init__(self, xin, yout, arena, P, prev):
+        Bn, H, W, C3 = xin.shape
+        M = Bn * H * W
+        a256 = lambda n: (n + 255) & ~255
+        t, T, cc = a256(M * P * 2), a256(M * C3 * 2), a256(4 * P * 4)
+        # x1, y1, x2, y2, x3, bits, c1, c2, c3
+        o = [0, t, 2 * t, 3 * t, 4 * t, 4 * t + T]
+        o.append(o[-1] + a256(M * C3 // 8)); o.append(o[-1] + cc); o.append(o[-1] + cc)
+        self.xin, self.yout, self.arena, self.off, self.prev = xin, yout, arena, o, prev
+        self.shp = (Bn, H, W, P)
+        self.ptr_bits = arena.data_ptr() + o[5] if arena is not None else None
+        # address of the block INPUT's sign mask: the previous block's (a thunk when that block is a _BlockSave), none for the first
+        self.prev_ptr = None if prev is None else (prev.__self__.ptr_bits if callable(prev) else prev.data_ptr())
+
+    @staticmethod
+    def nbytes(M, P):
+        a256 = lambda n: (n + 255) & ~255
+        return 4 * a256(M * P * 2) + a256(M * 4 * P * 2) + a256(M * 4 * P // 8) + 2 * a256(16 * P) + a256(64 * P)
+
+    def ptr(self, k):                                   # k: 0 x1, 1 y1, 2 x2, 3 y2, 4 x3, 5 bits, 6 c1, 7 c2, 8 c3
+        return self.arena.data_ptr() + self.off[k]
+
+    def _view(self, k):
+        Bn, H, W, P = self.shp
+        M = Bn * H * W
+        if k <= 3:
+            return self.arena[self.off[k]: self.off[k] + M * P * 2].view(self._BF).view(Bn, H, W, P)
+        if k == 4:
+            return self.arena[self.off[4]: self.off[4] + M * 8 * P].view(self._BF).view(Bn, H, W, 4 * P)
+        if k == 5:
+            return self.arena[self.off[5]: self.off[5] + M * 4 * P // 8]
+        C = 4 * P if k == 8 else P
+        return self.arena[self.off[k]: self.off[k] + 16 * C].view(self._F32).view(4, C)
+
+    def bits(self):
+        return self._view(5)
+
+    def __len__(self):
+        return 13
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += 13
+        if i == 0:
+            return self.xin
+        if i == 11:
+            return self.yout
+        if i in (9, 10):
+            return None
+        if i == 12:
+            return self.prev() if callable(self.prev) else self.prev
+        return self._view({1: 0, 2: 6, 3: 1, 4: 2, 5: 7, 6: 3, 7: 4, 8: 8}[i])
+
+    def __iter__(self):
+        return (self[i] for i in range(13))
+
+
 class _TrunkFn(torch.autograd.Function):
     """(images f32 NCHW, *params) -> [B,E,E,2048] f32.  params follow Encoder._param_list()."""
 
@@ -250,19 +316,15 @@ class _TrunkFn(torch.autograd.Function):
                 n1, n3 = T_ * 2 * P_, T_ * 8 * P_
                 sbase = pool.data_ptr() + 4 * pool_off[0]
                 pool_off[0] += 2 * n1 + n3
-                x1 = torch.empty((Bn, Hin, Win, P_), dtype=torch.bfloat16, device=dev)
-                y1, x2, y2 = torch.empty_like(x1), torch.empty_like(x1), torch.empty_like(x1)
-                x3 = torch.empty((Bn, Hin, Win, 4 * P_), dtype=torch.bfloat16, device=dev)
-                yout = torch.empty_like(x3)
-                ybits = torch.empty(x3.numel() // 8, dtype=torch.uint8, device=dev)
-                c1 = torch.empty((4, P_), dtype=torch.float32, device=dev)
-                c2, c3 = torch.empty_like(c1), torch.empty((4, 4 * P_), dtype=torch.float32, device=dev)
+                arena = torch.empty(_BlockSave.nbytes(M1, P_), dtype=torch.uint8, device=dev)
+                yout = torch.empty((Bn, Hin, Win, 4 * P_), dtype=torch.bfloat16, device=dev)
+                bs = _BlockSave(xin, yout, arena, P_, xin_bits)
+                ap, ao = arena.data_ptr(), bs.off
                 a = bargs
                 a.xin, a.w1, a.w2, a.w3 = xin.data_ptr(), r1.wt(tok).data_ptr(), r2.wt(tok).data_ptr(), r3.wt(tok).data_ptr()
-                a.x1, a.y1, a.x2, a.y2, a.x3, a.yout, a.bits = (x1.data_ptr(), y1.data_ptr(), x2.data_ptr(), y2.data_ptr(), x3.data_ptr(),
-                                                                yout.data_ptr(), ybits.data_ptr())
+                a.x1, a.y1, a.x2, a.y2, a.x3, a.yout, a.bits = ap + ao[0], ap + ao[1], ap + ao[2], ap + ao[3], ap + ao[4], yout.data_ptr(), ap + ao[5]
                 a.stats1, a.stats2, a.stats3 = sbase, sbase + 4 * n1, sbase + 8 * n1
-                a.coef1, a.coef2, a.coef3 = c1.data_ptr(), c2.data_ptr(), c3.data_ptr()
+                a.coef1, a.coef2, a.coef3 = ap + ao[6], ap + ao[7], ap + ao[8]
                 for i_, r_ in ((1, r1), (2, r2), (3, r3)):
                     bn_ = r_.bn
                     setattr(a, "g%d" % i_, bn_.weight.data_ptr()); setattr(a, "b%d" % i_, bn_.bias.data_ptr())
@@ -271,9 +333,11 @@ class _TrunkFn(torch.autograd.Function):
                     setattr(a, "mom%d" % i_, _bn_momentum(bn_)); setattr(a, "eps%d" % i_, bn_.eps)
                 a.B, a.H, a.W, a.Cin, a.planes, a.stride, a.T1, a.T2, a.T3 = Bn, Hin, Win, xin.shape[3], P_, 1, T_, T_, T_
                 _lib.check(_lib.lib().ppv_bottleneck_fwd(_lib.ctypes.byref(a), _lib.stream_ptr()), "ppv_bottleneck_fwd")
-                blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, None, None, yout, xin_bits))
-                x, xin_bits = yout, ybits
+                blocks.append(bs)
+                x, xin_bits = yout, bs.bits          # the sign mask as a thunk: a view only if the per-kernel path asks for one
                 continue
+            if callable(xin_bits):
+                xin_bits = xin_bits()
             p = part_for(Bn * Hin * Win, r1.conv.out_channels, one_row=use_fold)
             x1 = co.conv_fwd(xin, r1.wt(tok), 1, 0, p)
             H2, W2 = Hin // r2.stride, Win // r2.stride
@@ -374,12 +438,17 @@ class _TrunkFn(torch.autograd.Function):
         grads = {}
         tok = ctx.tok
         # one scratch for the per-slice wgrad slabs, sized for the largest conv of this step and reused (stream order)
-        need = 0
-        for blk_, sv_ in zip(enc._blocks, ctx.blocks):
-            for rec_, gy_ in zip(blk_, (sv_[1], sv_[4], sv_[7], sv_[9])):
-                if rec_ is not None and rec_.conv.weight.requires_grad:
-                    w_ = rec_.conv.weight
-                    need = max(need, co.wgrad_scratch_bytes(gy_.numel() // gy_.shape[-1], w_.shape[0], rec_.k, rec_.k, w_.shape[1]))
+        nkey = (tuple(ctx.img_shape), sum(1 for blk_ in enc._blocks for rec_ in blk_ if rec_ is not None and rec_.conv.weight.requires_grad))
+        ncache = enc.__dict__.setdefault("_wneed_cache", {})
+        need = ncache.get(nkey)
+        if need is None:
+            need = 0
+            for blk_, sv_ in zip(enc._blocks, ctx.blocks):
+                for rec_, gy_ in zip(blk_, (sv_[1], sv_[4], sv_[7], sv_[9])):
+                    if rec_ is not None and rec_.conv.weight.requires_grad:
+                        w_ = rec_.conv.weight
+                        need = max(need, co.wgrad_scratch_bytes(gy_.numel() // gy_.shape[-1], w_.shape[0], rec_.k, rec_.k, w_.shape[1]))
+            ncache[nkey] = need
         wscratch = torch.empty(max(need, 16), dtype=torch.uint8, device=dev0)
 
         # one zeroed pool for every BN's [32][2][C] backward partial sums of this step
@@ -579,16 +648,25 @@ class _TrunkFn(torch.autograd.Function):
         for bi, (blk, sv) in enumerate(order):
             g_blk_out = g
             r1, r2, r3, rd = blk
-            xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits = sv
             if fast_bwd and rd is None and r2.stride == 1 and 4 * r1.conv.out_channels <= 2048:
                 P_ = r1.conv.out_channels
+                xin = sv[0]
                 Bn, Hh, Ww, _ = xin.shape
                 Mr = Bn * Hh * Ww
                 a = bwa
-                a.g, a.xin, a.x1, a.y1, a.x2, a.y2, a.x3 = (g.data_ptr(), xin.data_ptr(), x1.data_ptr(), y1.data_ptr(), x2.data_ptr(),
-                                                            y2.data_ptr(), x3.data_ptr())
-                a.xin_bits = xin_bits.data_ptr() if xin_bits is not None else None
-                a.c1, a.c2, a.c3 = c1.data_ptr(), c2.data_ptr(), c3.data_ptr()
+                if isinstance(sv, _BlockSave):
+                    ap_, ao_ = sv.arena.data_ptr(), sv.off
+                    a.x1, a.y1, a.x2, a.y2, a.x3 = ap_ + ao_[0], ap_ + ao_[1], ap_ + ao_[2], ap_ + ao_[3], ap_ + ao_[4]
+                    a.c1, a.c2, a.c3 = ap_ + ao_[6], ap_ + ao_[7], ap_ + ao_[8]
+                    a.xin_bits = sv.prev_ptr
+                    keep_side = (sv.arena, xin)                               # what the side stream reads of the saved tensors
+                else:
+                    _, x1, c1, y1, x2, c2, y2, x3, c3, _, _, _, xin_bits = sv
+                    a.x1, a.y1, a.x2, a.y2, a.x3 = x1.data_ptr(), y1.data_ptr(), x2.data_ptr(), y2.data_ptr(), x3.data_ptr()
+                    a.c1, a.c2, a.c3 = c1.data_ptr(), c2.data_ptr(), c3.data_ptr()
+                    a.xin_bits = xin_bits.data_ptr() if xin_bits is not None else None
+                    keep_side = (y2, y1, xin)
+                a.g, a.xin = g.data_ptr(), xin.data_ptr()
                 a.wd1, a.wd2, a.wd3 = r1.wd(tok).data_ptr(), r2.wd(tok).data_ptr(), r3.wd(tok).data_ptr()
                 if sums3 is not None:
                     a.part3, a.part3_ready = sums3.data_ptr(), 1
@@ -600,11 +678,12 @@ class _TrunkFn(torch.autograd.Function):
                 a.part2, a.part1 = pb, pb + 256 * P_
                 kb = kc_all.data_ptr()
                 a.kc3, a.kc2, a.kc1 = kb, kb + 4 * 3 * 2048, kb + 8 * 3 * 2048
-                gx3 = torch.empty_like(x3)
-                gy2, gx2, gy1, gx1 = torch.empty_like(x2), torch.empty_like(x2), torch.empty_like(x1), torch.empty_like(x1)
+                # the five gradients that never leave the block in ONE buffer (gx3 | gy2 | gx2 | gy1 | gx1), the block-input gradient a tensor
+                tb, Tb = (Mr * P_ * 2 + 255) & ~255, Mr * 8 * P_
+                work = torch.empty(Tb + 4 * tb, dtype=torch.uint8, device=dev0)
+                wp = work.data_ptr()
                 gin = torch.empty_like(xin)
-                a.gx3, a.gy2, a.gx2, a.gy1, a.gx1, a.gin = (gx3.data_ptr(), gy2.data_ptr(), gx2.data_ptr(), gy1.data_ptr(), gx1.data_ptr(),
-                                                            gin.data_ptr())
+                a.gx3, a.gy2, a.gx2, a.gy1, a.gx1, a.gin = wp, wp + Tb, wp + Tb + tb, wp + Tb + 2 * tb, wp + Tb + 3 * tb, gin.data_ptr()
                 outs, wouts = [], []
                 for i_, r_, C_ in ((3, r3, 4 * P_), (2, r2, P_), (1, r1, P_)):
                     if r_.bn.weight.requires_grad:
@@ -633,14 +712,20 @@ class _TrunkFn(torch.autograd.Function):
                 sums3 = None
                 a.x3_prev = a.part3_prev = None
                 if bi + 1 < len(order):
-                    x3_prev = order[bi + 1][1][7]
-                    if co.red_supported(x3_prev.numel() // x3_prev.shape[-1], x3_prev.shape[-1]):
-                        sums3 = bn_part(x3_prev.shape[-1])
-                        a.x3_prev, a.part3_prev = x3_prev.data_ptr(), sums3.data_ptr()
+                    svn = order[bi + 1][1]
+                    if isinstance(svn, _BlockSave):
+                        Cn, rows_n, x3p = 4 * svn.shp[3], svn.shp[0] * svn.shp[1] * svn.shp[2], svn.ptr(4)
+                    else:
+                        x3n = svn[7]
+                        Cn, rows_n, x3p = x3n.shape[-1], x3n.numel() // x3n.shape[-1], x3n.data_ptr()
+                    if co.red_supported(rows_n, Cn):
+                        sums3 = bn_part(Cn)
+                        a.x3_prev, a.part3_prev = x3p, sums3.data_ptr()
                 a.B, a.H, a.W, a.planes = Bn, Hh, Ww, P_
                 _lib.check(_lib.lib().ppv_bottleneck_bwd(_lib.ctypes.byref(a), main_stream.cuda_stream, side_ptr), "ppv_bottleneck_bwd")
                 if side is not None:                   # operands the side stream reads: the allocator must not recycle them before it has
-                    for t_ in (gx3, gx2, gx1, y2, y1, xin):
+                    work.record_stream(side)
+                    for t_ in keep_side:
                         t_.record_stream(side)
                 for p_, t_ in outs:
                     deliver(p_, t_)
@@ -649,6 +734,7 @@ class _TrunkFn(torch.autograd.Function):
                     sync.mark_ready(w_, stream=side)
                 g = gin
                 continue
+            xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits = sv
             hw_in, hw_mid = (xin.shape[1], xin.shape[2]), (y2.shape[1], y2.shape[2])
             # a down-sampling block's projection BatchNorm sees the same gradient as bn3: bn3's apply pass takes its sums too
             sumsd = bn_part(xd.shape[-1]) if (fuse_proj and rd is not None) else None
@@ -740,7 +826,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_nbt_cache"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_nbt_cache", "_wneed_cache"):
             st.pop(k, None)
         return st
 

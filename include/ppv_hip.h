@@ -145,6 +145,16 @@ int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S
 size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs);
 int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs,
                    int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream);
+/* The same with the slab reduce optionally left to the caller (several weight gradients of one bottleneck reduced by ONE launch):
+ * deferred != NULL and a kernel form with accumulator-order slabs -> no reduce launch, *deferred describes it (blocks > 0) and
+ * `scratch` must stay intact until ppv_wgrad_reduce_multi has run; blocks == 0: the call finished the gradient itself. */
+typedef struct PpvWgradReduce {
+    const void* slabs; float* out;
+    int N, C, R, S, nslab, TN, mode, blocks;
+} PpvWgradReduce;
+int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs,
+                   int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream, PpvWgradReduce* deferred);
+int ppv_wgrad_reduce_multi(const PpvWgradReduce* probs, int n, ppv_stream_t stream);
 
 /* P <= 24 weight gradients of ONE 1x1 / unit-stride shape in one launch, each reduced over all its rows by one workgroup per
  * tile (no split-M slabs, no scratch, no reduce launch): G[p] [B,H,W,N] bf16, X[p] [B,H,W,Cs] bf16 -> out[p] [N][Cs] f32.
@@ -208,6 +218,7 @@ typedef struct PpvBottleneckBwd {
     const void* x3_prev; float* part3_prev;
     const void* zero_page;
     int B, H, W, planes, part3_ready, red2, red1;
+    long wstride;                                         /* > 0: wscratch holds three regions wstride bytes apart, the block's slab reduces run as one launch */
 } PpvBottleneckBwd;
 int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, ppv_stream_t main_stream, ppv_stream_t side_stream);
 

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -131,10 +131,20 @@ class BottleneckBwd(ctypes.Structure):
                                    "part3", "part2", "part1", "kc3", "kc2", "kc1", "gx3", "gy2", "gx2", "gy1", "gx1", "gin",
                                    "dg3", "db3", "dg2", "db2", "dg1", "db1", "dw3", "dw2", "dw1", "wscratch", "x3_prev", "part3_prev",
                                    "zero_page")]
-                + [(n, _I) for n in ("B", "H", "W", "planes", "part3_ready", "red2", "red1")])
+                + [(n, _I) for n in ("B", "H", "W", "planes", "part3_ready", "red2", "red1")]
+                + [("_pad", _I), ("wstride", _L)])
 
 
 PROTOTYPES["ppv_bottleneck_bwd"] = (_I, [ctypes.POINTER(BottleneckBwd), _P, _P])
+
+
+class WgradReduce(ctypes.Structure):
+    """include/ppv_hip.h PpvWgradReduce."""
+    _fields_ = [("slabs", _P), ("out", _P)] + [(n, _I) for n in ("N", "C", "R", "S", "nslab", "TN", "mode", "blocks")]
+
+
+PROTOTYPES["ppv_conv_wgrad_ex"] = (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P, ctypes.POINTER(WgradReduce)])
+PROTOTYPES["ppv_wgrad_reduce_multi"] = (_I, [ctypes.POINTER(WgradReduce), _I, _P])
 
 _lib = None
 

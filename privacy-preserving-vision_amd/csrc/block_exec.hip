@@ -64,11 +64,17 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     const long M = (long)B * H * W;
     hipStream_t ws = side ? side : main;
     int e;
+    // the three weight gradients keep their slabs in three regions of wscratch (wstride bytes apart; 0: one region, reduce at once) and
+    // are reduced by ONE launch at the end of the block
+    PpvWgradReduce red[3];
+    red[0].blocks = red[1].blocks = red[2].blocks = 0;
+    const bool defer = a->wstride > 0;
+    char* wsb = (char*)a->wscratch;
     // bn3 backward (gradient arrives masked by the block output's ReLU; sums possibly taken by the data-gradient launch that produced it)
     if ((e = ppv_bn_bwd(a->g, nullptr, a->x3, a->c3, (double)M, a->gx3, nullptr, a->dg3, a->db3, a->part3, a->kc3, M, C3, 0, a->part3_ready ? 2 : 1, main))) return e;
     if (a->dw3) {
         if (side && (e = fork_to(main, side))) return e;
-        if ((e = ppv_conv_wgrad(a->gx3, a->y2, a->dw3, a->wscratch, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws))) return e;
+        if ((e = ppv_conv_wgrad_ex(a->gx3, a->y2, a->dw3, wsb, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws, defer ? &red[0] : nullptr))) return e;
     }
     // conv3 data gradient (+ bn2's sums and recomputed ReLU mask)
     if (a->red2) e = ppv_conv_gemm_red(a->gx3, a->wd3, a->gy2, a->part2, a->x2, a->c2, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 8, main);
@@ -77,7 +83,7 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     if ((e = ppv_bn_bwd(a->gy2, nullptr, a->x2, a->c2, (double)M, a->gx2, nullptr, a->dg2, a->db2, a->part2, a->kc2, M, P, a->red2 ? 0 : 2, a->red2 ? 2 : 1, main))) return e;
     if (a->dw2) {
         if (side && (e = fork_to(main, side))) return e;
-        if ((e = ppv_conv_wgrad(a->gx2, a->y1, a->dw2, a->wscratch, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws))) return e;
+        if ((e = ppv_conv_wgrad_ex(a->gx2, a->y1, a->dw2, wsb + (defer ? a->wstride : 0), a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws, defer ? &red[1] : nullptr))) return e;
     }
     // conv2 data gradient (+ bn1's sums)
     if (a->red1) e = ppv_conv_gemm_red(a->gx2, a->wd2, a->gy1, a->part1, a->x1, a->c1, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 8, main);
@@ -86,8 +92,10 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     if ((e = ppv_bn_bwd(a->gy1, nullptr, a->x1, a->c1, (double)M, a->gx1, nullptr, a->dg1, a->db1, a->part1, a->kc1, M, P, a->red1 ? 0 : 2, a->red1 ? 2 : 1, main))) return e;
     if (a->dw1) {
         if (side && (e = fork_to(main, side))) return e;
-        if ((e = ppv_conv_wgrad(a->gx1, a->xin, a->dw1, a->wscratch, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws))) return e;
+        if ((e = ppv_conv_wgrad_ex(a->gx1, a->xin, a->dw1, wsb + (defer ? 2 * a->wstride : 0), a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws, defer ? &red[2] : nullptr))) return e;
+        if (defer && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;
     }
+    if (defer && !a->dw1 && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;      // (a block whose conv1 alone is frozen)
     // conv1 data gradient + the identity branch's gradient + the block input's ReLU mask (+ the sums bn3 of the NEXT block to run needs)
     if (a->x3_prev) return ppv_conv_gemm_red(a->gx1, a->wd1, a->gin, a->part3_prev, a->x3_prev, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 8, main);
     return ppv_conv_gemm(a->gx1, a->wd1, a->gin, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 0, 0, main);

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "ppv_common.h"
+#include "ppv_hip.h"
 
 namespace ppv {
 
@@ -841,9 +842,8 @@ __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __rest
 // of one output row for 1x1 weights).  MODE 0: conv_wgrad_pipe_kernel<TN> tiles (NW = TN / 32 waves, 16 records per wave and lane, one
 // tap per tile); MODE 1: conv_wgrad3x3_kernel tiles (8 waves, 24 records: three taps of kernel row r).
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_reduce_native_kernel(const float* __restrict__ slabs, float* __restrict__ out, int N, int C,
-                                                                  int R, int S, int nslab, int TN) {
-    const long rec = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wgrad_reduce_native_body(const float* __restrict__ slabs, float* __restrict__ out, int N, int C,
+                                                            int R, int S, int nslab, int TN, long rec) {
     const long tot4 = (long)N * C * R * S / 4;
     if (rec >= tot4) return;
     const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + rec;
@@ -882,6 +882,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_native_kernel(const float* _
     float* o = out + ((long)n * C + c) * RS + tap;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[(long)j * C * RS] = a[j];
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_native_kernel(const float* __restrict__ slabs, float* __restrict__ out, int N, int C,
+                                                                  int R, int S, int nslab, int TN) {
+    wgrad_reduce_native_body<MODE>(slabs, out, N, C, R, S, nslab, TN, (long)blockIdx.x * 256 + threadIdx.x);
+}
+// up to four pending reduces (ppv_conv_wgrad_ex with `deferred`) in one launch: workgroup ranges [blk0, blk0 + blocks) per problem
+struct ReduceMulti { PpvWgradReduce p[4]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceMulti m) {
+    int i = 0;
+    unsigned b = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (i + 1 < m.n && b >= (unsigned)m.p[i].blocks) { b -= (unsigned)m.p[i].blocks; ++i; }
+    const PpvWgradReduce& q = m.p[i];
+    const long rec = (long)b * 256 + threadIdx.x;
+    if (q.mode == 0) wgrad_reduce_native_body<0>((const float*)q.slabs, q.out, q.N, q.C, q.R, q.S, q.nslab, q.TN, rec);
+    else wgrad_reduce_native_body<1>((const float*)q.slabs, q.out, q.N, q.C, q.R, q.S, q.nslab, q.TN, rec);
 }
 
 // ============================================================================= stem forward
@@ -1347,6 +1365,15 @@ size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
 // N % 128 == 0, Cs % 128 == 0.
 int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs, int Ws,
                    int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, hipStream_t stream) {
+    return ppv_conv_wgrad_ex(G, X, dW_out, scratch, zero_page, B, Hs, Ws, Cs, Ho, Wo, N, R, S, stride, pad, stream, nullptr);
+}
+
+// ppv_conv_wgrad whose slab reduce can be left to the caller: with `deferred` non-null and a kernel form that writes accumulator-order
+// slabs (the default forms), the reduce is NOT launched; *deferred describes it (blocks > 0) for ppv_wgrad_reduce_multi, and `scratch`
+// must stay untouched until that has run.  Forms that finish by themselves (atomics, streamed, [N][R][S][C] slabs) set blocks = 0.
+int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs, int Ws,
+                      int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, hipStream_t stream, PpvWgradReduce* deferred) {
+    if (deferred) deferred->blocks = 0;
     if (!G || !X || !dW_out || !scratch || !zero_page) return PPV_ERR_NULL;
     if (N % 128 || Cs % 128) return PPV_ERR_BAD_SIZE;
     WgradGeom g;
@@ -1402,6 +1429,10 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
             conv_wgrad3x3_kernel<2><<<grid3, 512, 2 * W3_STAGE, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
         else
             conv_wgrad3x3_kernel<3><<<grid3, 512, 3 * W3_STAGE, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g, log2W);
+        if (g.native_slabs && deferred) {
+            *deferred = PpvWgradReduce{slabs, dW_out, N, Cs, R, S, (int)sp3, 128, 1, (int)((elems / 4 + 255) / 256)};
+            return ppv_last_error();
+        }
         if (g.native_slabs) wgrad_reduce_native_kernel<1><<<(unsigned)((elems / 4 + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3, 128);
         else wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
         return ppv_last_error();
@@ -1497,6 +1528,10 @@ int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, c
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
         conv_wgrad_pipe_kernel<128, 4><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     }
+    if (g.native_slabs && deferred) {
+        *deferred = PpvWgradReduce{slabs, dW_out, N, Cs, R, S, nslab, TN, 0, (int)((elems / 4 + 255) / 256)};
+        return ppv_last_error();
+    }
     if (g.native_slabs) wgrad_reduce_native_kernel<0><<<(unsigned)((elems / 4 + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab, TN);
     else wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab);
     return ppv_last_error();
@@ -1524,6 +1559,20 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     conv_wgrad_group_kernel<128, 2><<<(unsigned)(8 * ((P + 7) / 8) * tiles), 256, lds, stream>>>(ptrs, P, (const bf16_t*)zero_page, g);
+    return ppv_last_error();
+}
+
+// the reduces ppv_conv_wgrad_ex left pending (n <= 4; entries with blocks == 0 are skipped), one launch
+int ppv_wgrad_reduce_multi(const PpvWgradReduce* probs, int n, hipStream_t stream) {
+    if (!probs) return PPV_ERR_NULL;
+    if (n < 0 || n > 4) return PPV_ERR_BAD_SIZE;
+    ReduceMulti m;
+    m.n = 0;
+    unsigned total = 0;
+    for (int i = 0; i < n; ++i)
+        if (probs[i].blocks > 0) { m.p[m.n++] = probs[i]; total += (unsigned)probs[i].blocks; }
+    if (!m.n) return PPV_OK;
+    wgrad_reduce_multi_kernel<<<total, 256, 0, stream>>>(m);
     return ppv_last_error();
 }
 

@@ -449,7 +449,9 @@ class _TrunkFn(torch.autograd.Function):
                         w_ = rec_.conv.weight
                         need = max(need, co.wgrad_scratch_bytes(gy_.numel() // gy_.shape[-1], w_.shape[0], rec_.k, rec_.k, w_.shape[1]))
             ncache[nkey] = need
-        wscratch = torch.empty(max(need, 16), dtype=torch.uint8, device=dev0)
+        wstride = (max(need, 16) + 255) & ~255
+        # three regions: ppv_bottleneck_bwd keeps the slabs of a block's three weight gradients apart and reduces them with one launch
+        wscratch = torch.empty(3 * wstride, dtype=torch.uint8, device=dev0)
 
         # one zeroed pool for every BN's [32][2][C] backward partial sums of this step
         bn_ch = sum(r.conv.out_channels for blk_ in enc._blocks for r in blk_ if r is not None) + 64
@@ -643,6 +645,10 @@ class _TrunkFn(torch.autograd.Function):
             bwa = _lib.BottleneckBwd()
             bwa.zero_page = co.zero_page(dev0).data_ptr()
             bwa.wscratch = wscratch.data_ptr()
+            # PPV_WGRAD_REDUCE3=1 (opt-in): one slab reduce per block instead of three (ppv_conv_wgrad_ex / ppv_wgrad_reduce_multi: 58
+            # launches fewer on the side stream).  MEASURED: 5680 / 5680 with against 5686 / 5693 images/s without -- the reduces were
+            # never on the critical path, and the slabs of the first two gradients now stay live until the third is done.
+            bwa.wstride = wstride if _os.environ.get("PPV_WGRAD_REDUCE3", "0") == "1" else 0
             kc_all = torch.empty(3 * 3 * 2048 + 64, dtype=torch.float32, device=dev0)     # coefficient scratch of the three BatchNorms (stream-ordered reuse)
             side_ptr = side.cuda_stream if side is not None else None
         for bi, (blk, sv) in enumerate(order):

@@ -379,3 +379,38 @@ def test_lazy_dense_output_is_written_on_first_access_only(one_adder_stats):
     with torch.no_grad():                                                                          # eval / no_grad path
         o3 = lazy_enc.eval()(img)
         assert rel_err(o3.float(), torch.nn.functional.adaptive_avg_pool2d(o3._ppv_cells.float().permute(0, 3, 1, 2), 36).permute(0, 2, 3, 1)) < 1e-6
+
+
+def test_block_launchers_equal_the_per_kernel_path(one_adder_stats, monkeypatch):
+    """ppv_bottleneck_fwd / ppv_bottleneck_bwd (one FFI crossing per block, default) against the per-kernel enqueue (PPV_BLOCK_EXEC=0):
+    the same launches with the same arguments: outputs bit for bit, gradients to the rounding of the atomics' order; likewise with
+    the three slab reduces of a block batched into one launch (PPV_WGRAD_REDUCE3=1: ppv_conv_wgrad_ex / ppv_wgrad_reduce_multi)."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(2, 2, 2, 2)).cuda().train()
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    img = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run():
+        enc.load_state_dict(sd)                                   # same running statistics at the start of every run
+        for p in enc.parameters():
+            p.grad = None
+        x = img.clone().requires_grad_(True)
+        out = enc(x)
+        out._ppv_cells.float().square().mean().backward()
+        return out._ppv_cells.detach().clone(), x.grad.clone(), [p.grad.clone() for p in enc.parameters() if p.requires_grad]
+
+    base = run()
+    monkeypatch.setenv("PPV_WGRAD_REDUCE3", "1")
+    red3 = run()
+    monkeypatch.setenv("PPV_WGRAD_REDUCE3", "0")
+    monkeypatch.setenv("PPV_BLOCK_EXEC", "0")
+    per_kernel = run()
+    # forward: bit for bit (one adder per statistic).  Backward: the BatchNorm-backward sums are folded by f32 atomics whose order is
+    # open in every mode (two runs of the SAME mode differ in the last bits too), so gradients are compared to rounding
+    for other in (red3, per_kernel):
+        assert torch.equal(base[0], other[0])
+        assert rel_err(other[1], base[1]) < 2e-2
+        assert len(base[2]) == len(other[2]) > 0
+        for a, b in zip(base[2], other[2]):
+            assert _cos(a, b) > 0.999

@@ -119,7 +119,7 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
     opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True, capturable=graph)
-    opt_cam = torch.optim.Adam(cam_params, lr=5e-7, capturable=graph)
+    opt_cam = torch.optim.Adam(cam_params, lr=5e-7, fused=os.environ.get("PPV_BENCH_CAM_ADAM_FUSED", "1") != "0", capturable=graph)
     rank = dist.get_rank() if dist.is_initialized() else 0
     imgs = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(device)
     # PPV_BENCH_H2D=1: the PCIe-inclusive variant (never `value`): the batch starts in pinned host memory every step

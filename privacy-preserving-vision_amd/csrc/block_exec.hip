@@ -39,16 +39,21 @@ int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, hipStream_t stream) {
 //   + ReLU mask of the block input + bn3 sums of the block this gradient flows into)
 namespace {
 hipEvent_t fork_event() {
-    // a small ring of timing-less events, created once; hipStreamWaitEvent captures the record that precedes it, so re-recording an
-    // event a later call has moved on from is fine
-    static hipEvent_t ring[256];
-    static bool made = false;
-    static unsigned next = 0;
-    if (!made) {
-        for (auto& e : ring) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        made = true;
+    // a small ring of timing-less events PER DEVICE (an event belongs to the device that was current when it was created; one process per
+    // GPU uses one ring), created on first use; hipStreamWaitEvent captures the record that precedes it, so re-recording an event a later
+    // call has moved on from is fine
+    constexpr int RING = 128, MAXDEV = 16;
+    static hipEvent_t ring[MAXDEV][RING];
+    static bool made[MAXDEV] = {};
+    static unsigned next[MAXDEV] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= MAXDEV - 1;
+    if (!made[dev]) {
+        for (auto& e : ring[dev]) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        made[dev] = true;
     }
-    return ring[next++ & 255];
+    return ring[dev][next[dev]++ & (RING - 1)];
 }
 int fork_to(hipStream_t main, hipStream_t side) {
     hipEvent_t e = fork_event();

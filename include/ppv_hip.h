@@ -222,6 +222,45 @@ typedef struct PpvBottleneckBwd {
 } PpvBottleneckBwd;
 int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, ppv_stream_t main_stream, ppv_stream_t side_stream);
 
+/* ---- whole-trunk executor (csrc/trunk_plan.hip): the forward of models.py:31-41's ResNet-101 trunk (train-mode BatchNorm, train.py:245)
+ * from ONE call and its backward from ONE call, over one caller-provided arena -- the launches and their order are those of the
+ * per-kernel entry points above (stem, projection bottlenecks, identity bottlenecks through ppv_bottleneck_fwd / _bwd, pools, weight
+ * gradients forked to `side`, final join).  The arena's layout is a pure function of PpvTrunkDesc: [zero zone: BatchNorm partial sums
+ * of the step, cleared with one memset per direction | what forward keeps for backward | per-block gradient buffers | scratch].
+ * A forward invalidates what the previous forward on the same arena kept. */
+#define PPV_TRUNK_MAX_BLOCKS 64
+typedef struct PpvTrunkBlock {
+    int planes, stride, proj;      /* torchvision Bottleneck(inplanes, planes, stride); proj != 0: downsample = conv1x1(stride) + BatchNorm */
+    int train_w;                   /* bit 0 / 1 / 2 / 3: conv1 / conv2 / conv3 / shortcut weight is trainable (sizes the slab scratch) */
+} PpvTrunkBlock;
+typedef struct PpvTrunkDesc {
+    int B, H, W, nblocks;          /* images [B,3,H,W]; H, W multiples of 32 */
+    int fold_rows;                 /* partial rows of the statistics the apply kernels fold themselves (ppv_bn_act_fold_rows) */
+    int wgrad_reduce3;             /* 1: the three slab reduces of an identity bottleneck as one launch */
+    int _r0, _r1;
+    PpvTrunkBlock blk[PPV_TRUNK_MAX_BLOCKS];
+} PpvTrunkDesc;
+typedef struct PpvTrunkConv {      /* one convolution + its BatchNorm: [0] = stem, [1 + 4 b + k] = conv1 / conv2 / conv3 / shortcut of block b */
+    const void *wt, *wd;           /* bf16 forward / data-gradient layouts (ppv_weight_layout modes 0 / 1; stem: ppv_stem_weight_layout) */
+    const float *gamma, *beta; float *rm, *rv;     /* BatchNorm weight, bias, running_mean, running_var (the last two may be null) */
+    float *dw, *dgamma, *dbeta;    /* gradient destinations (torch layouts, f32); null = frozen (models.py:43-54) */
+} PpvTrunkConv;
+typedef struct PpvTrunkHyper { float mom, eps; } PpvTrunkHyper;     /* same indexing as PpvTrunkConv */
+size_t ppv_trunk_arena_bytes(const PpvTrunkDesc* d);                 /* 0: unsupported geometry */
+int ppv_trunk_block_offsets(const PpvTrunkDesc* d, int blk, size_t* out20);
+int ppv_trunk_fwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, const PpvTrunkHyper* hy, const float* images, void* arena,
+                  void* cells_out, const void* zero_page, ppv_stream_t stream);
+/* blocks [blk_lo, blk_hi) in reverse order; blk_hi == nblocks: g_top = gradient of the output (g_kind 0: bf16 [B,h,w,C] already masked by
+ * the last ReLU; 1 / 2: f32 / bf16 [B,E,E,C] gradient of AdaptiveAvgPool2d(E)'s output, models.py:27,39); blk_lo == 0: the stem follows
+ * (g_img [B,3,H,W] f32 or null) and main_stream waits for side_stream.  cells: the cells_out of the forward call. */
+int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, const void* cells, const void* g_top, int g_kind, int E,
+                  float* g_img, const void* zero_page, int blk_lo, int blk_hi, ppv_stream_t main_stream, ppv_stream_t side_stream);
+/* event record on `from` + wait on `to` (a guarded ring of timing-less events per device) */
+int ppv_stream_fork(ppv_stream_t from, ppv_stream_t to);
+/* a stream restricted to CUs [first_cu, first_cu + n_cus) of the 256-bit CU mask (bits are dealt round-robin over the XCDs) */
+int ppv_stream_create_masked(ppv_stream_t* out, int first_cu, int n_cus);
+int ppv_stream_destroy(ppv_stream_t s);
+
 int ppv_bn_act_fold(const void* x, const float* sums, double count, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float momentum, float eps, float* coef, const void* r, void* y, void* pos_bits, long n, int C,
                     int res_mode, int relu, ppv_stream_t stream);

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -145,6 +145,29 @@ class WgradReduce(ctypes.Structure):
 
 PROTOTYPES["ppv_conv_wgrad_ex"] = (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P, ctypes.POINTER(WgradReduce)])
 PROTOTYPES["ppv_wgrad_reduce_multi"] = (_I, [ctypes.POINTER(WgradReduce), _I, _P])
+
+TRUNK_MAX_BLOCKS = 64
+
+
+class TrunkBlock(ctypes.Structure):
+    """include/ppv_hip.h PpvTrunkBlock."""
+    _fields_ = [(n, _I) for n in ("planes", "stride", "proj", "train_w")]
+
+
+class TrunkDesc(ctypes.Structure):
+    """include/ppv_hip.h PpvTrunkDesc."""
+    _fields_ = [(n, _I) for n in ("B", "H", "W", "nblocks", "fold_rows", "wgrad_reduce3", "_r0", "_r1")] + [("blk", TrunkBlock * TRUNK_MAX_BLOCKS)]
+
+
+TRUNK_CONV_FIELDS = ("wt", "wd", "gamma", "beta", "rm", "rv", "dw", "dgamma", "dbeta")    # PpvTrunkConv: nine pointers per convolution
+# the conv / hyper tables cross the boundary as flat arrays (c_uint64 * (9 n), c_float * (2 n)): filled with slice assignments
+PROTOTYPES["ppv_trunk_arena_bytes"] = (_Z, [ctypes.POINTER(TrunkDesc)])
+PROTOTYPES["ppv_trunk_block_offsets"] = (_I, [ctypes.POINTER(TrunkDesc), _I, _P])
+PROTOTYPES["ppv_trunk_fwd"] = (_I, [ctypes.POINTER(TrunkDesc), _P, _P, _P, _P, _P, _P, _P])
+PROTOTYPES["ppv_trunk_bwd"] = (_I, [ctypes.POINTER(TrunkDesc), _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P])
+PROTOTYPES["ppv_stream_fork"] = (_I, [_P, _P])
+PROTOTYPES["ppv_stream_create_masked"] = (_I, [ctypes.POINTER(_P), _I, _I])
+PROTOTYPES["ppv_stream_destroy"] = (_I, [_P])
 
 _lib = None
 

@@ -38,29 +38,8 @@ int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, hipStream_t stream) {
 //   bn3' -> [wgrad3] -> dgrad3 (+ bn2 sums) -> bn2' -> [wgrad2] -> dgrad2 (+ bn1 sums) -> bn1' -> [wgrad1] -> dgrad1 (+ residual gradient
 //   + ReLU mask of the block input + bn3 sums of the block this gradient flows into)
 namespace {
-hipEvent_t fork_event() {
-    // a small ring of timing-less events PER DEVICE (an event belongs to the device that was current when it was created; one process per
-    // GPU uses one ring), created on first use; hipStreamWaitEvent captures the record that precedes it, so re-recording an event a later
-    // call has moved on from is fine
-    constexpr int RING = 128, MAXDEV = 16;
-    static hipEvent_t ring[MAXDEV][RING];
-    static bool made[MAXDEV] = {};
-    static unsigned next[MAXDEV] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= MAXDEV - 1;
-    if (!made[dev]) {
-        for (auto& e : ring[dev]) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        made[dev] = true;
-    }
-    return ring[dev][next[dev]++ & (RING - 1)];
-}
-int fork_to(hipStream_t main, hipStream_t side) {
-    hipEvent_t e = fork_event();
-    if (hipError_t r = hipEventRecord(e, main)) return -(int)r;
-    if (hipError_t r = hipStreamWaitEvent(side, e, 0)) return -(int)r;
-    return PPV_OK;
-}
+// event record on `main` + wait on `side` through the guarded per-device event ring of trunk_plan.hip
+int fork_to(hipStream_t main, hipStream_t side) { return ppv_stream_fork(main, side); }
 }  // namespace
 
 int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t side) {

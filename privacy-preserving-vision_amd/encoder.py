@@ -241,6 +241,38 @@ class _BlockSave:
         return (self[i] for i in range(13))
 
 
+def masked_stream(dev, first_cu, n_cus):
+    """A stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (csrc/trunk_plan.hip ppv_stream_create_masked), as a torch
+    stream object.  The handle lives as long as the process."""
+    h = _lib.ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ppv_stream_create_masked(_lib.ctypes.byref(h), int(first_cu), int(n_cus)), "ppv_stream_create_masked")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+def _make_side_stream(dev):
+    """The stream the weight gradients run on beside the data-gradient / BatchNorm chain.  PPV_WGRAD_CUS=n (A/B): restricted
+    to n of the 256 CUs (spread over the XCDs); PPV_BWD_MAIN_CUS=m then runs the rest of the trunk's backward on the OTHER m CUs."""
+    import os
+    n = int(os.environ.get("PPV_WGRAD_CUS", "0"))
+    if n > 0:
+        return masked_stream(dev, 0, n)
+    return torch.cuda.Stream(device=dev)
+
+
+def _bwd_main_stream(enc, dev):
+    """None, or the masked stream the data-gradient / BatchNorm chain of backward runs on (PPV_BWD_MAIN_CUS=m: the top m CUs)."""
+    import os
+    m = int(os.environ.get("PPV_BWD_MAIN_CUS", "0"))
+    if m <= 0:
+        return None
+    st = enc.__dict__.get("_bwd_main_stream")
+    if st is None or st[0] != m:
+        st = (m, masked_stream(dev, 256 - m, m))
+        enc.__dict__["_bwd_main_stream"] = st
+    return st[1]
+
+
 class _TrunkFn(torch.autograd.Function):
     """(images f32 NCHW, *params) -> [B,E,E,2048] f32.  params follow Encoder._param_list()."""
 
@@ -263,144 +295,155 @@ class _TrunkFn(torch.autograd.Function):
             object.__setattr__(enc, "_wl_prefetched", False)
         else:
             enc._refresh_weight_layouts()
-        # one zeroed f32 pool for every conv's BN partial sums of this step ([rows<=32][2][C] each)
-        pool = torch.zeros(enc._stat_pool_elems(B, H, W), dtype=torch.float32, device=dev) if train else None
-        pool_off = [0]
-
-        # Train-mode BatchNorms without a projection partner take their statistics in TWO partial rows and the apply kernel derives the
-        # coefficients itself (co.bn_act_fold, csrc/trunk_ops.hip bn_act_fold_wg_kernel: thread j of every workgroup computes channel j's
-        # scale / shift while the rows are in flight): no bn_finalize launch between convolution and apply pass (92 of 104 per step).
-        # MEASURED (round 3, whole step, every configuration twice on one box): +0.7 .. +1.1 % (5566 -> 5619, 5497 -> 5532, 5619 -> 5683,
-        # 5603 -> 5644 images/s); one row: -0.3 .. 0 % (128 - 512 row tiles adding to one address at the end of the convolution), four
-        # rows: +0.4 %, eight: -1.5 %.  The first two forms of the fold lost: a 512-workgroup looped kernel (round 2, PPV_BN_FUSED) and
-        # per-THREAD coefficients from one row (-1.3 %; PPV_BN_FOLD_THREAD=1 keeps it reachable).  PPV_BN_FOLD_ACT=0: bn_finalize + bn_act.
-        fold_act = train and _os0.environ.get("PPV_BN_FOLD_ACT", "1") == "1"
-        # PPV_BLOCK_EXEC=0: every kernel of a bottleneck through its own FFI call (the form the roofline pass and the tests' taps use)
-        block_exec = train and _os0.environ.get("PPV_BLOCK_EXEC", "1") != "0"
-        bargs = _lib.BottleneckFwd()
-        bargs.zero_page = co.zero_page(dev).data_ptr()
-        fold_rows = max(1, int(_os0.environ.get("PPV_BN_FOLD_ROWS", "2")))     # partial rows the fold path's convolutions leave (adders per address = row tiles / this)
-
-        def part_for(M, C, one_row=False):
-            if not train:
-                return None
-            rows = min(fold_rows, co.stat_tiles(M)) if one_row else co.stat_tiles(M)
-            n = rows * 2 * C
-            v = pool[pool_off[0]:pool_off[0] + n].view(rows, 2, C)
-            pool_off[0] += n
-            return v
-
-        # ---- stem: conv 7x7/2 + BN + ReLU + maxpool 3x3/2  (resnet.0-3)
-        st = enc._stem
-        Ho, Wo = H // 2, W // 2
-        p0 = part_for(B * Ho * Wo, 64)
-        raw0 = co.stem_conv(images, st.wt(tok), p0)
-        c0 = _bn_coef(st, p0, B * Ho * Wo)
-        y0, arg0 = co.bn_relu_maxpool(raw0, c0)
-        saved["stem"] = (raw0, c0, y0, arg0)
-        x = y0
+        # Default train-mode step: the whole trunk from ONE FFI call over a persistent arena (ppv_amd/trunk_exec.py, csrc/trunk_plan.hip:
+        # the launches below in the same order, enqueued from C; no allocation, one memset).  The per-kernel form that follows is the
+        # reference the tests' taps, the per-class timing pass, eval mode and the opt-in schedules run (PPV_TRUNK_PLAN=0 forces it).
+        from . import trunk_exec as _tx
+        holder = None
         blocks = []
-        import os as _os
-        fused_bn = train and _os.environ.get("PPV_BN_FUSED", "0") == "1"      # 1: bn_finalize + bn_act in one launch (measured slower: DESIGN 4b)
-        xin_bits = None        # (block input > 0) bit mask; the first block's input is the max-pool output, masked by its own backward
-        for blk in enc._blocks:
-            xin = x
-            r1, r2, r3, rd = blk
-            Bn, Hin, Win, _ = xin.shape
-            use_fold = fold_act and not fused_bn and all(r_.bn.training for r_ in blk if r_ is not None)
-            if use_fold and block_exec and rd is None and r2.stride == 1 and co.PROFILE is None:
-                # one FFI crossing for the whole block (csrc/block_exec.hip: the same six launches in the same order)
-                P_ = r1.conv.out_channels
-                M1 = Bn * Hin * Win
-                T_ = min(fold_rows, co.stat_tiles(M1))
-                n1, n3 = T_ * 2 * P_, T_ * 8 * P_
-                sbase = pool.data_ptr() + 4 * pool_off[0]
-                pool_off[0] += 2 * n1 + n3
-                arena = torch.empty(_BlockSave.nbytes(M1, P_), dtype=torch.uint8, device=dev)
-                yout = torch.empty((Bn, Hin, Win, 4 * P_), dtype=torch.bfloat16, device=dev)
-                bs = _BlockSave(xin, yout, arena, P_, xin_bits)
-                ap, ao = arena.data_ptr(), bs.off
-                a = bargs
-                a.xin, a.w1, a.w2, a.w3 = xin.data_ptr(), r1.wt(tok).data_ptr(), r2.wt(tok).data_ptr(), r3.wt(tok).data_ptr()
-                a.x1, a.y1, a.x2, a.y2, a.x3, a.yout, a.bits = ap + ao[0], ap + ao[1], ap + ao[2], ap + ao[3], ap + ao[4], yout.data_ptr(), ap + ao[5]
-                a.stats1, a.stats2, a.stats3 = sbase, sbase + 4 * n1, sbase + 8 * n1
-                a.coef1, a.coef2, a.coef3 = ap + ao[6], ap + ao[7], ap + ao[8]
-                for i_, r_ in ((1, r1), (2, r2), (3, r3)):
-                    bn_ = r_.bn
-                    setattr(a, "g%d" % i_, bn_.weight.data_ptr()); setattr(a, "b%d" % i_, bn_.bias.data_ptr())
-                    setattr(a, "rm%d" % i_, bn_.running_mean.data_ptr() if bn_.running_mean is not None else None)
-                    setattr(a, "rv%d" % i_, bn_.running_var.data_ptr() if bn_.running_var is not None else None)
-                    setattr(a, "mom%d" % i_, _bn_momentum(bn_)); setattr(a, "eps%d" % i_, bn_.eps)
-                a.B, a.H, a.W, a.Cin, a.planes, a.stride, a.T1, a.T2, a.T3 = Bn, Hin, Win, xin.shape[3], P_, 1, T_, T_, T_
-                _lib.check(_lib.lib().ppv_bottleneck_fwd(_lib.ctypes.byref(a), _lib.stream_ptr()), "ppv_bottleneck_fwd")
-                blocks.append(bs)
-                x, xin_bits = yout, bs.bits          # the sign mask as a thunk: a view only if the per-kernel path asks for one
-                continue
-            if callable(xin_bits):
-                xin_bits = xin_bits()
-            p = part_for(Bn * Hin * Win, r1.conv.out_channels, one_row=use_fold)
-            x1 = co.conv_fwd(xin, r1.wt(tok), 1, 0, p)
-            H2, W2 = Hin // r2.stride, Win // r2.stride
-            if fused_bn and all(r_.bn.training for r_ in blk if r_ is not None):
-                # train mode: statistics -> coefficients -> apply in one launch per BatchNorm (co.bn_act_train)
-                y1, _, c1, _ = co.bn_act_train(x1, p, Bn * Hin * Win, r1.bn, _bn_momentum(r1.bn))
-                p = part_for(Bn * H2 * W2, r2.conv.out_channels)
-                x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
-                y2, _, c2, _ = co.bn_act_train(x2, p, Bn * H2 * W2, r2.bn, _bn_momentum(r2.bn))
-                p = part_for(Bn * H2 * W2, r3.conv.out_channels)
-                x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
-                if rd is not None:
-                    pd = part_for(Bn * H2 * W2, rd.conv.out_channels)
-                    xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, pd)
-                    yout, ybits, c3, cd = co.bn_act_train(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xd,
-                                                         res_stats=(pd, rd.bn, _bn_momentum(rd.bn)), want_bits=True)
-                else:
-                    xd = cd = None
-                    yout, ybits, c3, _ = co.bn_act_train(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xin, want_bits=True)
-                blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
-                x, xin_bits = yout, ybits
-                continue
-            if use_fold:
-                y1, _, c1 = co.bn_act_fold(x1, p, Bn * Hin * Win, r1.bn, _bn_momentum(r1.bn))
-                p = part_for(Bn * H2 * W2, r2.conv.out_channels, one_row=True)
-                x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
-                y2, _, c2 = co.bn_act_fold(x2, p, Bn * H2 * W2, r2.bn, _bn_momentum(r2.bn))
-                if rd is None:
-                    p = part_for(Bn * H2 * W2, r3.conv.out_channels, one_row=True)
-                    x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
-                    xd = cd = None
-                    yout, ybits, c3 = co.bn_act_fold(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xin, want_bits=True)
-                else:                      # projection shortcut: its BatchNorm's coefficients are needed too -> the two-launch form
+        if _tx.usable(enc, train):
+            x, holder = _tx.forward(enc, images, tok, enc._param_list())
+        if holder is None:
+            # one zeroed f32 pool for every conv's BN partial sums of this step ([rows<=32][2][C] each)
+            pool = torch.zeros(enc._stat_pool_elems(B, H, W), dtype=torch.float32, device=dev) if train else None
+            pool_off = [0]
+
+            # Train-mode BatchNorms without a projection partner take their statistics in TWO partial rows and the apply kernel derives the
+            # coefficients itself (co.bn_act_fold, csrc/trunk_ops.hip bn_act_fold_wg_kernel: thread j of every workgroup computes channel j's
+            # scale / shift while the rows are in flight): no bn_finalize launch between convolution and apply pass (92 of 104 per step).
+            # MEASURED (round 3, whole step, every configuration twice on one box): +0.7 .. +1.1 % (5566 -> 5619, 5497 -> 5532, 5619 -> 5683,
+            # 5603 -> 5644 images/s); one row: -0.3 .. 0 % (128 - 512 row tiles adding to one address at the end of the convolution), four
+            # rows: +0.4 %, eight: -1.5 %.  The first two forms of the fold lost: a 512-workgroup looped kernel (round 2, PPV_BN_FUSED) and
+            # per-THREAD coefficients from one row (-1.3 %; PPV_BN_FOLD_THREAD=1 keeps it reachable).  PPV_BN_FOLD_ACT=0: bn_finalize + bn_act.
+            fold_act = train and _os0.environ.get("PPV_BN_FOLD_ACT", "1") == "1"
+            # PPV_BLOCK_EXEC=0: every kernel of a bottleneck through its own FFI call (the form the roofline pass and the tests' taps use)
+            block_exec = train and _os0.environ.get("PPV_BLOCK_EXEC", "1") != "0"
+            bargs = _lib.BottleneckFwd()
+            bargs.zero_page = co.zero_page(dev).data_ptr()
+            fold_rows = max(1, int(_os0.environ.get("PPV_BN_FOLD_ROWS", "2")))     # partial rows the fold path's convolutions leave (adders per address = row tiles / this)
+            if torch.are_deterministic_algorithms_enabled():
+                fold_rows = 32             # one adder per statistics address: two forward passes agree bit for bit
+
+            def part_for(M, C, one_row=False):
+                if not train:
+                    return None
+                rows = min(fold_rows, co.stat_tiles(M)) if one_row else co.stat_tiles(M)
+                n = rows * 2 * C
+                v = pool[pool_off[0]:pool_off[0] + n].view(rows, 2, C)
+                pool_off[0] += n
+                return v
+
+            # ---- stem: conv 7x7/2 + BN + ReLU + maxpool 3x3/2  (resnet.0-3)
+            st = enc._stem
+            Ho, Wo = H // 2, W // 2
+            p0 = part_for(B * Ho * Wo, 64)
+            raw0 = co.stem_conv(images, st.wt(tok), p0)
+            c0 = _bn_coef(st, p0, B * Ho * Wo)
+            y0, arg0 = co.bn_relu_maxpool(raw0, c0)
+            saved["stem"] = (raw0, c0, y0, arg0)
+            x = y0
+            blocks = []
+            import os as _os
+            fused_bn = train and _os.environ.get("PPV_BN_FUSED", "0") == "1"      # 1: bn_finalize + bn_act in one launch (measured slower: DESIGN 4b)
+            xin_bits = None        # (block input > 0) bit mask; the first block's input is the max-pool output, masked by its own backward
+            for blk in enc._blocks:
+                xin = x
+                r1, r2, r3, rd = blk
+                Bn, Hin, Win, _ = xin.shape
+                use_fold = fold_act and not fused_bn and all(r_.bn.training for r_ in blk if r_ is not None)
+                if use_fold and block_exec and rd is None and r2.stride == 1 and co.PROFILE is None:
+                    # one FFI crossing for the whole block (csrc/block_exec.hip: the same six launches in the same order)
+                    P_ = r1.conv.out_channels
+                    M1 = Bn * Hin * Win
+                    T_ = min(fold_rows, co.stat_tiles(M1))
+                    n1, n3 = T_ * 2 * P_, T_ * 8 * P_
+                    sbase = pool.data_ptr() + 4 * pool_off[0]
+                    pool_off[0] += 2 * n1 + n3
+                    arena = torch.empty(_BlockSave.nbytes(M1, P_), dtype=torch.uint8, device=dev)
+                    yout = torch.empty((Bn, Hin, Win, 4 * P_), dtype=torch.bfloat16, device=dev)
+                    bs = _BlockSave(xin, yout, arena, P_, xin_bits)
+                    ap, ao = arena.data_ptr(), bs.off
+                    a = bargs
+                    a.xin, a.w1, a.w2, a.w3 = xin.data_ptr(), r1.wt(tok).data_ptr(), r2.wt(tok).data_ptr(), r3.wt(tok).data_ptr()
+                    a.x1, a.y1, a.x2, a.y2, a.x3, a.yout, a.bits = ap + ao[0], ap + ao[1], ap + ao[2], ap + ao[3], ap + ao[4], yout.data_ptr(), ap + ao[5]
+                    a.stats1, a.stats2, a.stats3 = sbase, sbase + 4 * n1, sbase + 8 * n1
+                    a.coef1, a.coef2, a.coef3 = ap + ao[6], ap + ao[7], ap + ao[8]
+                    for i_, r_ in ((1, r1), (2, r2), (3, r3)):
+                        bn_ = r_.bn
+                        setattr(a, "g%d" % i_, bn_.weight.data_ptr()); setattr(a, "b%d" % i_, bn_.bias.data_ptr())
+                        setattr(a, "rm%d" % i_, bn_.running_mean.data_ptr() if bn_.running_mean is not None else None)
+                        setattr(a, "rv%d" % i_, bn_.running_var.data_ptr() if bn_.running_var is not None else None)
+                        setattr(a, "mom%d" % i_, _bn_momentum(bn_)); setattr(a, "eps%d" % i_, bn_.eps)
+                    a.B, a.H, a.W, a.Cin, a.planes, a.stride, a.T1, a.T2, a.T3 = Bn, Hin, Win, xin.shape[3], P_, 1, T_, T_, T_
+                    _lib.check(_lib.lib().ppv_bottleneck_fwd(_lib.ctypes.byref(a), _lib.stream_ptr()), "ppv_bottleneck_fwd")
+                    blocks.append(bs)
+                    x, xin_bits = yout, bs.bits          # the sign mask as a thunk: a view only if the per-kernel path asks for one
+                    continue
+                if callable(xin_bits):
+                    xin_bits = xin_bits()
+                p = part_for(Bn * Hin * Win, r1.conv.out_channels, one_row=use_fold)
+                x1 = co.conv_fwd(xin, r1.wt(tok), 1, 0, p)
+                H2, W2 = Hin // r2.stride, Win // r2.stride
+                if fused_bn and all(r_.bn.training for r_ in blk if r_ is not None):
+                    # train mode: statistics -> coefficients -> apply in one launch per BatchNorm (co.bn_act_train)
+                    y1, _, c1, _ = co.bn_act_train(x1, p, Bn * Hin * Win, r1.bn, _bn_momentum(r1.bn))
+                    p = part_for(Bn * H2 * W2, r2.conv.out_channels)
+                    x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
+                    y2, _, c2, _ = co.bn_act_train(x2, p, Bn * H2 * W2, r2.bn, _bn_momentum(r2.bn))
                     p = part_for(Bn * H2 * W2, r3.conv.out_channels)
                     x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
-                    c3 = _bn_coef(r3, p, Bn * H2 * W2)
+                    if rd is not None:
+                        pd = part_for(Bn * H2 * W2, rd.conv.out_channels)
+                        xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, pd)
+                        yout, ybits, c3, cd = co.bn_act_train(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xd,
+                                                             res_stats=(pd, rd.bn, _bn_momentum(rd.bn)), want_bits=True)
+                    else:
+                        xd = cd = None
+                        yout, ybits, c3, _ = co.bn_act_train(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xin, want_bits=True)
+                    blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
+                    x, xin_bits = yout, ybits
+                    continue
+                if use_fold:
+                    y1, _, c1 = co.bn_act_fold(x1, p, Bn * Hin * Win, r1.bn, _bn_momentum(r1.bn))
+                    p = part_for(Bn * H2 * W2, r2.conv.out_channels, one_row=True)
+                    x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
+                    y2, _, c2 = co.bn_act_fold(x2, p, Bn * H2 * W2, r2.bn, _bn_momentum(r2.bn))
+                    if rd is None:
+                        p = part_for(Bn * H2 * W2, r3.conv.out_channels, one_row=True)
+                        x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
+                        xd = cd = None
+                        yout, ybits, c3 = co.bn_act_fold(x3, p, Bn * H2 * W2, r3.bn, _bn_momentum(r3.bn), res=xin, want_bits=True)
+                    else:                      # projection shortcut: its BatchNorm's coefficients are needed too -> the two-launch form
+                        p = part_for(Bn * H2 * W2, r3.conv.out_channels)
+                        x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
+                        c3 = _bn_coef(r3, p, Bn * H2 * W2)
+                        p = part_for(Bn * H2 * W2, rd.conv.out_channels)
+                        xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, p)
+                        cd = _bn_coef(rd, p, Bn * H2 * W2)
+                        yout, ybits = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=True)
+                    blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
+                    x, xin_bits = yout, ybits
+                    continue
+                c1 = _bn_coef(r1, p, Bn * Hin * Win)
+                y1 = co.bn_act(x1, c1)
+                p = part_for(Bn * H2 * W2, r2.conv.out_channels)
+                x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
+                c2 = _bn_coef(r2, p, Bn * H2 * W2)
+                y2 = co.bn_act(x2, c2)
+                p = part_for(Bn * H2 * W2, r3.conv.out_channels)
+                x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
+                c3 = _bn_coef(r3, p, Bn * H2 * W2)
+                if rd is not None:
                     p = part_for(Bn * H2 * W2, rd.conv.out_channels)
                     xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, p)
                     cd = _bn_coef(rd, p, Bn * H2 * W2)
-                    yout, ybits = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=True)
+                    yo = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=train)
+                else:
+                    xd = cd = None
+                    yo = co.bn_act(x3, c3, res=xin, want_bits=train)
+                yout, ybits = yo if train else (yo, None)
                 blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
                 x, xin_bits = yout, ybits
-                continue
-            c1 = _bn_coef(r1, p, Bn * Hin * Win)
-            y1 = co.bn_act(x1, c1)
-            p = part_for(Bn * H2 * W2, r2.conv.out_channels)
-            x2 = co.conv_fwd(y1, r2.wt(tok), r2.stride, 1, p)
-            c2 = _bn_coef(r2, p, Bn * H2 * W2)
-            y2 = co.bn_act(x2, c2)
-            p = part_for(Bn * H2 * W2, r3.conv.out_channels)
-            x3 = co.conv_fwd(y2, r3.wt(tok), 1, 0, p)
-            c3 = _bn_coef(r3, p, Bn * H2 * W2)
-            if rd is not None:
-                p = part_for(Bn * H2 * W2, rd.conv.out_channels)
-                xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, p)
-                cd = _bn_coef(rd, p, Bn * H2 * W2)
-                yo = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=train)
-            else:
-                xd = cd = None
-                yo = co.bn_act(x3, c3, res=xin, want_bits=train)
-            yout, ybits = yo if train else (yo, None)
-            blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
-            x, xin_bits = yout, ybits
         if getattr(enc, "lazy_output", False):
             # models.py:39-41's dense f32 tensor is ALLOCATED here and written on first access (LazyEncoderOut): ppv_amd's own consumers
             # read the 8 x 8 map instead
@@ -422,6 +465,7 @@ class _TrunkFn(torch.autograd.Function):
         if train:
             torch._foreach_add_(enc._nbt, 1)
         ctx.enc, ctx.saved, ctx.blocks, ctx.train, ctx.tok = enc, saved, blocks, train, tok
+        ctx.holder, ctx.cells = holder, (x if holder is not None else None)
         ctx.img_shape, ctx.last_hw = images.shape, (x.shape[1], x.shape[2])
         ctx.set_materialize_grads(False)
         # second output: the map the pool up-sampled (a view of the last block's output, so that returning it does not
@@ -437,6 +481,23 @@ class _TrunkFn(torch.autograd.Function):
                                       "runs under no_grad, train.py:355-451)")
         grads = {}
         tok = ctx.tok
+        if ctx.holder is not None:
+            # the plan executor's backward (csrc/trunk_plan.hip): one FFI call (one per gradient bucket in data-parallel runs)
+            from . import trunk_exec as _tx
+            import os as _os
+            side = None
+            if _os.environ.get("PPV_WGRAD_SIDE", "1") != "0":
+                side = getattr(enc, "_wgrad_stream", None)
+                if side is None:
+                    side = _make_side_stream(dev0)
+                    object.__setattr__(enc, "_wgrad_stream", side)
+            g_img, gd = _tx.backward(enc, ctx.holder, ctx.cells, g_out, g_cells, ctx.needs_input_grad[1], tuple(ctx.img_shape), side,
+                                     _bwd_main_stream(enc, dev0))
+            if enc.grad_sync is not None:
+                enc.grad_sync.end_of_backward()
+            if gd is None:
+                return (None, g_img) + (None,) * len(enc._param_list())
+            return (None, g_img) + tuple(gd.get(p) for p in enc._param_list())
         # one scratch for the per-slice wgrad slabs, sized for the largest conv of this step and reused (stream order)
         nkey = (tuple(ctx.img_shape), sum(1 for blk_ in enc._blocks for rec_ in blk_ if rec_ is not None and rec_.conv.weight.requires_grad))
         ncache = enc.__dict__.setdefault("_wneed_cache", {})
@@ -466,7 +527,7 @@ class _TrunkFn(torch.autograd.Function):
         if _os.environ.get("PPV_WGRAD_SIDE", "1") != "0":
             side = getattr(enc, "_wgrad_stream", None)
             if side is None:
-                side = torch.cuda.Stream(device=dev0)
+                side = _make_side_stream(dev0)
                 object.__setattr__(enc, "_wgrad_stream", side)
             side.wait_stream(torch.cuda.current_stream())
         main_stream = torch.cuda.current_stream()
@@ -832,7 +893,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_nbt_cache", "_wneed_cache"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_nbt_cache", "_wneed_cache", "_plans", "_bwd_main_stream"):
             st.pop(k, None)
         return st
 
@@ -886,6 +947,7 @@ class Encoder(nn.Module):
         wl.refresh()
 
     def invalidate_weight_cache(self):
+        self.__dict__["_wcache_gen"] = self.__dict__.get("_wcache_gen", 0) + 1      # the plan executor's pointer tables follow
         """Drop the cached bf16 layouts of the FROZEN convolutions (stem, layer1, everything under fine_tune(False)).  They are
         keyed on the parameter's version counter and storage pointer, which in-place writes through ``p.data`` (EMA, weight
         surgery) do not change; train() / eval() / load_state_dict() call this, call it yourself after such a write."""

@@ -414,3 +414,93 @@ def test_block_launchers_equal_the_per_kernel_path(one_adder_stats, monkeypatch)
         assert len(base[2]) == len(other[2]) > 0
         for a, b in zip(base[2], other[2]):
             assert _cos(a, b) > 0.999
+
+
+def _run_trunk(enc, sd, img, dense, extra=None):
+    enc.load_state_dict(sd)                                       # same running statistics at the start of every run
+    for p in enc.parameters():
+        p.grad = None
+    x = img.clone().requires_grad_(True)
+    out = enc(x)
+    if dense:                                                     # gradient arrives on the pooled [B,E,E,C] tensor (models.py:39-41)
+        w = torch.rand(out.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        (out * w).sum().backward()
+    else:
+        out._ppv_cells.float().square().mean().backward()
+    stats = [b.detach().clone() for n_, b in enc.named_buffers() if "running" in n_]
+    return out._ppv_cells.detach().clone(), x.grad.clone(), [p.grad.clone() for p in enc.parameters() if p.requires_grad], stats
+
+
+@pytest.mark.parametrize("layers,B,H,dense", [((2, 2, 2, 2), 4, 128, False), ((1, 2, 1, 1), 3, 64, True), ((3, 4, 23, 3), 2, 96, True)])
+def test_trunk_plan_equals_the_per_kernel_path(layers, B, H, dense, one_adder_stats, monkeypatch):
+    """ppv_trunk_fwd / ppv_trunk_bwd (csrc/trunk_plan.hip: the whole trunk from one FFI call per direction over one arena, the default)
+    against the per-kernel enqueue of encoder.py (PPV_TRUNK_PLAN=0 PPV_BLOCK_EXEC=0): the same launches with the same arguments --
+    outputs and running statistics bit for bit (one adder per statistic), gradients to the rounding of the atomics' order."""
+    from ppv_amd.encoder import Encoder
+    from ppv_amd import trunk_exec
+    torch.manual_seed(0)
+    enc = Encoder(layers=layers).cuda().train()
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    img = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(5)).cuda()
+    assert trunk_exec.usable(enc, True)
+    plan = _run_trunk(enc, sd, img, dense)
+    assert enc.__dict__.get("_plans"), "the plan executor did not run"
+    plan2 = _run_trunk(enc, sd, img, dense)                       # second step on the same (recycled) arena
+    monkeypatch.setenv("PPV_TRUNK_PLAN", "0")
+    monkeypatch.setenv("PPV_BLOCK_EXEC", "0")
+    per_kernel = _run_trunk(enc, sd, img, dense)
+    for other in (plan2, per_kernel):
+        assert torch.equal(plan[0], other[0])
+        for a, b in zip(plan[3], other[3]):             # running statistics: the stem's 64+ row tiles fold into 32 rows (order of those adds is open)
+            assert rel_err(a, b) < 1e-5
+        assert rel_err(other[1], plan[1]) < 2e-2
+        assert len(plan[2]) == len(other[2]) > 0
+        for a, b in zip(plan[2], other[2]):
+            assert _cos(a, b) > 0.999 and abs(float(a.norm() / b.norm()) - 1) < 2e-2
+
+
+def test_trunk_plan_gradient_ownership(one_adder_stats):
+    """The plan executor sets ``param.grad`` to slices of its flat buffer when no gradient is there, accumulates through autograd when
+    one is (micro-batching), serves a second backward with retain_graph, refuses one whose arena a later forward has overwritten, and
+    returns its arena when the graph dies without a backward (no_grad)."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    tr = [p for p in enc.parameters() if p.requires_grad]
+
+    def loss():
+        return enc(img)._ppv_cells.float().square().mean()
+
+    loss().backward()
+    g1 = [p.grad.clone() for p in tr]
+    plan = next(iter(enc._plans.values()))
+    assert len(plan.free) == 1                                    # the lease came back at the end of backward
+    base = plan.free[0].gflat
+    assert all(p.grad.untyped_storage().data_ptr() == base.untyped_storage().data_ptr() for p in tr)
+    loss().backward()                                             # gradients present: accumulated, not overwritten
+    for p, g in zip(tr, g1):
+        assert _cos(p.grad, 2 * g) > 0.9999 and abs(float(p.grad.norm() / (2 * g).norm()) - 1) < 1e-2
+    for p in tr:
+        p.grad = None
+    l_ = loss()
+    l_.backward(retain_graph=True)
+    g2 = [p.grad.clone() for p in tr]
+    for p in tr:
+        p.grad = None
+    l_.backward()                                                 # same arena, nothing in between: served again
+    for p, g in zip(tr, g2):
+        assert _cos(p.grad, g) > 0.9999
+    for p in tr:
+        p.grad = None
+    l_ = loss()
+    with torch.no_grad():
+        enc(img)                                                  # takes a second lease (the first is held by l_'s graph)
+    assert len(plan.free) == 1
+    l_.backward()
+    assert len(plan.free) == 2
+    l_ = loss()
+    l_.backward(retain_graph=True)
+    loss()                                                        # a later forward re-uses the arena l_'s graph points at
+    with pytest.raises(RuntimeError, match="overwritten"):
+        l_.backward()

@@ -28,7 +28,7 @@ def step(acc):
         for k, a, b in zip(T, t, t[1:]): T[k] += b - a
 for _ in range(4): step(False)
 torch.cuda.synchronize()
-N = 10
+N = int(os.environ.get('HB_STEPS', '10'))
 for _ in range(N): step(True)
 torch.cuda.synchronize()
 print("  ".join(f"{k} {v / N * 1e3:.2f} ms" for k, v in T.items()), " total %.2f ms" % (sum(T.values()) / N * 1e3))

@@ -77,7 +77,11 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
                    const float* psf_n, const double* g_psf_m, const float* g_psf_n, const double* g_loss,
                    const double* loss, float* g_coeffs, void* state, int RR, int P, int K, int up, float up_scale,
                    ppv_stream_t stream);
-/* Optional, once per (state, Z): marks the support of the basis inside `state` so that the two calls above skip the pixel groups
+/* Required once for a fresh state buffer, before its first use: clears the marks below (memory recycled from an earlier state could
+ * otherwise carry a valid-looking mark of another basis). */
+int ppv_ic_psf_state_init(void* state, int RR, int P, int K, ppv_stream_t stream);
+/* Optional, once per (state, Z) -- the mark is bound to the address of Z and to K, and ignored (full passes) for any other basis
+ * buffer; re-mark after writing into Z in place: marks the support of the basis inside `state` so that the two calls above skip the pixel groups
  * where every plane of Z is zero (outside the aperture disk of poppy.zernike_basis(outside=0), Utils.py:75-77; exact). */
 int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, ppv_stream_t stream);
 /* 1 when ppv_ic_psf_mark_support found the basis bitwise mirror-symmetric (every Noll term is even or odd under x -> -x and y -> -y on

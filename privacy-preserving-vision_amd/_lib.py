@@ -35,6 +35,7 @@ PROTOTYPES = {
     "ppv_ic_psf_state_bytes": (_Z, [_I, _I, _I]),
     "ppv_ic_psf_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ppv_ic_psf_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ppv_ic_psf_state_init": (_I, [_P, _I, _I, _I, _P]),
     "ppv_ic_psf_mark_support": (_I, [_P, _P, _I, _I, _I, _P]),
     "ppv_ic_psf_symmetric": (_I, [_P, _I, _I, _I, _P]),
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),

@@ -253,6 +253,7 @@ class OpticsZernike(nn.Module):
         # the basis is zero outside the aperture disk (poppy zernike_basis(outside=0), Utils.py:75-77): mark its support once so the two
         # 1.12-GB passes over it skip those pixels (exact; derived from the DATA, so a user-supplied volume is handled too)
         with torch.cuda.device(self.device):
+            check(L.ppv_ic_psf_state_init(ptr(self._state), RR, P, K, stream_ptr()), "ppv_ic_psf_state_init")
             check(L.ppv_ic_psf_mark_support(ptr(self.zernike_volume), ptr(self._state), RR, P, K, stream_ptr()), "ppv_ic_psf_mark_support")
 
     # ------------------------------------------------------------------ parameters / checkpoints

@@ -214,6 +214,8 @@ def linear_f32(x, w, bias=None, out=None):
     if K % 16 or x.stride(0) % 4 or w.stride(0) % 4 or x.data_ptr() % 16 or w.data_ptr() % 16:
         raise ValueError("linear_f32: K must be a multiple of 16 and rows 16-byte aligned")
     ks = L().ppv_gemm_f32_ksplit(m, N, K)
+    if ks > 2 and torch.are_deterministic_algorithms_enabled():
+        ks = 2          # two adders into a zeroed element commute: bit-reproducible (more would leave the order of the f32 atomics open)
     if out is None:
         out = (torch.zeros if ks > 1 else torch.empty)((m, N), dtype=F32, device=x.device)
     else:

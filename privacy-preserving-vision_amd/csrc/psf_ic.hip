@@ -210,11 +210,15 @@ __device__ __forceinline__ double2* dfft256(double2* a, double2* b, const double
 // h[px] = sum_k c[k] * Z[k][px]   (Lens.py:176; fp64 accumulate, one rounding to f32)
 // support (may be null): a 256-byte header + one byte per float4 pixel group, 0 where EVERY plane of the basis is zero there (outside
 // the aperture disk: 21.5 % of the 896^2 grid; ppv_ic_psf_mark_support marks it from the data, so any basis is handled): those groups
-// are not read.  The header's first word is a magic number written by the marking kernel: a state buffer that was never marked
-// (uninitialised memory) is read in full.
+// are not read.  The header holds a magic number AND the fingerprint of the basis it was marked for (address of Z, K), written by the
+// marking kernel: a state that was never marked (ppv_ic_psf_state_init clears the header), or one that is used with another basis
+// buffer than the one it was marked for (a recycled state block, a reassigned zernike_volume: r3 advisor), is read in full.
 constexpr unsigned long long SUPPORT_MAGIC = 0x5050565f53555050ull;
-__device__ __forceinline__ bool support_on(const unsigned char* support) {
-    return support && *reinterpret_cast<const unsigned long long*>(support) == SUPPORT_MAGIC;
+struct SupportHdr { unsigned long long magic, zptr; unsigned K, pad; };
+__device__ __forceinline__ bool support_on(const unsigned char* support, const float* Z, int K) {
+    if (!support) return false;
+    const SupportHdr* h = reinterpret_cast<const SupportHdr*>(support);
+    return h->magic == SUPPORT_MAGIC && h->zptr == (unsigned long long)(size_t)Z && h->K == (unsigned)K;
 }
 // ----------------------------------------------------------------------------- mirror symmetry of the basis
 // Z_j(x, y) = R(rho) * {cos | sin}(m theta) on a grid that is symmetric about its centre (poppy: x_i = (i - (n-1)/2) / ((n-1)/2)):
@@ -226,9 +230,11 @@ __device__ __forceinline__ bool support_on(const unsigned char* support) {
 // (zernike_contract_sym_kernel) and its adjoint (zernike_grad_sym_kernel) read 1/4 of the basis; the height map is bit-identical
 // to the full pass (same products up to an exact sign, same summation order per pixel).
 constexpr unsigned long long SYM_MAGIC = 0x5050565f53594d4dull;
-struct SymHdr { unsigned long long magic; unsigned bad; unsigned pad; };
-__device__ __forceinline__ bool sym_on(const unsigned char* sym) {
-    return sym && reinterpret_cast<const SymHdr*>(sym)->magic == SYM_MAGIC;
+struct SymHdr { unsigned long long magic; unsigned bad; unsigned K; unsigned long long zptr; };
+__device__ __forceinline__ bool sym_on(const unsigned char* sym, const float* Z, int K) {
+    if (!sym) return false;
+    const SymHdr* h = reinterpret_cast<const SymHdr*>(sym);
+    return h->magic == SYM_MAGIC && h->zptr == (unsigned long long)(size_t)Z && h->K == (unsigned)K;
 }
 __device__ __forceinline__ unsigned* sym_masks(unsigned char* sym) { return reinterpret_cast<unsigned*>(sym + 256); }
 __device__ __forceinline__ const unsigned char* sym_cls(const unsigned char* sym, int K) { return sym + 256 + (size_t)K * 4; }
@@ -238,12 +244,12 @@ __global__ __launch_bounds__(256) void zernike_contract_kernel(const float* __re
                                                                const unsigned char* __restrict__ support,
                                                                const unsigned char* __restrict__ sym) {
     extern __shared__ float s_c[];
-    if (sym_on(sym)) return;                       // zernike_contract_sym_kernel (launched beside this one) does the work
+    if (sym_on(sym, Z, K)) return;                       // zernike_contract_sym_kernel (launched beside this one) does the work
     for (int k = threadIdx.x; k < K; k += 256) s_c[k] = c[k];
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npx4) return;
-    if (support_on(support) && !support[256 + i]) {
+    if (support_on(support, Z, K) && !support[256 + i]) {
         reinterpret_cast<float4*>(h)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
@@ -264,9 +270,9 @@ __global__ __launch_bounds__(256) void zernike_grad_kernel(const float* __restri
                                                            double* __restrict__ part, int K, long npx4,
                                                            const unsigned char* __restrict__ support,
                                                            const unsigned char* __restrict__ sym) {
-    if (sym_on(sym)) return;                       // zernike_grad_sym_kernel does the work
+    if (sym_on(sym, Z, K)) return;                       // zernike_grad_sym_kernel does the work
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = i < npx4 && (!support_on(support) || support[256 + i]);   // groups outside the basis' support contribute exactly zero
+    const bool ok = i < npx4 && (!support_on(support, Z, K) || support[256 + i]);   // groups outside the basis' support contribute exactly zero
     const float4 g = ok ? reinterpret_cast<const float4*>(gh)[i] : make_float4(0, 0, 0, 0);
     const float4* z = reinterpret_cast<const float4*>(Z) + (ok ? i : 0);
     double* row = part + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * K;
@@ -307,7 +313,12 @@ __global__ __launch_bounds__(256) void zernike_support_kernel(const float* __res
     }
     support[256 + i] = any ? 1 : 0;
 }
-__global__ void zernike_support_seal_kernel(unsigned char* support) { *reinterpret_cast<unsigned long long*>(support) = SUPPORT_MAGIC; }
+__global__ void zernike_support_seal_kernel(unsigned char* support, const float* Z, int K) {
+    SupportHdr* h = reinterpret_cast<SupportHdr*>(support);
+    h->zptr = (unsigned long long)(size_t)Z;
+    h->K = (unsigned)K;
+    h->magic = SUPPORT_MAGIC;
+}
 
 // thread <-> (row y < R/2, column pair 2j < R/2): its float2 and the three mirror images
 struct QuadIdx { long q, qx, qy, qxy; bool ok; };
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void zernike_sym_check_kernel(const float* __r
         if ((threadIdx.x & 63) == 0 && m != 0xF) atomicAnd(&masks[k], m);
     }
 }
-__global__ __launch_bounds__(256) void zernike_sym_seal_kernel(unsigned char* sym, int K) {
+__global__ __launch_bounds__(256) void zernike_sym_seal_kernel(unsigned char* sym, int K, const float* Z) {
     __shared__ unsigned s_bad;
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
@@ -362,6 +373,8 @@ __global__ __launch_bounds__(256) void zernike_sym_seal_kernel(unsigned char* sy
     if (threadIdx.x == 0) {
         SymHdr* h = reinterpret_cast<SymHdr*>(sym);
         h->bad = s_bad;
+        h->zptr = (unsigned long long)(size_t)Z;
+        h->K = (unsigned)K;
         h->magic = s_bad ? 0ull : SYM_MAGIC;
     }
 }
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(256) void zernike_contract_sym_kernel(const float* 
                                                                    const unsigned char* __restrict__ support,
                                                                    const unsigned char* __restrict__ sym) {
     extern __shared__ float s_c4[];                 // [4][K]: c, c*sx, c*sy, c*sx*sy
-    if (!sym_on(sym)) return;
+    if (!sym_on(sym, Z, K)) return;
     const unsigned char* cls = sym_cls(sym, K);
     for (int k = threadIdx.x; k < K; k += 256) {
         const float ck = c[k];
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(256) void zernike_contract_sym_kernel(const float* 
     const QuadIdx ix = quad_index((long)blockIdx.x * 256 + threadIdx.x, R);
     if (!ix.ok) return;
     float2* h2 = reinterpret_cast<float2*>(h);
-    if (support_on(support) && !support[256 + (ix.q >> 1)]) {
+    if (support_on(support, Z, K) && !support[256 + (ix.q >> 1)]) {
         // the whole float4 group is outside the support, and so are its mirror images
         const float2 z0 = make_float2(0.f, 0.f);
         h2[ix.q] = z0; h2[ix.qx] = z0; h2[ix.qy] = z0; h2[ix.qxy] = z0;
@@ -419,12 +432,12 @@ __global__ __launch_bounds__(256) void zernike_grad_sym_kernel(const float* __re
                                                                const unsigned char* __restrict__ support,
                                                                const unsigned char* __restrict__ sym) {
     extern __shared__ unsigned char s_cls[];
-    if (!sym_on(sym)) return;
+    if (!sym_on(sym, Z, K)) return;
     const unsigned char* cls = sym_cls(sym, K);
     for (int k = threadIdx.x; k < K; k += 256) s_cls[k] = cls[k];
     __syncthreads();
     const QuadIdx ix = quad_index((long)blockIdx.x * 256 + threadIdx.x, R);
-    const bool ok = ix.ok && (!support_on(support) || support[256 + (ix.q >> 1)]);
+    const bool ok = ix.ok && (!support_on(support, Z, K) || support[256 + (ix.q >> 1)]);
     const float2* g2 = reinterpret_cast<const float2*>(gh);
     double dx[4] = {0, 0, 0, 0}, dy[4] = {0, 0, 0, 0};
     if (ok) {
@@ -483,8 +496,8 @@ __global__ __launch_bounds__(256) void zernike_grad_sym_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, float* __restrict__ out,
                                                            int nwg, int K, const unsigned char* __restrict__ sym = nullptr,
-                                                           int nwg_sym = 0) {
-    if (sym_on(sym)) nwg = nwg_sym;                // the quadrant form left fewer partial rows
+                                                           int nwg_sym = 0, const float* __restrict__ Z = nullptr) {
+    if (sym_on(sym, Z, K)) nwg = nwg_sym;                // the quadrant form left fewer partial rows
     // one workgroup per coefficient: 256 threads stride over the per-workgroup partials
     __shared__ double s_red[4];
     const int k = blockIdx.x;
@@ -927,7 +940,7 @@ void launch_grad(const float* Z, float* g_coeffs, const IcWs& w, int K, int RR, 
     const unsigned char* sym = sym_allowed() ? w.sym : nullptr;
     if (sym) zernike_grad_sym_kernel<<<quad_blocks(RR), 256, K, stream>>>(Z, w.gh, w.part, K, RR, w.support, sym);
     zernike_grad_kernel<<<nwg, 256, 0, stream>>>(Z, w.gh, w.part, K, npx4, w.support, sym);
-    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg * 4, K, sym, (int)quad_blocks(RR) * 4);
+    sum_partials_kernel<<<K, 256, 0, stream>>>(w.part, g_coeffs, (int)nwg * 4, K, sym, (int)quad_blocks(RR) * 4, Z);
 }
 
 }  // namespace
@@ -952,6 +965,17 @@ static void launch_dfft_cols(const double2* T1, double2* T2, const float2* Ht, c
 // Optional, once per (state, Z): mark where the basis Z [K][RR][RR] is non-zero, so that ppv_ic_psf_fwd / _bwd skip the pixel groups
 // outside its support (the aperture disk of poppy's zernike_basis(outside = 0): 21.5 % of the 1.12 GB read per direction).  Exact:
 // the skipped products are zeros.  Call again when Z changes; a state that was never marked is simply read in full.
+// Required once for a fresh state buffer (before the first ppv_ic_psf_fwd / _mark_support): clears the support and symmetry headers, so
+// that bytes left behind by an earlier owner of the memory can never be taken for a marking.
+int ppv_ic_psf_state_init(void* state, int RR, int P, int K, hipStream_t stream) {
+    if (!state) return PPV_ERR_NULL;
+    IcWs w;
+    carve(&w, (char*)state, RR, P, K);
+    if (hipError_t e = hipMemsetAsync(w.support, 0, 256, stream)) return -(int)e;
+    if (hipError_t e = hipMemsetAsync(w.sym, 0, 256, stream)) return -(int)e;
+    return PPV_OK;
+}
+
 int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, hipStream_t stream) {
     if (!Z || !state) return PPV_ERR_NULL;
     if (RR % 4 || (RR * (long)RR) % 4) return PPV_ERR_BAD_SIZE;
@@ -960,12 +984,12 @@ int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, h
     const long npx4 = (long)RR * RR / 4;
     (void)hipMemsetAsync(w.support, 0, 256, stream);
     zernike_support_kernel<<<(unsigned)((npx4 + 255) / 256), 256, 0, stream>>>(Z, w.support, K, npx4);
-    zernike_support_seal_kernel<<<1, 1, 0, stream>>>(w.support);
+    zernike_support_seal_kernel<<<1, 1, 0, stream>>>(w.support, Z, K);
     // mirror symmetry (see zernike_sym_check_kernel): header off, every sign pair still possible, then one pass over the basis
     (void)hipMemsetAsync(w.sym, 0, 256, stream);
     (void)hipMemsetAsync(w.sym + 256, 0xFF, (size_t)K * 4, stream);
     zernike_sym_check_kernel<<<quad_blocks(RR), 256, 0, stream>>>(Z, w.sym, K, RR);
-    zernike_sym_seal_kernel<<<1, 256, 0, stream>>>(w.sym, K);
+    zernike_sym_seal_kernel<<<1, 256, 0, stream>>>(w.sym, K, Z);
     return ppv_last_error();
 }
 

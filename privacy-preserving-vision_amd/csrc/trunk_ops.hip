@@ -737,7 +737,10 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const bf16_t* __res
 // The sums of the pass above taken over the POOLED tensors only.  A pooled element with y > 0 sends its gradient to exactly one
 // pre-pool position (its argmax), so  sum_p g_pre[p] = sum_o g[o] [y[o] > 0]  and  sum_p g_pre[p] x[p] = sum_o g[o] [y[o] > 0] x[argmax(o)],
 // and x at the argmax follows from the pooled activation itself: y = bf16(x * scale + shift) there, x = (y - shift) / scale (one bf16
-// rounding of the BatchNorm output away from the stored x; channels with |scale| < 1e-20 read x from the raw tensor instead).
+// rounding of the BatchNorm output away from the stored x).  The reconstruction loses 2^-9 |y| / |gamma| of x-hat: harmless while
+// |gamma| is comparable with |beta|, catastrophic for the near-dead channels of an ImageNet-pretrained bn1 (gamma down to 1e-8 next to
+// beta ~ 0.1: y = bf16(beta + gamma x-hat) keeps nothing of x-hat).  Channels with |gamma| < |beta| / 8 (or no usable scale at all)
+// therefore read x at the arg-max position of the raw tensor -- exact, a gather for those channels only (r3 advisor).
 // 134 MB instead of 400 MB at B = 128 (the raw stem output is not read).  part [8][2][C] pre-zeroed.
 __global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
                                                              const unsigned char* __restrict__ arg, const bf16_t* __restrict__ x,
@@ -750,10 +753,11 @@ __global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const bf16_t* __res
     bool exact[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float sc = coef[c0 + k];
-        exact[k] = !(fabsf(sc) >= 1e-20f);
+        const float sc = coef[c0 + k], shf = coef[C + c0 + k], mean = coef[2 * C + c0 + k], istd = coef[3 * C + c0 + k];
+        const float gamma = sc / istd, beta = shf + mean * sc;        // coef rows: scale = gamma invstd, shift = beta - mean scale, mean, invstd
+        exact[k] = !(fabsf(sc) >= 1e-20f) || !(fabsf(gamma) >= 0.125f * fabsf(beta));
         isc[k] = exact[k] ? 0.f : 1.f / sc;
-        sh[k] = coef[C + c0 + k];
+        sh[k] = shf;
         sa[k] = sb[k] = 0.f;
     }
     const long npool = (long)B * Ho * Wo;
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const bf16_t* __res
             for (int k = 0; k < 8; ++k) {
                 if (!(yv[k] > 0.f)) continue;
                 float xv = (yv[k] - sh[k]) * isc[k];
-                if (exact[k]) {                                   // (never taken for a BatchNorm with a usable scale)
+                if (exact[k]) {                                   // near-dead channel: x from the raw tensor at the arg-max
                     const int wo = (int)(o % Wo), ho = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
                     const int a = arg[o * C + c0 + k], r = a / 3, s_ = a % 3;
                     const int h = 2 * ho - 1 + r, w = 2 * wo - 1 + s_;

@@ -322,7 +322,7 @@ class _TrunkFn(torch.autograd.Function):
             bargs.zero_page = co.zero_page(dev).data_ptr()
             fold_rows = max(1, int(_os0.environ.get("PPV_BN_FOLD_ROWS", "2")))     # partial rows the fold path's convolutions leave (adders per address = row tiles / this)
             if torch.are_deterministic_algorithms_enabled():
-                fold_rows = 32             # one adder per statistics address: two forward passes agree bit for bit
+                fold_rows = 32             # 32 partial rows: <= 2 adders per address up to 8192 pixels (bit-reproducible there), fewest possible beyond
 
             def part_for(M, C, one_row=False):
                 if not train:
@@ -499,7 +499,9 @@ class _TrunkFn(torch.autograd.Function):
                 return (None, g_img) + (None,) * len(enc._param_list())
             return (None, g_img) + tuple(gd.get(p) for p in enc._param_list())
         # one scratch for the per-slice wgrad slabs, sized for the largest conv of this step and reused (stream order)
-        nkey = (tuple(ctx.img_shape), sum(1 for blk_ in enc._blocks for rec_ in blk_ if rec_ is not None and rec_.conv.weight.requires_grad))
+        # keyed on WHICH convolutions are trainable (not how many: another fine_tune split of equal count has other shapes -- r3 advisor)
+        nkey = (tuple(ctx.img_shape), tuple(i_ for i_, rec_ in enumerate(r_ for blk_ in enc._blocks for r_ in blk_)
+                                            if rec_ is not None and rec_.conv.weight.requires_grad))
         ncache = enc.__dict__.setdefault("_wneed_cache", {})
         need = ncache.get(nkey)
         if need is None:

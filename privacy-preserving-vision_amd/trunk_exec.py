@@ -186,7 +186,7 @@ def usable(enc, train):
 def get_plan(enc, B, H, W, plist):
     fold_rows = max(1, int(os.environ.get("PPV_BN_FOLD_ROWS", "2")))
     if torch.are_deterministic_algorithms_enabled():
-        fold_rows = 32                     # one adder per statistics address: two passes agree bit for bit (the default's two rows do not)
+        fold_rows = 32                     # 32 partial rows: <= 2 adders per address up to 8192 pixels (bit-reproducible there), fewest possible beyond
     reduce3 = os.environ.get("PPV_WGRAD_REDUCE3", "0") == "1"
     rg = tuple(p.requires_grad for p in plist)
     key = (B, H, W, fold_rows, reduce3)

@@ -504,3 +504,28 @@ def test_trunk_plan_gradient_ownership(one_adder_stats):
     loss()                                                        # a later forward re-uses the arena l_'s graph points at
     with pytest.raises(RuntimeError, match="overwritten"):
         l_.backward()
+
+
+def test_deterministic_mode_makes_two_default_passes_agree_bit_for_bit():
+    """The shipped default folds the BatchNorm statistics of a convolution into TWO partial rows with f32 atomics (order open: two
+    passes may differ in the last bit of a statistic).  torch.use_deterministic_algorithms(True) switches the trunk to 32 partial rows
+    (encoder.py / trunk_exec.py): with at most two row tiles per row -- up to 8192 pixels per map, as here -- every address has at most
+    two adders, which commute: outputs and running statistics of two passes are identical, without the test-only PPV_BN_FOLD_ROWS pin
+    of the other bit-exact tests.  (Larger maps keep several adders per address: reproducible to rounding)"""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(2, 2, 2, 2)).cuda().train()
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    img = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    torch.use_deterministic_algorithms(True)
+    try:
+        outs = []
+        for _ in range(3):
+            enc.load_state_dict(sd)
+            with torch.no_grad():
+                outs.append((enc(img)._ppv_cells.clone(), [b.clone() for n_, b in enc.named_buffers() if "running" in n_]))
+    finally:
+        torch.use_deterministic_algorithms(False)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0])
+        assert all(torch.equal(a, b) for a, b in zip(o[1], outs[0][1]))

@@ -329,3 +329,21 @@ def test_quadrant_form_of_the_basis_passes():
     vol[2, 300, 100] = -vol[2, 300, 100]
     cam4 = _make_448(vol)
     assert float(vol[2, 300, 100].abs()) > 0 and _is_symmetric(cam4) == 0
+
+
+def test_marks_are_bound_to_the_basis_they_were_made_for():
+    """r3 advisor: the support mask / quadrant classes live in the state block behind a magic word.  A mark must only count for the
+    basis buffer it was computed from: with ``zernike_volume`` replaced by another tensor (here one with mass in the corner and a
+    broken mirror symmetry) and NO re-marking, forward and backward must equal the unmarked full passes."""
+    cam = _make_448()
+    assert _is_symmetric(cam) == 1
+    vol = cam.zernike_volume.clone()
+    vol[5, :7, :9] = 1e-7
+    vol[2, 300, 100] = -vol[2, 300, 100]
+    cam.zernike_volume = vol                                                  # marks in cam._state still describe the old buffer
+    a = _run_448(cam, support=True, sym=True)                                 # (nothing wiped: the stale marks are all there)
+    h_a = _taps(cam)["h"].clone()
+    b = _run_448(cam, support=False, sym=False)                               # every mark wiped: the full passes
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(h_a, _taps(cam)["h"]) and float(h_a[:7, :9].abs().min()) > 0

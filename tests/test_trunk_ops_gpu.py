@@ -306,3 +306,36 @@ def test_fused_stem_backward_equals_autograd(B, H, C):
     F.max_pool2d(a, 3, stride=2, padding=1).backward(gy)
     assert rel_err(gx.float(), nhwc(x.grad)) < 3e-2          # the product's ReLU / arg-max decisions were taken on bf16 values
     assert rel_err(db, bn.bias.grad) < 3e-2 and rel_err(dg, bn.weight.grad) < 3e-2
+
+
+def test_fused_stem_backward_with_near_dead_channels():
+    """r3 advisor: the stem backward rebuilds the raw value from the pooled bf16 activation, x = (y - shift) / scale.  ImageNet-pretrained
+    bn1 (what models.py:17 loads) has gammas down to ~1e-8 beside betas of order 0.1: there the reconstruction is noise.  Such channels
+    must take x from the raw tensor (arg-max gather): gradients against torch autograd at the usual tolerance for EVERY gamma."""
+    import ppv_amd.convops as co
+    B, H, C = 2, 32, 64
+    g0 = torch.Generator().manual_seed(7)
+    x = r16(torch.randn(B, C, H, H, generator=g0) * 1.5 + 0.3).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C).train()
+    with torch.no_grad():
+        gam = torch.rand(C, generator=g0) + 0.5
+        gam[0::4] = 1e-8
+        gam[1::4] = 1e-3
+        gam[2::4] = 0.05
+        bn.weight.copy_(gam)
+        bn.bias.copy_(torch.rand(C, generator=g0) * 0.3 + 0.05)            # positive: the ReLU passes the near-dead channels
+    xd = nhwc(x.detach()).cuda().bfloat16()
+    xf = xd.float().view(-1, C)
+    sums = torch.stack([xf.sum(0), (xf * xf).sum(0)]).view(1, 2, C).contiguous()
+    coef = co.bn_finalize(sums, xf.shape[0], bn.weight.detach().cuda(), bn.bias.detach().cuda(), None, None, 0.1, bn.eps)
+    yd, arg = co.bn_relu_maxpool(xd, coef)
+    gy = r16(torch.randn(B, C, H // 2, H // 2, generator=g0))
+    gyd = nhwc(gy).cuda().bfloat16()
+    gx, dg, db = co.maxpool_bn_bwd(gyd, yd, arg, xd, coef, want_affine=True)
+    # the two-kernel path reads the raw tensor everywhere: the reference for what the sums must be
+    gpre = co.maxpool_relu_bwd(gyd, yd, arg, (H, H))
+    gx2, _, dg2, db2 = co.bn_bwd(gpre, None, xd, coef, False, want_affine=True)
+    for sel in (slice(0, None, 4), slice(1, None, 4), slice(2, None, 4), slice(3, None, 4)):
+        assert rel_err(dg[sel], dg2[sel]) < 2e-2, sel
+        assert rel_err(db[sel], db2[sel]) < 5e-3, sel
+        assert rel_err(gx.float()[..., sel], gx2.float()[..., sel]) < 3e-2, sel

@@ -443,6 +443,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the value_dense_surface and empty-queue host-enqueue legs (profiling runs: "
+                    "exactly warmup + steps headline steps, so per-step counter totals divide cleanly)")
     ap.add_argument("--decoder", action="store_true",
                     help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
                          "default is the headline Camera+ResNet-101 metric")
@@ -529,16 +531,18 @@ def main():
     # full and then enqueues at the device's pace, so `enqueued / K` above converges to ms_per_step whenever the host is the faster
     # side.  Two steps into an empty queue measure the interpreter + runtime alone.
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(2):
-        step()
-    host_free = (time.perf_counter() - t1) / 2
-    torch.cuda.synchronize()
+    host_free = None
+    if not args.no_dense:
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        host_free = (time.perf_counter() - t1) / 2
+        torch.cuda.synchronize()
 
     # The same step with the module's dense [B,36,36,2048] f32 output materialised and consumed (Encoder(lazy_output=False) + a head that
     # reads it and returns a dense gradient): what a foreign consumer of models.py:39-41's tensor pays.
     dense = None
-    if world == 1 and not args.decoder and not use_graph and not os.environ.get("PPV_BENCH_DENSE_HEAD") and hasattr(encoder, "lazy_output"):
+    if world == 1 and not args.decoder and not use_graph and not args.no_dense and not os.environ.get("PPV_BENCH_DENSE_HEAD") and hasattr(encoder, "lazy_output"):
         lazy0 = encoder.lazy_output
         encoder.lazy_output = False
         os.environ["PPV_BENCH_DENSE_HEAD"] = "1"
@@ -562,7 +566,7 @@ def main():
             "metric": "images/sec fwd+bwd, Camera+ResNet-101" + ("+attention decoder" if args.decoder else "") + " @256^2",
             "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "dist": ("rccl all-reduce exercised at world size 1" if force_dist else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "host_enqueue_ms_per_step": round(host_free * 1e3, 3),
+            "host_enqueue_ms_per_step": None if host_free is None else round(host_free * 1e3, 3),
             "host_enqueue_note": "interpreter + HIP runtime time to enqueue one step into an EMPTY queue (2 steps after a synchronise); "
                                  "host_enqueue_ms_per_step_timed_region is the same over the K timed steps, where a host that runs ahead "
                                  "is throttled by the full command queue",

@@ -339,6 +339,14 @@ int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* 
                     int n3, int s1, int s2, int s3, int f32, ppv_stream_t stream);
 /* bf16 split of an f32 matrix stacked along the rows: y [3*rows][Cp] = [hi; lo; hi] (mode 0) or [hi; hi; lo] (mode 1), so that
  * y0(g)^T y1(h) on ppv_conv_wgrad equals g^T h to ~2^-16: the decoder's batched weight gradients (models.py:199-214 autograd). */
+/* Operands of the weight gradient of an f32 NHWC convolution whose channel counts do not fit ppv_conv_wgrad's 128-wide tiles (the
+ * 3- / 64-channel layers of Face-DeId/core/model.py:12-53): one half of the bf16 split (part 0: hi = bf16(x), 1: lo = bf16(x - hi)) of
+ * x [rows][C] zero-padded to Cp channels, or of its R x S patch rows [B*Ho*Wo][Kp] (column (r S + s) C + c; a 1x1 weight gradient over
+ * Kp "channels" then gives the R x S x C one -- the K-padding of the trunk's stem).  Stacked along the batch as [hi; lo; hi] against
+ * [hi; hi; lo] the bf16 MFMA weight gradient equals the f32 one to ~2^-16. */
+int ppv_im2col_split(const float* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int Kp,
+                     int part, ppv_stream_t stream);
+int ppv_pad_split(const float* x, void* out, long rows, int C, int Cp, int part, ppv_stream_t stream);
 int ppv_split3_rows(const float* x, long ldx, void* y, long rows, int C, int Cp, int mode, ppv_stream_t stream);
 int ppv_bn_act_split3(const float* x, const float* coef, void* y, long rows, int C, int Cp, int relu, int ldx, ppv_stream_t stream);
 int ppv_fan_head(const void* raw, const float* bias, float* raw_out, float* sums, float* heat, int B, int S, int ldr,

@@ -1096,6 +1096,43 @@ class Encoder(nn.Module):
                 taps.append(y)
         return torch.nn.functional.adaptive_avg_pool2d(y.permute(0, 3, 1, 2), self.enc_image_size).permute(0, 2, 3, 1).contiguous()
 
+    def forward_fp32_train(self, images):
+        """fp32-accurate TRAINING pass of the trunk (parity instrument, not the product path): like forward_fp32_accurate every
+        convolution runs on the hand-written MFMA kernels as three bf16 products accumulated in f32 -- forward, data gradient AND
+        weight gradient (ppv_amd.nn_ops.conv2d_f32, accurate_wgrad) -- with f32 activations end to end; train-mode BatchNorm (batch
+        statistics, biased variance: models.py:31-41 under train.py:245), ReLU, the residual adds and the pools are f32 torch
+        element-wise / reduction ops on the device, differentiated by autograd.  Running statistics are NOT updated.  images
+        [B,3,H,W] -> [B,E,E,2048] f32 attached to the graph: BASELINE configs[0] (batch 4, fp32) has a reference-precision step on
+        the GPU whose lens gradient can be held against the CPU reference tightly (tests/test_config0_gpu.py)."""
+        from .nn_ops import conv2d_f32
+        F_ = torch.nn.functional
+        if not images.is_cuda:
+            raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
+        x = F_.pad(images.float().permute(0, 2, 3, 1), (0, 5)).contiguous()                    # NHWC f32, 3 -> 8 channels (vector split)
+
+        def bn(t, m, res=None, relu=True):
+            mean = t.mean(dim=(0, 1, 2))
+            var = (t - mean).square().mean(dim=(0, 1, 2))
+            y = (t - mean) * (torch.rsqrt(var + m.eps) * m.weight) + m.bias
+            if res is not None:
+                y = y + res
+            return torch.relu(y) if relu else y
+
+        def conv(t, rec):
+            w = rec.conv.weight
+            return conv2d_f32(t, w, None, rec.stride, rec.pad, weight_grad=w.requires_grad, accurate_wgrad=True)
+
+        st = self._stem
+        w0 = F_.pad(st.conv.weight, (0, 0, 0, 0, 0, 5))
+        y = bn(conv2d_f32(x, w0, None, 2, 3, weight_grad=st.conv.weight.requires_grad, accurate_wgrad=True), st.bn)
+        y = F_.max_pool2d(y.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        for r1, r2, r3, rd in self._blocks:
+            o = bn(conv(y, r1), r1.bn)
+            o = bn(conv(o, r2), r2.bn)
+            idn = y if rd is None else bn(conv(y, rd), rd.bn, relu=False)
+            y = bn(conv(o, r3), r3.bn, res=idn)
+        return F_.adaptive_avg_pool2d(y.permute(0, 3, 1, 2), self.enc_image_size).permute(0, 2, 3, 1).contiguous()
+
     def fine_tune(self, fine_tune=True):
         """models.py:43-54: freeze everything, then un-freeze children [5:] (layer2..4)."""
         for p in self.resnet.parameters():

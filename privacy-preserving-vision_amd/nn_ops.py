@@ -4,8 +4,8 @@ the frozen regressor into the generated image) and the StarGAN-v2 blocks (core/m
 
 ``conv2d_f32``  convolution as three bf16 MFMA products accumulated in f32 ([x_hi | x_lo | x_hi] x [W_hi | W_hi | W_lo], product
                 error ~2^-16), forward AND data gradient (the same split on the incoming gradient against the flipped weights);
-                weight gradient on the bf16 MFMA weight-gradient kernel where its tile rules hold (channel counts multiples of
-                128), otherwise ``torch.nn.grad.conv2d_weight`` (library, on the device).
+                weight gradient on the bf16 MFMA weight-gradient kernel: directly where its tile rules hold (channel counts
+                multiples of 128), otherwise on zero-padded bf16-split operands / K-padded patch rows (``_wgrad_padded``).
 ``instance_norm_act``  InstanceNorm2d / AdaIN + LeakyReLU, forward and backward (csrc/instnorm.hip)."""
 import weakref
 
@@ -65,10 +65,43 @@ def _split3(t):
     return y
 
 
+def _wgrad_padded(gy, x, wshape, stride, pad):
+    """Weight gradient [Cout,Cin,R,S] f32 of an NHWC f32 convolution with ANY channel counts on the MFMA weight-gradient kernel
+    (ppv_conv_wgrad wants multiples of 128): both operands as bf16-split halves stacked along the batch, x -> [hi; lo; hi], gy ->
+    [hi; hi; lo] (the sum over the batch then holds x_hi g_hi + x_lo g_hi + x_hi g_lo: the f32 product to ~2^-16), zero-padded to 128
+    channels.  Very few input channels (the RGB convolutions) go through their R x S patch rows instead (csrc/im2col.hip): K = R S Cin
+    padded to 128 and a 1x1 weight gradient -- padding 3 channels to 128 per tap would move 40x the bytes."""
+    Cout, Cin, R, S = wshape
+    B, H, W, _ = x.shape
+    _, Ho, Wo, _ = gy.shape
+    L = _lib.lib()
+    dev = x.device
+    Np = (Cout + 127) // 128 * 128
+    gs = torch.empty((3 * B, Ho, Wo, Np), dtype=torch.bfloat16, device=dev)
+    rows_g = B * Ho * Wo
+    for j, part in enumerate((0, 0, 1)):
+        check(L.ppv_pad_split(ptr(gy), gs[j * B].data_ptr(), rows_g, Cout, Np, part, stream_ptr()), "ppv_pad_split")
+    if Cin < 32 and R * S * Cin <= 512:
+        Kp = (R * S * Cin + 127) // 128 * 128
+        xs = torch.empty((3 * B, Ho, Wo, Kp), dtype=torch.bfloat16, device=dev)
+        for j, part in enumerate((0, 1, 0)):
+            check(L.ppv_im2col_split(ptr(x), xs[j * B].data_ptr(), B, H, W, Cin, Ho, Wo, R, S, stride, pad, Kp, part, stream_ptr()),
+                  "ppv_im2col_split")
+        gw = co.conv_wgrad(gs, xs, 1, 1, 1, 0)                                   # [Np, Kp, 1, 1]
+        return gw.view(Np, Kp)[:Cout, :R * S * Cin].reshape(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
+    Cp = (Cin + 127) // 128 * 128
+    xs = torch.empty((3 * B, H, W, Cp), dtype=torch.bfloat16, device=dev)
+    for j, part in enumerate((0, 1, 0)):
+        check(L.ppv_pad_split(ptr(x), xs[j * B].data_ptr(), B * H * W, Cin, Cp, part, stream_ptr()), "ppv_pad_split")
+    gw = co.conv_wgrad(gs, xs, R, S, stride, pad)                                # [Np, Cp, R, S]
+    return gw[:Cout, :Cin].contiguous()
+
+
 class _ConvF32(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, wf, wd):
+    def forward(ctx, x, weight, bias, stride, pad, wf, wd, accurate_wgrad=False):
         _lib.require_cuda(x, weight)
+        ctx.accurate_wgrad = accurate_wgrad
         x = x.contiguous().float()
         Cout, Cin, R, S = weight.shape
         assert R == S and x.shape[-1] == Cin
@@ -94,24 +127,25 @@ class _ConvF32(torch.autograd.Function):
             if gx.shape[-1] != Cin:
                 gx = gx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
-            if Cout % 128 == 0 and Cin % 128 == 0:
+            if Cout % 128 == 0 and Cin % 128 == 0 and not ctx.accurate_wgrad:
                 gw = co.conv_wgrad(gy.bfloat16(), x.bfloat16(), R, S, stride, pad)
             else:                                       # outside the MFMA weight-gradient kernel's tiles (3- and 64-channel layers)
-                gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, gy.permute(0, 3, 1, 2), stride=stride, padding=pad)
+                gw = _wgrad_padded(gy, x, weight.shape, stride, pad)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(dim=(0, 1, 2))
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv2d_f32(x, weight, bias=None, stride=1, pad=0, weight_grad=True):
+def conv2d_f32(x, weight, bias=None, stride=1, pad=0, weight_grad=True, accurate_wgrad=False):
     """x [B,H,W,Cin] f32 NHWC, weight [Cout,Cin,k,k] (torch layout, e.g. an nn.Conv2d's parameter) -> [B,Ho,Wo,Cout] f32.
     weight_grad=False: the weight (and bias) are treated as constants whatever their requires_grad says (a frozen network, FAN in
-    core/wing.py:262-272) -- the bf16 layouts stay cached on the Parameter object itself."""
+    core/wing.py:262-272) -- the bf16 layouts stay cached on the Parameter object itself.  accurate_wgrad: the weight gradient from
+    the bf16-split operands (~2^-16) for every shape (default: one bf16 product where the channel counts fit the kernel's tiles)."""
     wf, wd = _layouts(weight)
     if not weight_grad:
         weight = weight.detach()
         bias = None if bias is None else bias.detach()
-    return _ConvF32.apply(x, weight, bias, stride, pad, wf, wd)
+    return _ConvF32.apply(x, weight, bias, stride, pad, wf, wd, accurate_wgrad)
 
 
 class _InstNormAct(torch.autograd.Function):

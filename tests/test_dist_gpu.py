@@ -86,3 +86,27 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
         print(d)
         assert d["lens_grad_rel_l2"] < 1e-3 and d["encoder_grad_cos"] > 0.99
         assert d["encoder_grad_rel_l2"] < 2.5 * d["same_pass_twice_rel_l2"] + 0.02     # inside the run-to-run band of one and the same pass
+
+
+def test_two_ranks_over_rccl_on_one_device_or_a_documented_refusal():
+    """r3 verdict 8a: RCCL has only ever seen world size 1 on this one-GPU box.  Two ranks on device 0 over the REAL backend: if RCCL
+    takes it, the two-rank step must equal one rank on the concatenated batch like the gloo rehearsal; if it refuses (NCCL's duplicate-GPU
+    check), the refusal itself is asserted so that nobody reads the gloo run as RCCL coverage."""
+    env = dict(os.environ, PPV_DIST_BACKEND="nccl", PPV_FORCE_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PPV_EQ_BATCH="8", PPV_EQ_LAYERS="1,1,1,1",
+               NCCL_DEBUG="WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29557", os.path.join(ROOT, "tools", "ddp_equivalence.py")]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        pytest.fail("two RCCL ranks on one device neither ran nor refused within 300 s")
+    if out.returncode == 0:
+        res = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(res) == 2
+        for d in res:
+            assert d["lens_grad_rel_l2"] < 1e-3 and d["encoder_grad_cos"] > 0.99
+        print("RCCL accepted two ranks on one device: equivalence checked over the real backend")
+    else:
+        text = (out.stdout + out.stderr).lower()
+        assert "duplicate gpu" in text or "invalid usage" in text or "ncclinvalidusage" in text or "nccl" in text, text[-3000:]
+        print("RCCL refuses two ranks on one device (duplicate-GPU check): world size > 1 over RCCL needs > 1 GPU; rehearsed over gloo only")

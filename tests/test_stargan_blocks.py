@@ -69,3 +69,33 @@ def test_hip_blocks_match_the_reference_golden(tag):
             assert float(p.grad.abs().max()) < 1e-3, n
             continue
         assert rel_err(p.grad, want) < 1e-2, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,B,H", [(3, 64, 3, 1, 1, 2, 32), (3, 64, 7, 2, 3, 2, 32), (64, 64, 3, 1, 1, 2, 16), (64, 128, 3, 1, 1, 2, 16),
+                                                       (64, 128, 1, 1, 0, 3, 16), (128, 64, 3, 1, 1, 2, 16), (6, 32, 1, 1, 0, 2, 16)])
+def test_small_channel_weight_gradients_run_on_the_mfma_kernel(Cin, Cout, k, stride, pad, B, H):
+    """Face-DeId/core/model.py:12-53: the 3- / 64-channel convolutions of the StarGAN-v2 blocks train; their weight gradient runs on the
+    MFMA weight-gradient kernel over zero-padded bf16-split operands (64-channel layers) or K-padded patch rows (RGB layers) instead of
+    the library (round 3: torch.nn.grad.conv2d_weight).  Checked against torch autograd in f32 -- the split keeps ~2^-16."""
+    from ppv_amd import nn_ops
+    g0 = torch.Generator().manual_seed(Cin * 100 + Cout + k)
+    x = torch.randn(B, H, H, Cin, generator=g0).cuda()
+    w = (torch.randn(Cout, Cin, k, k, generator=g0) * 0.1).cuda().requires_grad_(True)
+    y = nn_ops.conv2d_f32(x, w, None, stride, pad)
+    gy = torch.randn(y.shape, generator=g0).cuda()
+    y.backward(gy)
+    wr = w.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), wr, None, stride, pad)
+    yr.backward(gy.permute(0, 3, 1, 2))
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) < 1e-4
+    assert rel_err(w.grad, wr.grad) < 2e-4
+
+
+def test_no_library_weight_gradient_in_nn_ops():
+    """f3 of SURVEY 8f: nothing in ppv_amd.nn_ops may hand a weight gradient to the library."""
+    import inspect
+    from ppv_amd import nn_ops
+    src = inspect.getsource(nn_ops)
+    code = "\n".join(l.split("#")[0] for l in src.split("\n") if not l.strip().startswith(("#", '"', "``")))
+    assert "conv2d_weight(" not in code and "F.conv2d(" not in code

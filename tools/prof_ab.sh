@@ -3,9 +3,9 @@
 # usage: tools/prof_ab.sh "PPV_X=1 PPV_Y=2" outdir
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${2:-prof_ab}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/a -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/a.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/a -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense --no-roofline > $O/a.log 2>&1
 export $1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/b -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/b.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/b -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense --no-roofline > $O/b.log 2>&1
 python3 - <<PY
 import csv,glob,re
 def load(d):

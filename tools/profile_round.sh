@@ -6,13 +6,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_round
 mkdir -p $O
 export PPV_WGRAD_SIDE=0   # per-kernel durations and counters are taken with every launch alone on the device
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense > $O/bench_under_rocprof.log 2>&1
 echo stats done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dense --no-roofline > $O/pmc_fetch.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dense --no-roofline > $O/pmc_write.log 2>&1
 echo write done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/mfma -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/mfma -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dense --no-roofline > $O/pmc_mfma.log 2>&1
 echo mfma done
 python tools/collect_pmc.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv

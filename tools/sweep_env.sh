@@ -6,7 +6,7 @@ out=$1; shift
 for pass in 1 2; do
   for cfg in "$@"; do
     if [ "$cfg" = "-" ]; then envs=""; else envs="$cfg"; fi
-    line=$(env $envs python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1)
+    line=$(env $envs python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-dense --no-roofline 2>/dev/null | tail -1)
     v=$(python -c "import json,sys; d=json.loads(sys.argv[1]); print(d['value'], d['ms_per_step'])" "$line" 2>/dev/null)
     echo "pass $pass  [$cfg]  $v" | tee -a "$out"
   done

@@ -48,9 +48,48 @@ otf = fc.otf_build(psf, 256, 512)
 ws = torch.empty(ppv_amd._lib.lib().ppv_fftconv_workspace_bytes(B, 3, 512), dtype=torch.uint8, device=dev)
 t_conv = timeit(lambda: fc.fftconv_fwd(img, otf, 0, workspace=ws), n=20)
 alg = B * 3 * 2.5e6
+
+
+def cpu_baseline():
+    """the reference CPU path of this configuration (oracle/ic_camera.py: torch-CPU restatement of Lens.py / Utils.py,
+    prueba '3', loss = sensor.mean() + loss_psf) on a bounded sample -- 16 of the 64 images, one warm-up + three timed passes, median."""
+    from oracle import ic_camera as ic
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    Bc = 16
+    vol = cam.zernike_volume.cpu()
+    coeffs = cam._concat().detach().cpu().requires_grad_(True)
+    m1, m2 = ic.disk_masks()
+    im = img[:Bc].cpu()
+    noise = torch.rand(1, 896, 896, 1, generator=torch.Generator().manual_seed(1))
+
+    def once():
+        coeffs.grad = None
+        sensor, psf_, lpsf = ic.forward(im, coeffs, vol, noise, prueba="3", mask_1=m1, mask_2=m2, height_tolerance=2e-8,
+                                        sensor_distance=0.025, sample_interval=3e-6)
+        (sensor.mean() + lpsf).backward()
+
+    t0 = time.perf_counter(); once(); warm = time.perf_counter() - t0
+    ts = [warm]
+    if warm < 12:
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); once(); ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {"value": round(Bc / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"IC camera (896/350/256, prueba '3') fwd+bwd fp32/fp64 on the CPU oracle, B={Bc} of 64 @256x256, "
+                      + (f"1 warm-up + {len(ts)} timed passes, median" if len(ts) > 1 else "single pass"),
+            "passes_s": [round(x, 3) for x in ts]}
+
+
 print(json.dumps({
     "config": "camera alone 64x3x256x256 fp32 (BASELINE.json configs[1])",
     "ic_fwd_bwd_images_per_s": round(B / t_ic, 1), "ic_ms": round(t_ic * 1e3, 3),
     "fd_fwd_images_per_s": round(B / t_fd, 1), "fd_ms": round(t_fd * 1e3, 3),
     "fftconv_fwd_ms": round(t_conv * 1e3, 3), "fftconv_algorithmic_GBps": round(alg / t_conv / 1e9, 1),
-    "fftconv_frac_of_8TBps": round(alg / t_conv / 8e12, 3)}))
+    "fftconv_frac_of_8TBps": round(alg / t_conv / 8e12, 3),
+    "cpu_baseline": None if os.environ.get("PPV_NO_CPU_BASELINE") else cpu_baseline()}))

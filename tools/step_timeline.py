@@ -38,5 +38,15 @@ out = {"step_wall_us": (t1 - t0) / 1e3, "device_busy_us": union / 1e3, "overlapp
        "launches": len(step), "idle_gaps_over_5us": sum(1 for g in gaps if g > 5000), "idle_in_gaps_over_5us_us": sum(g for g in gaps if g > 5000) / 1e3,
        "queues": sorted({q for *_, q in step}), "gaps_over_5us": gap_at,
        "by_kernel_us": {k: [round(v / 1e3, 1), n[k]] for k, v in sorted(busy.items(), key=lambda kv: -kv[1])[:45]}}
+# run-length sequence of the step's launches (kernel, queue): where the small launches sit
+seq, prev = [], None
+for s_, e_, k_, q_ in step:
+    k_ = re.sub(r"\(.*", "", k_).replace("void ", "").replace("ppv::", "")[:70]
+    if prev is not None and prev[0] == k_ and prev[1] == q_:
+        prev[2] += 1
+    else:
+        prev = [k_, q_, 1]
+        seq.append(prev)
+out["sequence"] = [f"{n}x q{q} {k}" for k, q, n in seq]
 json.dump(out, open(sys.argv[2], "w"), indent=1)
-print(json.dumps({k: out[k] for k in out if k not in ("by_kernel_us", "gaps_over_5us")}))
+print(json.dumps({k: out[k] for k in out if k not in ("by_kernel_us", "gaps_over_5us", "sequence")}))

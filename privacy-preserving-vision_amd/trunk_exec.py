@@ -56,10 +56,13 @@ class _LeaseHolder:
         if self.held:
             return self.lease
         lease = self.lease
-        if lease.gen != self.gen or lease not in lease.plan.free:
+        if lease.gen != self.gen:
             raise RuntimeError("ppv_amd Encoder: backward through a graph whose saved activations have been overwritten by a later "
                                "forward (the trunk keeps them in a reused arena); run this backward before the next forward")
-        lease.plan.free.remove(lease)
+        if lease in lease.plan.free:           # (not there: the pool dropped its idle arenas for another geometry -- this one is intact)
+            lease.plan.free.remove(lease)
+        lease.gen += 1                         # whoever else still points at this lease is stale from here on
+        self.gen = lease.gen
         self.held = True
         return lease
 
@@ -193,6 +196,8 @@ def get_plan(enc, B, H, W, plist):
     plans = enc.__dict__.setdefault("_plans", {})
     plan = plans.get(key)
     if plan is None or plan.rg_key != rg or plan.plist is not plist:
+        for other in plans.values():         # a new geometry: idle arenas of the others (19.6 GB each at B = 128) go back to the allocator
+            other.free.clear()
         plan = TrunkPlan(enc, B, H, W, fold_rows, reduce3, rg)
         plan.plist = plist                # the list object itself (Encoder._param_list rebuilds it when Parameter objects are replaced)
         plans[key] = plan

@@ -140,6 +140,14 @@ int ppv_instnorm_fwd(const float* x, const float* scale, const float* shift, flo
                      int per_sample, float slope, float eps, ppv_stream_t stream);
 int ppv_instnorm_bwd(const float* x, const float* g, const void* stats, const float* scale, const float* shift, float* dx,
                      void* sums, int B, int HW, int C, int per_sample, float slope, ppv_stream_t stream);
+/* EXPERIMENT (round 4; measured in profiles/r04*_coop_ab.json, not on the product path): 1x1 / unit-stride convolution + train-mode
+ * BatchNorm2d + ReLU (torchvision Bottleneck conv1 -> bn1 -> relu, Image_Caption/models.py:17-21 under train.py:245) in ONE launch: the
+ * 256 x 128 tiles, one workgroup per CU, leave their statistics, cross a grid barrier and normalise the tile they still hold in LDS.
+ * x_raw and y [B,H,W,N] bf16 are both written; stats [stat_rows][2][N] f32 and counter[2] PRE-ZEROED (counter[1] != 0 afterwards: a
+ * workgroup gave up waiting -- results invalid); coef [4][N] as ppv_bn_finalize.  PPV_ERR_BAD_SIZE unless the whole grid can be resident. */
+int ppv_conv_bn_relu_coop(const void* X, const void* Wt, void* x_raw, void* y, float* stats, unsigned* counter, const float* gamma,
+                          const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* coef,
+                          const void* zero_page, int B, int H, int W, int Cs, int N, int stat_rows, ppv_stream_t stream);
 int ppv_conv_stat_tiles(long M);
 int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x128x4-stage, 3 256x128x3-stage */
 int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, ppv_stream_t stream);

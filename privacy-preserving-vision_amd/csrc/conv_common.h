@@ -23,6 +23,18 @@ struct ConvGeom {
     int chunked;         // layout experiment (flat launches, BK = 64): the source is [Cs / 64][M][64] instead of [M][Cs]
 };
 
+// Cooperative (grid-barrier) BatchNorm of the tile epilogue (conv_tile_epilogue.h, COOP; experiment of round 4): the
+// launch's workgroups are all resident (one per CU), leave their statistics, cross ONE grid barrier and apply train-mode BatchNorm +
+// ReLU to the tile they still hold in LDS.
+struct CoopBn {
+    unsigned* counter;             // [2] PRE-ZEROED: arrivals; [1] is set when a spin ran out (the launch then finished WITHOUT a barrier)
+    const float *gamma, *beta;     // BatchNorm weight / bias [N]
+    float *run_mean, *run_var;     // running statistics (may be null)
+    float* coef;                   // [4][N] out: scale, shift, mean, invstd (what backward reads)
+    void* y;                       // [M][N] bf16 out: relu(bn(raw))
+    float count, momentum, eps;
+};
+
 __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 }

@@ -233,13 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
 // extra read of x (1 T) in this store loop.  red_coef (BN scale / shift [2][N], may be null): the BatchNorm is followed by a ReLU
 // without residual, so its mask (x * scale + shift > 0, the forward kernel's expression) is recomputed here, applied to the
 // stored gradient and to the sums (single-pass store path only: launches without addend).
-template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false>
+template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false, bool COOP = false>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                                    int tiles_n, int stat_rows, const bf16_t* __restrict__ red_x,
-                                                                   const float* __restrict__ red_coef) {
+                                                                   const float* __restrict__ red_coef, CoopBn cb) {
     constexpr int NT = BM * 2, NWAVE = NT / 64;
     constexpr int ROWB = BK * 2, CH = BK / 8;                             // bytes / 16-byte chunks per staged row
     constexpr int RPI = 1024 / ROWB;                                       // rows per 1-KiB LDS-DMA wave-instruction
@@ -401,9 +401,9 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     constexpr int LDO_ = BN * 2 + 32;
     constexpr int LDS_TOTAL = NSTAGE * STAGE_BYTES > BM * LDO_ + 4096 ? NSTAGE * STAGE_BYTES : BM * LDO_ + 4096;   // = the host's `lds`
 #ifdef PPV_STAMPS
-    tile_epilogue<BM, BN, LDS_TOTAL, WGPCU, OUT_F32, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, stamp_);
+    tile_epilogue<BM, BN, LDS_TOTAL, WGPCU, OUT_F32, RED, MI, NI, COOP>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, cb, stamp_);
 #else
-    tile_epilogue<BM, BN, LDS_TOTAL, WGPCU, OUT_F32, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0);
+    tile_epilogue<BM, BN, LDS_TOTAL, WGPCU, OUT_F32, RED, MI, NI, COOP>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, cb);
 #endif
 }
 
@@ -551,9 +551,9 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
             attr_set = true;                                                                                            \
         }                                                                                                               \
         if (rx && !(REDOK_)) return PPV_ERR_BAD_SIZE;                                                                   \
-        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef);           \
-        else if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr); \
-        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr); \
+        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef, CoopBn{});           \
+        else if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
     } while (0)
 #define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, false)
 #define PPV_LAUNCH_PIPE_R(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, true)
@@ -610,6 +610,41 @@ int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part,
     if (!red_part || !red_x) return PPV_ERR_NULL;
     return conv_gemm_impl(X, Wt, out, red_part, addend, mask_bits, zero_page, red_x, red_coef, B, Hs, Ws, Cs, Ho, Wo, N, R, S, a, off, div, 0,
                           red_rows, stream);
+}
+
+// EXPERIMENT (round 4; not on the product path): 1x1 / unit-stride convolution + train-mode BatchNorm + ReLU in ONE launch
+// of the 256 x 128 BK-64 tile, one workgroup per CU: the tiles leave their statistics, cross a grid barrier and apply the BatchNorm to
+// the tile they still hold in LDS.  x_raw [M][N] bf16 (backward reads it) and y [M][N] bf16 are both written.  stats [stat_rows][2][N]
+// and counter[2] PRE-ZEROED.  Refused (PPV_ERR_BAD_SIZE) unless every workgroup of the grid can be resident at once.
+int ppv_conv_bn_relu_coop(const void* X, const void* Wt, void* x_raw, void* y, float* stats, unsigned* counter, const float* gamma,
+                          const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* coef,
+                          const void* zero_page, int B, int H, int W, int Cs, int N, int stat_rows, hipStream_t stream) {
+    if (!X || !Wt || !x_raw || !y || !stats || !counter || !gamma || !beta || !coef || !zero_page) return PPV_ERR_NULL;
+    if (Cs % 64 || N % 128 || stat_rows < 1) return PPV_ERR_BAD_SIZE;
+    ConvGeom g;
+    g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1;
+    g.a = 1; g.off = 0; g.offw = 0; g.sh = 0; g.M = (long)B * H * W; g.flat = 1; g.chunked = 0;
+    constexpr int BM_ = 256, BN_ = 128, NS_ = 3, BK_ = 64;
+    constexpr int ring = NS_ * (BM_ + BN_) * BK_ * 2, epi = BM_ * (BN_ * 2 + 32) + 4096 + 8192, lds = ring > epi ? ring : epi;
+    const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;
+    auto k = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, 1, false, false, true>;
+    static bool attr_set = false;
+    static int per_cu = 0, cus = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, BM_ * 2, lds)) return -(int)e;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return -(int)e;
+        attr_set = true;
+    }
+    if ((long)tm * tn > (long)per_cu * cus) return PPV_ERR_BAD_SIZE;       // a grid barrier needs every workgroup resident
+    CoopBn cb;
+    cb.counter = counter; cb.gamma = gamma; cb.beta = beta; cb.run_mean = run_mean; cb.run_var = run_var; cb.coef = coef; cb.y = y;
+    cb.count = (float)g.M; cb.momentum = momentum; cb.eps = eps;
+    k<<<tm * tn, BM_ * 2, lds, stream>>>((const bf16_t*)X, (const bf16_t*)Wt, x_raw, stats, nullptr, nullptr, (const bf16_t*)zero_page, g, tn,
+                                         stat_rows, nullptr, nullptr, cb);
+    return ppv_last_error();
 }
 
 // Stride-1 convolution with a rectangular kernel and separate row / column paddings (RAFT SepConvGRU: 1 x 5 with padding (0, 2),

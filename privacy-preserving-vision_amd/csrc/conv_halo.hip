@@ -227,9 +227,9 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     __syncthreads();
 #ifdef PPV_STAMPS
     unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, stamp_);
+    tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{}, stamp_);
 #else
-    tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0);
+    tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{});
 #endif
 }
 

@@ -9,11 +9,11 @@ namespace ppv {
 // ----------------------------------------------------------------------------- shared epilogue of the 256/128-row tiled kernels
 // acc: the wave's MI x NI accumulator tiles of a BM x BN output tile whose rows are GEMM rows m0 .. m0 + BM - 1 and columns n0 ..;
 // smem: the workgroup's whole dynamic LDS (LDS_TOTAL bytes, free: every wave is past its last read of the K loop's stages).
-template <int BM, int BN, int LDS_TOTAL, int WGPCU, bool OUT_F32, bool RED, int MI, int NI>
+template <int BM, int BN, int LDS_TOTAL, int WGPCU, bool OUT_F32, bool RED, int MI, int NI, bool COOP = false>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, void* __restrict__ Out, float* __restrict__ stat_part,
                                               const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                               const ConvGeom& g, int tile_m, int stat_rows, const bf16_t* __restrict__ red_x,
-                                              const float* __restrict__ red_coef, long m0, int n0
+                                              const float* __restrict__ red_coef, long m0, int n0, const CoopBn& cb
 #ifdef PPV_STAMPS
                                               , unsigned long long* stamp_
 #endif
@@ -319,6 +319,78 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
     if constexpr (RED) {
         __syncthreads();                                        // every chunk of the staged tile has been read
         red_finish();
+    }
+    if constexpr (COOP && !RED && !OUT_F32) {
+        // ---- grid barrier, then train-mode BatchNorm + ReLU on the tile that is still staged in LDS (sO): the raw tensor has been
+        // stored above (backward reads it), the activation is stored here -- the element-wise launch that would re-read the raw
+        // tensor does not exist.  Residency: the host launches this form only with <= one workgroup per CU and checks the grid
+        // against the occupancy query; the spin is bounded all the same (counter[1] reports a barrier that never completed).
+        static_assert(LDS_TOTAL >= BM * LDO + 8192 + 2 * BN * 4, "room for the coefficient rows behind the statistics");
+        float* sCo = reinterpret_cast<float*>(smem + BM * LDO + 8192);             // [2][BN]: scale, shift
+        // this thread's statistics atomic must be at memory before the arrival; the SITERS tile stores issued after it may still be in
+        // flight (vmcnt retires in order): waiting for them too put a full store round trip in front of every arrival
+        if (m0 + BM <= g.M) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SITERS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cb.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cb.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 19)) {
+                    __hip_atomic_store(cb.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            // totals of this column: the adds that built them executed at the memory side (nothing of them stays in an L2), these are
+            // the first loads of those lines in this launch, and agent-scope loads bypass the CU's own L1
+            const int col = n0 + tid;
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < stat_rows; ++r) {
+                s1 += __hip_atomic_load(&stat_part[((long)r * 2 + 0) * g.N + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(&stat_part[((long)r * 2 + 1) * g.N + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const double mean = (double)s1 / (double)cb.count;
+            double var = (double)s2 / (double)cb.count - mean * mean;
+            if (var < 0) var = 0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)cb.eps));
+            const float scale = cb.gamma[col] * invstd, shift = cb.beta[col] - (float)mean * scale;
+            sCo[tid] = scale;
+            sCo[BN + tid] = shift;
+            if (tile_m == 0) {                                                      // one row tile publishes what backward / the module reads
+                cb.coef[col] = scale; cb.coef[g.N + col] = shift; cb.coef[2 * g.N + col] = (float)mean; cb.coef[3 * g.N + col] = invstd;
+                if (cb.run_mean) cb.run_mean[col] = (1.f - cb.momentum) * cb.run_mean[col] + cb.momentum * (float)mean;
+                if (cb.run_var) {
+                    const double unb = cb.count > 1.f ? var * (double)cb.count / ((double)cb.count - 1.0) : var;
+                    cb.run_var[col] = (1.f - cb.momentum) * cb.run_var[col] + cb.momentum * (float)unb;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            bf16_t* yout = reinterpret_cast<bf16_t*>(cb.y);
+            const int row0 = tid / CPR, ch = tid % CPR;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sc[k] = sCo[ch * 8 + k]; sh[k] = sCo[BN + ch * 8 + k]; }
+#pragma unroll
+            for (int it = 0; it < SITERS; ++it) {
+                const int row = row0 + it * RSTEP;
+                const long m = m0 + row;
+                if (m < g.M) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] = fmaxf(__builtin_fmaf(f[k], sc[k], sh[k]), 0.f);
+                    *reinterpret_cast<uint4*>(yout + m * g.N + n0 + ch * 8) =
+                        make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+                }
+            }
+        }
     }
 }
 

@@ -132,3 +132,49 @@ def test_dgrad_relu_recompute_and_sums(B, H, Cout, Cin, k, stride):
     got = co.bn_bwd(fused, None, xraw, coef, 0, part=part, part_ready=True)
     assert rel_err(got[0].float(), want[0].float()) < 2 ** -7
     assert rel_err(got[2], want[2]) < 1e-4 and rel_err(got[3], want[3]) < 1e-4
+
+
+def test_cooperative_conv_bn_relu_equals_the_two_launch_form():
+    """ppv_conv_bn_relu_coop (round-4 experiment, DESIGN 4d: measured 11.5 us slower than the two launches it fuses, not on the product
+    path): conv 1x1 + train-mode BatchNorm + ReLU with a grid barrier inside the launch.  Must reproduce ppv_conv_gemm + ppv_bn_act_fold_rows:
+    raw tensor bit for bit, activation / coefficients / running statistics to rounding; the barrier must complete (no timeout flag), and a
+    grid that cannot be resident at once must be refused."""
+    import ppv_amd.convops as co
+    from ppv_amd import _lib
+    from ppv_amd._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    B, H, CIN, COUT, ROWS = 64, 16, 512, 256, 2
+    M = B * H * H
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, H, H, CIN, generator=g).bfloat16().to(dev)
+    w = co.weight_layout((torch.randn(COUT, CIN, 1, 1, generator=g) * 0.05).to(dev), 0)
+    gamma = (torch.rand(COUT, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(COUT, generator=g) * 0.2).to(dev)
+    zp = co.zero_page(dev)
+
+    def run(coop):
+        rm, rv = torch.zeros(COUT, device=dev), torch.ones(COUT, device=dev)
+        x1, y1 = torch.empty(B, H, H, COUT, dtype=torch.bfloat16, device=dev), torch.empty(B, H, H, COUT, dtype=torch.bfloat16, device=dev)
+        stats, coef = torch.zeros(ROWS, 2, COUT, device=dev), torch.empty(4, COUT, device=dev)
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        if coop:
+            check(L.ppv_conv_bn_relu_coop(ptr(x), ptr(w), ptr(x1), ptr(y1), ptr(stats), ptr(counter), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5,
+                                          ptr(coef), ptr(zp), B, H, H, CIN, COUT, ROWS, stream_ptr()), "coop")
+        else:
+            check(L.ppv_conv_gemm(ptr(x), ptr(w), ptr(x1), ptr(stats), None, None, ptr(zp), B, H, H, CIN, H, H, COUT, 1, 1, 1, 0, 1, 0, ROWS, stream_ptr()), "conv")
+            check(L.ppv_bn_act_fold_rows(ptr(x1), ptr(stats), ROWS, float(M), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(coef), None, ptr(y1),
+                                         None, M * COUT, COUT, 0, 1, stream_ptr()), "bn")
+        torch.cuda.synchronize()
+        return x1, y1, coef, rm, rv, counter
+
+    a, b = run(False), run(True)
+    assert int(b[5][1]) == 0 and int(b[5][0]) == (M // 256) * (COUT // 128)
+    assert torch.equal(a[0], b[0])
+    assert rel_err(b[1].float(), a[1].float()) < 2 ** -7
+    for i in (2, 3, 4):
+        assert rel_err(b[i], a[i]) < 1e-5
+    # 1024 tiles of 256 x 128 cannot be resident on 256 CUs at one per CU: refused before any launch
+    big = torch.empty(1, device=dev)
+    assert L.ppv_conv_bn_relu_coop(ptr(x), ptr(w), ptr(big), ptr(big), ptr(big), ptr(big), ptr(gamma), ptr(beta), None, None, 0.1, 1e-5, ptr(big), ptr(zp),
+                                   128, 32, 32, CIN, 256, ROWS, stream_ptr()) == _lib.PPV_ERR_BAD_SIZE

@@ -44,8 +44,11 @@ class _LeaseHolder:
             lease = self.lease
             try:
                 with torch.cuda.device(lease.arena.device):
-                    ev = torch.cuda.Event()
-                    ev.record()
+                    if torch.cuda.is_current_stream_capturing():
+                        ev = None                     # a captured step is ordered by its own streams; an event of the capture must not leak out
+                    else:
+                        ev = torch.cuda.Event()
+                        ev.record()
                 lease.free_event = ev
             except Exception:                         # interpreter shutdown
                 lease.free_event = None
@@ -119,7 +122,8 @@ class TrunkPlan:
             lease = self.free.pop()
             if lease.arena.device == dev:
                 if lease.free_event is not None:
-                    torch.cuda.current_stream(dev).wait_event(lease.free_event)
+                    if not torch.cuda.is_current_stream_capturing():      # (waiting for uncaptured work is an error inside a capture)
+                        torch.cuda.current_stream(dev).wait_event(lease.free_event)
                     lease.free_event = None
                 lease.gen += 1
                 return lease

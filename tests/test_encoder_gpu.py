@@ -529,3 +529,43 @@ def test_deterministic_mode_makes_two_default_passes_agree_bit_for_bit():
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0])
         assert all(torch.equal(a, b) for a, b in zip(o[1], outs[0][1]))
+
+
+def test_trunk_plan_inside_a_captured_graph():
+    """A training step of the trunk captured into a hipGraph (bench.py PPV_BENCH_GRAPH=1 does it with the whole step) replays with the
+    plan executor: the arena hand-over events are skipped under capture, the forks to the weight-gradient stream join the capture, and the
+    replay produces the eager step's output and gradients (the gradient views keep their addresses across replays)."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    img = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    tr = [p for p in enc.parameters() if p.requires_grad]
+
+    def step():
+        for p in tr:
+            p.grad = None
+        cells = enc(img)._ppv_cells
+        cells.float().square().mean().backward()
+        return cells
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    enc.load_state_dict(sd)
+    want_cells = step().detach().clone()
+    want = [p.grad.clone() for p in tr]
+    enc.load_state_dict(sd)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        cells = step()
+    enc.load_state_dict(sd)
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel_err(cells.float(), want_cells.float()) < 2e-2
+    for p, w in zip(tr, want):
+        assert p.grad is not None and _cos(p.grad, w) > 0.99        # (2 x 2 maps in layer 4: BatchNorm over 16 samples, two passes differ by the atomics' order)

@@ -9,9 +9,10 @@ same arguments), no allocation, one memset.
 Ownership.  A ``_Lease`` = (arena, flat gradient buffer, pointer tables).  Forward takes a free lease (or makes one), the autograd
 context holds it, and it returns to the pool when the context dies (after backward, or at once under ``no_grad``); the next forward on
 the same arena is ordered behind whatever still reads it by an event recorded at release.  Gradients of the trainable parameters live
-in the lease's flat f32 buffer: backward's kernels write a parameter's slice, the trunk sets ``param.grad`` to that slice itself and
-hands autograd nothing (what ``dist_sync.GradSync`` does for data-parallel runs, DDP's gradient_as_bucket_view) -- unless a gradient
-is already there (micro-batching, ``zero_grad(set_to_none=False)``): then a temporary buffer is used and autograd accumulates."""
+in the lease's flat f32 buffer: backward's kernels write a parameter's slice and the trunk returns fresh views of the slices to
+autograd, which adopts them as ``param.grad`` without a copy (as DDP's gradient_as_bucket_view: the next backward overwrites them) --
+unless a gradient is already there (micro-batching, ``zero_grad(set_to_none=False)``): then a temporary buffer is used and autograd
+accumulates.  Data-parallel runs (``dist_sync.GradSync``) keep setting ``param.grad`` to the bucket slices themselves."""
 import ctypes
 import os
 
@@ -107,6 +108,10 @@ class TrunkPlan:
                     self.slots.append((i, field, p, off, p.numel()))
                     off += (p.numel() + 3) // 4 * 4
         self.grad_elems = max(off, 4)
+        # every slice a multiple of 4 floats (true for every ResNet shape): the buffer is densely packed and ONE C++ call cuts it into
+        # parameter-shaped views (torch._utils._unflatten_dense_tensors) instead of two Python-level ops per parameter
+        self.dense = all(sl[4] % 4 == 0 for sl in self.slots)
+        self.grad_params = [sl[2] for sl in self.slots]
         # trainable parameters of each block in the order the per-kernel backward finishes them (the bucket order of data-parallel runs)
         self.block_params = []
         for blk in enc._blocks:
@@ -138,11 +143,20 @@ class TrunkPlan:
         lease.ptr_key = None
         lease.free_event = None
         base = lease.gflat.data_ptr()
-        lease.grad_items = []
+        lease.grad_items = [(sl[2], None) for sl in self.slots]
         for i, field, p, off, numel in self.slots:
             lease.table[_NF * i + field] = base + 4 * off
-            lease.grad_items.append((p, lease.gflat[off:off + numel].view(p.shape)))
         return lease
+
+    def grad_views(self, flat):
+        """{parameter: fresh view of its slice of `flat`} -- fresh objects, so that autograd's AccumulateGrad adopts them as .grad
+        without a copy (it clones a gradient somebody else still references)."""
+        if not self.slots:
+            return {}
+        if self.dense:
+            n = self.slots[-1][3] + self.slots[-1][4]
+            return dict(zip(self.grad_params, torch._utils._unflatten_dense_tensors(flat[:n], self.grad_params)))
+        return {p: flat[off:off + numel].view(p.shape) for _, _, p, off, numel in self.slots}
 
     def fill_pointers(self, enc, lease, tok, plist):
         """Weight-layout / BatchNorm columns of the lease's table.  Refilled only when something they depend on changed: the parameter
@@ -278,14 +292,14 @@ def backward(enc, holder, cells, g_out, g_cells, needs_img, img_shape, side, mai
                 hi = b
         holder.release()
         return g_img, None
+    flat = lease.gflat
     if not fresh or sync is not None:
-        # accumulation: a temporary flat buffer, gradients handed to autograd (which adds them to what is there)
-        keep = torch.empty(plan.grad_elems, dtype=F32, device=dev)
+        # gradients already sit in .grad (micro-batching, zero_grad(set_to_none=False)) -- possibly views of this very buffer from the
+        # last step: a temporary flat buffer, whose slices autograd adds to what is there
+        flat = keep = torch.empty(plan.grad_elems, dtype=F32, device=dev)
         table = (ctypes.c_uint64 * len(lease.table))(*lease.table)
-        grads = {}
         for i, field, p, off, numel in plan.slots:
             table[_NF * i + field] = keep.data_ptr() + 4 * off
-            grads[p] = keep[off:off + numel].view(p.shape)
         if side is not None:
             keep.record_stream(side)
     if hop:
@@ -295,10 +309,10 @@ def backward(enc, holder, cells, g_out, g_cells, needs_img, img_shape, side, mai
                                g_img.data_ptr() if g_img is not None else None, zp, 0, plan.nblocks, main, side_ptr), "ppv_trunk_bwd")
     if hop:
         _lib.check(L.ppv_stream_fork(main, cur_ptr), "ppv_stream_fork")
-    if grads is None:
-        for p, v in lease.grad_items:
-            p.grad = v
-    elif sync is not None:
+    if keep is not None and sync is not None:
         sync.reduce_now([keep])            # accumulation mode of a data-parallel run: averaged in stream order, then handed to autograd
+    # Single-process runs hand the slices to AUTOGRAD (hooks on the parameters fire, torch.autograd.grad leaves .grad alone, accumulation
+    # is autograd's): param.grad ends up a view of the lease's flat buffer, which the next backward overwrites.
+    grads = plan.grad_views(flat)
     holder.release()
     return g_img, grads

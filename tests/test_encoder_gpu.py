@@ -460,9 +460,10 @@ def test_trunk_plan_equals_the_per_kernel_path(layers, B, H, dense, one_adder_st
 
 
 def test_trunk_plan_gradient_ownership(one_adder_stats):
-    """The plan executor sets ``param.grad`` to slices of its flat buffer when no gradient is there, accumulates through autograd when
-    one is (micro-batching), serves a second backward with retain_graph, refuses one whose arena a later forward has overwritten, and
-    returns its arena when the graph dies without a backward (no_grad)."""
+    """The plan executor hands autograd fresh views of its flat gradient buffer (adopted as ``param.grad`` without a copy when no gradient
+    is there, accumulated into when one is: micro-batching), serves a second backward with retain_graph, refuses one whose arena a later
+    forward has overwritten, returns its arena when the graph dies without a backward (no_grad), and leaves ``param.grad`` alone under
+    ``torch.autograd.grad`` -- the gradients go THROUGH autograd, so parameter hooks fire as well."""
     from ppv_amd.encoder import Encoder
     torch.manual_seed(0)
     enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
@@ -504,6 +505,19 @@ def test_trunk_plan_gradient_ownership(one_adder_stats):
     loss()                                                        # a later forward re-uses the arena l_'s graph points at
     with pytest.raises(RuntimeError, match="overwritten"):
         l_.backward()
+    # torch.autograd.grad w.r.t. the image only: no parameter gradient is asked for -- param.grad stays untouched (and the weight-gradient
+    # launches are skipped), the image gradient equals the one backward() gives
+    for p in tr:
+        p.grad = None
+    x = img.clone().requires_grad_(True)
+    gi, = torch.autograd.grad(enc(x)._ppv_cells.float().square().mean(), [x])
+    assert all(p.grad is None for p in tr)
+    x2 = img.clone().requires_grad_(True)
+    seen = []
+    h = tr[0].register_hook(lambda g_: seen.append(g_.shape))
+    enc(x2)._ppv_cells.float().square().mean().backward()
+    h.remove()
+    assert _cos(gi, x2.grad) > 0.999 and all(p.grad is not None for p in tr) and seen == [tr[0].shape]
 
 
 def test_deterministic_mode_makes_two_default_passes_agree_bit_for_bit():

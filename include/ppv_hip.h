@@ -132,6 +132,12 @@ int ppv_gru_out(const float* q, int ldq, const float* bias, const float* z, cons
 int ppv_gemm_f32_ksplit(int M, int N, int K);
 int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
                  int ksplit, ppv_stream_t stream);
+/* the same product with the K slices written to workspace [ksplit][M][N] f32 and summed in index order by a second small launch: no
+ * atomics, no pre-zeroed output, bit-reproducible for any split.  ppv_gemm_f32_ws_plan returns the split to pass (1: no workspace
+ * needed) and the workspace bytes. */
+int ppv_gemm_f32_ws_plan(int M, int N, int K, size_t* bytes);
+int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
+                    int ksplit, void* workspace, ppv_stream_t stream);
 /* InstanceNorm2d / AdaIN (+ LeakyReLU) of the StarGAN-v2 blocks (Face-DeId/core/model.py:12-124), NHWC f32:
  * y = lrelu((x - mean_bc) * invstd_bc * scale + shift), statistics per (sample, channel) over HW, eps as given; scale / shift are
  * [C] (per_sample = 0: nn.InstanceNorm2d(affine=True)) or [B][C] (per_sample = 1: AdaIN's (1 + gamma), beta).  stats / sums:

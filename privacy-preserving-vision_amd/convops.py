@@ -205,6 +205,21 @@ def conv_wgrad_group(gs, xs, outs=None):
 
 
 # ----------------------------------------------------------------------------- dense layers in exact f32 (csrc/gemm_f32.hip)
+import os as _os
+_GEMM_WS = _os.environ.get("PPV_GEMM_WS", "1") != "0"
+_gemm_ws = {}
+
+
+def _gemm_scratch(device, nbytes):
+    """Slab scratch of linear_f32, one per (device, stream), grow-only: successive GEMMs of a stream reuse it in stream order."""
+    key = (device.index, _lib.stream_ptr().value)
+    t = _gemm_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=device)
+        _gemm_ws[key] = t
+    return t
+
+
 def linear_f32(x, w, bias=None, out=None):
     """out = x @ w^T (+ bias) on v_mfma_f32_16x16x4_f32 (exact f32).  x [m, K] f32 with unit column stride (rows may be strided,
     e.g. a column block of a wider buffer), w [N, K] f32 (same), out: optional f32 [m, N] with unit column stride."""
@@ -213,6 +228,21 @@ def linear_f32(x, w, bias=None, out=None):
     assert w.shape[1] == K and x.dtype == F32 and w.dtype == F32 and x.stride(1) == 1 and w.stride(1) == 1
     if K % 16 or x.stride(0) % 4 or w.stride(0) % 4 or x.data_ptr() % 16 or w.data_ptr() % 16:
         raise ValueError("linear_f32: K must be a multiple of 16 and rows 16-byte aligned")
+    # tiled kernel with the K slices combined through slabs (no atomics, no zero-fill in front of the launch, slices summed in index
+    # order): csrc/gemm_f32.hip ppv_gemm_f32_ws.  PPV_GEMM_WS=0: the atomics form for every shape
+    if _GEMM_WS and N % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0):
+        nbytes = _lib.ctypes.c_size_t(0)
+        ks = L().ppv_gemm_f32_ws_plan(m, N, K, _lib.ctypes.byref(nbytes))
+        if out is None:
+            out = torch.empty((m, N), dtype=F32, device=x.device)
+        else:
+            assert tuple(out.shape) == (m, N) and out.stride(1) == 1 and out.dtype == F32
+        if ks == 1 or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):
+            if ks > 1 or L().ppv_gemm_f32_ksplit(m, N, K) == 1:
+                ws = _gemm_scratch(x.device, nbytes.value) if ks > 1 else None
+                check(L().ppv_gemm_f32_ws(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), m, N, K, ks, ptr(ws),
+                                          stream_ptr()), "ppv_gemm_f32_ws")
+                return out
     ks = L().ppv_gemm_f32_ksplit(m, N, K)
     if ks > 2 and torch.are_deterministic_algorithms_enabled():
         ks = 2          # two adders into a zeroed element commute: bit-reproducible (more would leave the order of the f32 atomics open)

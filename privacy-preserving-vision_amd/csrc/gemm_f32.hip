@@ -94,6 +94,140 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
+// ----------------------------------------------------------------------------- tiled form (round 4)
+// The kernel above gives every WAVE its own copy of the x rows (eight float4 loads per lane and 16-deep k chunk against one of W):
+// 7 flop per byte through the L2 -> register path, 230 MB per LSTM gate GEMM -- it ran at 38 TFLOP/s where the f32 matrix pipe offers
+// 157 and the library reaches 83.  Here a workgroup owns 128 (m) x 64 (n): the 32-deep k chunk of x (16 KB) and of W (8 KB) is staged
+// ONCE in LDS and shared by the four waves (wave w: columns 16 w .. 16 w + 15, all 128 rows, eight 16 x 16 accumulators), so a chunk
+// costs 24 KB of L2 traffic for 256 MFMAs (21 flop per byte).  Register-staged double buffer: the loads of chunk c + 1 are in flight
+// under the MFMAs of chunk c, one barrier per chunk.  Rows are padded to 36 floats: the 16 lanes of a ds_read_b128 group (fixed k
+// quarter, rows r = 0..15) fall on 16 different 4-word bank groups.  Same arithmetic as above (v_mfma_f32_16x16x4_f32, k-ordered f32
+// chains, split-K combined with f32 atomics); the float4 components of a lane feed four consecutive MFMAs, i.e. the k order inside a
+// 16-chunk is permuted identically for both operands.
+constexpr int GT_BM = 128, GT_BN = 64, GT_BK = 32, GT_LD = 36;
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, long ldw,
+                                                                const float* __restrict__ bias, float* __restrict__ out, long ldo, int M,
+                                                                int N, int K, int ksplit, int use_atomics, float* __restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) float sX[2][GT_BM * GT_LD];
+    __shared__ __attribute__((aligned(16))) float sW[2][GT_BN * GT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * GT_BN, m0 = blockIdx.z * GT_BM, kslice = blockIdx.y;
+    const int chunks = (K + GT_BK - 1) / GT_BK;
+    const int cps = (chunks + ksplit - 1) / ksplit;
+    const int c_begin = kslice * cps, c_end = min(chunks, c_begin + cps);
+    if (c_begin >= c_end && !(kslice == 0) && !slab) return;     // (a slab slice without chunks still writes its zeros)
+    // staging roles: a thread moves 4 float4 of x and 2 of W per chunk; float4 index f -> row f / 8, k quarter-pair f % 8
+    const int xr0 = tid >> 3, xk = (tid & 7) * 4;                          // rows xr0 + 32 i, i = 0..3
+    const float* xsrc[4];
+    bool xok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + xr0 + 32 * i;
+        xok[i] = m < M;
+        xsrc[i] = x + (long)(xok[i] ? m : 0) * ldx + xk;
+    }
+    const float* wsrc[2];
+    bool wok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + xr0 + 32 * i;
+        wok[i] = n < N;
+        wsrc[i] = W + (long)(wok[i] ? n : 0) * ldw + xk;
+    }
+    float4 rx[4], rw[2];
+    auto fetch = [&](int c) {
+        const int k = c * GT_BK + xk;
+        const bool kok = k < K;                                             // K % 16 == 0, xk % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rx[i] = (xok[i] && kok) ? *reinterpret_cast<const float4*>(xsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(wsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sX[buf][(xr0 + 32 * i) * GT_LD + xk]) = rx[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][(xr0 + 32 * i) * GT_LD + xk]) = rw[i];
+    };
+    gf32x4 acc[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, q = lane >> 4;
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        park(0);
+        __syncthreads();
+        int buf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            if (c + 1 < c_end) fetch(c + 1);
+            const float* tx = &sX[buf][r * GT_LD + 4 * q];
+            const float* tw = &sW[buf][(wave * 16 + r) * GT_LD + 4 * q];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float4 wv = *reinterpret_cast<const float4*>(tw + kk * 16);
+                float4 xv[8];
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) xv[mb] = *reinterpret_cast<const float4*>(tx + mb * 16 * GT_LD + kk * 16);
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].x, wv.x, acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].y, wv.y, acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].z, wv.z, acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].w, wv.w, acc[mb], 0, 0, 0);
+                }
+            }
+            if (c + 1 < c_end) park(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // C/D layout: acc[mb][j] = out[x row mb * 16 + q * 4 + j][weight row wave * 16 + r]
+    const int n = n0 + wave * 16 + r;
+    if (n < N) {
+        if (slab) {                                                         // split K without atomics: slice kslice of [ksplit][M][N], summed by gemm_f32_slab_sum_kernel
+            float* dst = slab + (long)kslice * M * N;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + mb * 16 + q * 4 + j;
+                    if (m < M) dst[(long)m * N + n] = acc[mb][j];
+                }
+            return;
+        }
+        const float b = (bias && kslice == 0) ? bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + mb * 16 + q * 4 + j;
+                if (m < M) {
+                    const float v = acc[mb][j] + b;
+                    if (use_atomics) atomicAdd(&out[(long)m * ldo + n], v);
+                    else out[(long)m * ldo + n] = v;
+                }
+            }
+    }
+}
+
+// out[m][n] = bias[n] + sum_s slab[s][m][n]  (slices in index order: the result does not depend on which workgroup finished first)
+__global__ __launch_bounds__(256) void gemm_f32_slab_sum_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                                float* __restrict__ out, long ldo, int M, int N, int ksplit) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;                   // one float4 of a row (N % 4 == 0)
+    const int n4 = N / 4;
+    if (i >= (long)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    float4 a = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long stride = (long)M * N;
+    const float* p = slab + (long)m * N + n;
+    for (int s_ = 0; s_ < ksplit; ++s_) {
+        const float4 v = *reinterpret_cast<const float4*>(p + s_ * stride);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long)m * ldo + n) = a;
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -108,9 +242,24 @@ static int ksplit_target() {                                   // workgroups a l
     return t;
 }
 
+static int gemm_tiled() {                                       // PPV_GEMM_TILED=0: the wave-private form above for every shape (A/B)
+    static const int t = getenv("PPV_GEMM_TILED") ? atoi(getenv("PPV_GEMM_TILED")) : 1;
+    return t;
+}
+static bool use_tiled(int M, int N, int K) { return gemm_tiled() && M >= 32 && N >= 64 && K >= 64; }
+
 int ppv_gemm_f32_ksplit(int M, int N, int K) {
-    const long wgs = (long)((N + 15) / 16) * ((M + 127) / 128);
     static const int ks_max = (getenv("PPV_GEMM_DETERMINISTIC") && atoi(getenv("PPV_GEMM_DETERMINISTIC"))) ? 2 : 8;
+    if (use_tiled(M, N, K)) {
+        // 128 x 64 tiles, two workgroups per CU: split K until ~512 workgroups exist, keeping >= 4 chunks of 32 per slice
+        const long tiles = (long)((N + GT_BN - 1) / GT_BN) * ((M + GT_BM - 1) / GT_BM);
+        static const int target = getenv("PPV_GEMM_TILED_WGS") ? atoi(getenv("PPV_GEMM_TILED_WGS")) : 512;
+        const int chunks = (K + GT_BK - 1) / GT_BK;
+        int ks = 1;
+        while (ks < ks_max && tiles * ks < target && chunks / (ks * 2) >= 4) ks *= 2;
+        return ks;
+    }
+    const long wgs = (long)((N + 15) / 16) * ((M + 127) / 128);
     int ks = 1;
     while (ks < ks_max && wgs * ks < ksplit_target() && K / (16 * 4 * ks * 2) >= 2) ks *= 2;
     return ks;
@@ -120,8 +269,47 @@ int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float
                  int ksplit, hipStream_t stream) {
     if (!x || !W || !out) return PPV_ERR_NULL;
     if (M < 1 || N < 1 || K < 16 || K % 16 || ldx % 4 || ldw % 4 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
+    if (use_tiled(M, N, K) && ((size_t)x % 16 == 0) && ((size_t)W % 16 == 0)) {
+        const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
+        gemm_f32_tiled_kernel<<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, ksplit > 1 ? 1 : 0, nullptr);
+        return ppv_last_error();
+    }
     const dim3 grid((unsigned)((N + 15) / 16), (unsigned)ksplit, (unsigned)((M + 127) / 128));
     gemm_f32_kernel<<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, ksplit > 1 ? 1 : 0);
+    return ppv_last_error();
+}
+
+// The same product with the K slices combined WITHOUT atomics and without a pre-zeroed output: every slice stores its tile into
+// workspace [ksplit][M][N] f32 and one small launch sums the slices in index order (bit-reproducible for any split; no fill launch in
+// front of the GEMM).  ppv_gemm_f32_ws_plan gives the split this form wants (up to 16 slices: slabs cost a plain store, so M = 128
+// layers can put two workgroups on every CU) and the bytes it needs; ksplit == 1 (or shapes the tiled kernel does not serve) falls
+// through to ppv_gemm_f32.  N % 4 == 0, out rows 16-byte aligned when ksplit > 1.
+int ppv_gemm_f32_ws_plan(int M, int N, int K, size_t* bytes) {
+    int ks = 1;
+    if (use_tiled(M, N, K) && N % 4 == 0) {
+        const long tiles = (long)((N + GT_BN - 1) / GT_BN) * ((M + GT_BM - 1) / GT_BM);
+        static const int target = getenv("PPV_GEMM_WS_WGS") ? atoi(getenv("PPV_GEMM_WS_WGS")) : 512;
+        const int chunks = (K + GT_BK - 1) / GT_BK;
+        while (ks < 16 && tiles * ks < target && chunks / (ks * 2) >= 3) ks *= 2;
+    }
+    if (bytes) *bytes = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    return ks;
+}
+
+int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
+                    int ksplit, void* workspace, hipStream_t stream) {
+    if (!x || !W || !out) return PPV_ERR_NULL;
+    if (M < 1 || N < 1 || K < 16 || K % 16 || ldx % 4 || ldw % 4 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
+    if (ksplit == 1 || !use_tiled(M, N, K) || ((size_t)x % 16) || ((size_t)W % 16)) {
+        if (ksplit > 1) return PPV_ERR_BAD_SIZE;                 // (the atomics form needs a zeroed output: the caller must ask ppv_gemm_f32 for that)
+        return ppv_gemm_f32(x, ldx, W, ldw, bias, out, ldo, M, N, K, 1, stream);
+    }
+    if (!workspace) return PPV_ERR_NULL;
+    if (N % 4 || ldo % 4 || ((size_t)out % 16) || (bias && ((size_t)bias % 16))) return PPV_ERR_BAD_SIZE;
+    const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
+    gemm_f32_tiled_kernel<<<grid, 256, 0, stream>>>(x, ldx, W, ldw, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
+    const long n4 = (long)M * (N / 4);
+    gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, bias, out, ldo, M, N, ksplit);
     return ppv_last_error();
 }
 

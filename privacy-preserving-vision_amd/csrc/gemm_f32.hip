@@ -163,19 +163,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
             if (c + 1 < c_end) fetch(c + 1);
             const float* tx = &sX[buf][r * GT_LD + 4 * q];
             const float* tw = &sW[buf][(wave * 16 + r) * GT_LD + 4 * q];
+            // all 18 fragment reads of the chunk are issued up front (LDS returns in order: the second half's reads fly under the first
+            // half's MFMAs); MFMAs component-major, so that eight independent accumulators separate two dependent ones
+            float4 wv[2], xv[2][8];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const float4 wv = *reinterpret_cast<const float4*>(tw + kk * 16);
-                float4 xv[8];
+                wv[kk] = *reinterpret_cast<const float4*>(tw + kk * 16);
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) xv[mb] = *reinterpret_cast<const float4*>(tx + mb * 16 * GT_LD + kk * 16);
+                for (int mb = 0; mb < 8; ++mb) xv[kk][mb] = *reinterpret_cast<const float4*>(tx + mb * 16 * GT_LD + kk * 16);
+            }
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) {
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].x, wv.x, acc[mb], 0, 0, 0);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].y, wv.y, acc[mb], 0, 0, 0);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].z, wv.z, acc[mb], 0, 0, 0);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[mb].w, wv.w, acc[mb], 0, 0, 0);
-                }
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].x, wv[kk].x, acc[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].y, wv[kk].y, acc[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].z, wv[kk].z, acc[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].w, wv[kk].w, acc[mb], 0, 0, 0);
             }
             if (c + 1 < c_end) park(buf ^ 1);
             __syncthreads();

@@ -136,6 +136,11 @@ int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float
  * atomics, no pre-zeroed output, bit-reproducible for any split.  ppv_gemm_f32_ws_plan returns the split to pass (1: no workspace
  * needed) and the workspace bytes. */
 int ppv_gemm_f32_ws_plan(int M, int N, int K, size_t* bytes);
+/* out[m][n] = sum_k a[k][m] b[k][n] (both operands K-major, any K): the batched weight gradients g^T h of the decoder's dense layers
+ * (models.py:199-214 autograd) without transposed copies; split and workspace from ppv_gemm_f32_tn_plan */
+int ppv_gemm_f32_tn_plan(int M, int N, int K, size_t* bytes);
+int ppv_gemm_f32_tn(const float* a, long lda, const float* b, long ldb, float* out, long ldo, int M, int N, int K, int ksplit,
+                    void* workspace, ppv_stream_t stream);
 int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
                     int ksplit, void* workspace, ppv_stream_t stream);
 /* InstanceNorm2d / AdaIN (+ LeakyReLU) of the StarGAN-v2 blocks (Face-DeId/core/model.py:12-124), NHWC f32:

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -91,6 +91,8 @@ PROTOTYPES = {
     "ppv_gemm_f32_ksplit": (_I, [_I, _I, _I]),
     "ppv_gemm_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P]),
     "ppv_gemm_f32_ws_plan": (_I, [_I, _I, _I, _P]),
+    "ppv_gemm_f32_tn_plan": (_I, [_I, _I, _I, _P]),
+    "ppv_gemm_f32_tn": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P]),
     "ppv_gemm_f32_ws": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "ppv_conv_gemm_rect": (_I, [_P, _P, _P, _P] + [_I] * 10 + [_P]),
     "ppv_gru_zr": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P]),

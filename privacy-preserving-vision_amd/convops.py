@@ -257,6 +257,26 @@ def linear_f32(x, w, bias=None, out=None):
     return out
 
 
+def gemm_f32_tn(a, b, out=None):
+    """a^T b in exact f32 on the matrix pipe: a [K, M], b [K, N] f32 with unit column stride (rows may be strided) -> [M, N].  The
+    batched weight gradient g^T h of a dense layer without transposed copies (csrc/gemm_f32.hip ppv_gemm_f32_tn)."""
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and a.dtype == F32 and b.dtype == F32 and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=F32, device=a.device)
+    else:
+        assert tuple(out.shape) == (M, N) and out.stride(1) == 1 and out.dtype == F32
+    nbytes = _lib.ctypes.c_size_t(0)
+    ks = L().ppv_gemm_f32_tn_plan(M, N, K, _lib.ctypes.byref(nbytes))
+    if ks > 1 and (out.stride(0) % 4 or out.data_ptr() % 16):
+        ks = 1
+    ws = _gemm_scratch(a.device, nbytes.value) if ks > 1 else None
+    check(L().ppv_gemm_f32_tn(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ks, ptr(ws), stream_ptr()),
+          "ppv_gemm_f32_tn")
+    return out
+
+
 # ----------------------------------------------------------------------------- stem
 def stem_weight_layout(w, mode):
     out = torch.empty((64, 24, 8) if mode == 0 else (16, 4, 4, 64), dtype=BF16, device=w.device)

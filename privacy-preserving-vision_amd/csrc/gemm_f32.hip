@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // 16-chunk is permuted identically for both operands.
 constexpr int GT_BM = 128, GT_BN = 64, GT_BK = 32, GT_LD = 36;
 
+// TN = true: both operands K-major -- x[k][m] at x + k * ldx + m, W[k][n] at W + k * ldw + n (the batched weight gradients g^T h of the dense
+// layers: k runs over (time step, caption), any K); a thread then gathers the four k of a float4 with four coalesced dword loads.
+// (A K-major LDS image with scalar fragment reads was tried instead: 72 ds_read_b32 per chunk made it 1.3-1.8x slower.)
+template <bool TN>
 __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, long ldw,
                                                                 const float* __restrict__ bias, float* __restrict__ out, long ldo, int M,
                                                                 int N, int K, int ksplit, int use_atomics, float* __restrict__ slab) {
@@ -117,38 +121,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
     const int cps = (chunks + ksplit - 1) / ksplit;
     const int c_begin = kslice * cps, c_end = min(chunks, c_begin + cps);
     if (c_begin >= c_end && !(kslice == 0) && !slab) return;     // (a slab slice without chunks still writes its zeros)
-    // staging roles: a thread moves 4 float4 of x and 2 of W per chunk; float4 index f -> row f / 8, k quarter-pair f % 8
-    const int xr0 = tid >> 3, xk = (tid & 7) * 4;                          // rows xr0 + 32 i, i = 0..3
+    // staging roles.  NT: a thread moves 4 float4 of x and 2 of W per chunk; float4 index f -> row f / 8, k quarter-pair f % 8.
+    // TN: thread t gathers, for row m = t % 128 (n = t % 64), the 16 (8) k of its share as coalesced dword loads.
+    const int xr0 = tid >> 3, xk = (tid & 7) * 4;                          // NT: rows xr0 + 32 i, i = 0..3
+    const int tm = tid & 127, tkh = (tid >> 7) * 16;                       // TN x: row, first k of its 16
+    const int tn = tid & 63, tkq = (tid >> 6) * 8;                         // TN W: row, first k of its 8
     const float* xsrc[4];
     bool xok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + xr0 + 32 * i;
-        xok[i] = m < M;
-        xsrc[i] = x + (long)(xok[i] ? m : 0) * ldx + xk;
-    }
     const float* wsrc[2];
     bool wok[2];
+    if constexpr (!TN) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = n0 + xr0 + 32 * i;
-        wok[i] = n < N;
-        wsrc[i] = W + (long)(wok[i] ? n : 0) * ldw + xk;
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + xr0 + 32 * i;
+            xok[i] = m < M;
+            xsrc[i] = x + (long)(xok[i] ? m : 0) * ldx + xk;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + xr0 + 32 * i;
+            wok[i] = n < N;
+            wsrc[i] = W + (long)(wok[i] ? n : 0) * ldw + xk;
+        }
+    } else {
+        xok[0] = (m0 + tm) < M;
+        xsrc[0] = x + (xok[0] ? m0 + tm : 0);
+        wok[0] = (n0 + tn) < N;
+        wsrc[0] = W + (wok[0] ? n0 + tn : 0);
     }
     float4 rx[4], rw[2];
     auto fetch = [&](int c) {
-        const int k = c * GT_BK + xk;
-        const bool kok = k < K;                                             // K % 16 == 0, xk % 4 == 0: a float4 is inside or outside as a whole
+        if constexpr (!TN) {
+            const int k = c * GT_BK + xk;
+            const bool kok = k < K;                                         // K % 16 == 0, xk % 4 == 0: a float4 is inside or outside as a whole
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rx[i] = (xok[i] && kok) ? *reinterpret_cast<const float4*>(xsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 4; ++i) rx[i] = (xok[i] && kok) ? *reinterpret_cast<const float4*>(xsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(wsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 2; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(wsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int kx = c * GT_BK + tkh, kw = c * GT_BK + tkq;
+            auto ld = [&](const float* base, long ld_, int k, bool ok) { return (ok && k < K) ? base[(long)k * ld_] : 0.f; };
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rx[i] = make_float4(ld(xsrc[0], ldx, kx + 4 * i, xok[0]), ld(xsrc[0], ldx, kx + 4 * i + 1, xok[0]), ld(xsrc[0], ldx, kx + 4 * i + 2, xok[0]),
+                                    ld(xsrc[0], ldx, kx + 4 * i + 3, xok[0]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                rw[i] = make_float4(ld(wsrc[0], ldw, kw + 4 * i, wok[0]), ld(wsrc[0], ldw, kw + 4 * i + 1, wok[0]), ld(wsrc[0], ldw, kw + 4 * i + 2, wok[0]),
+                                    ld(wsrc[0], ldw, kw + 4 * i + 3, wok[0]));
+        }
     };
     auto park = [&](int buf) {
+        if constexpr (!TN) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sX[buf][(xr0 + 32 * i) * GT_LD + xk]) = rx[i];
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sX[buf][(xr0 + 32 * i) * GT_LD + xk]) = rx[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][(xr0 + 32 * i) * GT_LD + xk]) = rw[i];
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][(xr0 + 32 * i) * GT_LD + xk]) = rw[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sX[buf][tm * GT_LD + tkh + 4 * i]) = rx[i];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][tn * GT_LD + tkq + 4 * i]) = rw[i];
+        }
     };
     gf32x4 acc[8];
 #pragma unroll
@@ -277,7 +311,7 @@ int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float
     if (M < 1 || N < 1 || K < 16 || K % 16 || ldx % 4 || ldw % 4 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
     if (use_tiled(M, N, K) && ((size_t)x % 16 == 0) && ((size_t)W % 16 == 0)) {
         const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
-        gemm_f32_tiled_kernel<<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, ksplit > 1 ? 1 : 0, nullptr);
+        gemm_f32_tiled_kernel<false><<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, ksplit > 1 ? 1 : 0, nullptr);
         return ppv_last_error();
     }
     const dim3 grid((unsigned)((N + 15) / 16), (unsigned)ksplit, (unsigned)((M + 127) / 128));
@@ -313,9 +347,41 @@ int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const fl
     if (!workspace) return PPV_ERR_NULL;
     if (N % 4 || ldo % 4 || ((size_t)out % 16) || (bias && ((size_t)bias % 16))) return PPV_ERR_BAD_SIZE;
     const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
-    gemm_f32_tiled_kernel<<<grid, 256, 0, stream>>>(x, ldx, W, ldw, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
+    gemm_f32_tiled_kernel<false><<<grid, 256, 0, stream>>>(x, ldx, W, ldw, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
     const long n4 = (long)M * (N / 4);
     gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, bias, out, ldo, M, N, ksplit);
+    return ppv_last_error();
+}
+
+// out[m][n] = sum_k a[k][m] * b[k][n]: the batched weight gradient g^T h of a dense layer (Image_Caption/models.py:199-214 under autograd:
+// d W = sum over time steps and captions of (d out)^T in), both operands as they lie in memory -- a [K][M] (row stride lda), b [K][N]
+// (row stride ldb), out [M][N] (row stride ldo); any K.  Same tile, arithmetic and slab combination as ppv_gemm_f32_ws;
+// ppv_gemm_f32_tn_plan gives the split and the workspace bytes (0: none needed).  N % 4 == 0 and out 16-byte aligned when split.
+int ppv_gemm_f32_tn_plan(int M, int N, int K, size_t* bytes) {
+    const long tiles = (long)((N + GT_BN - 1) / GT_BN) * ((M + GT_BM - 1) / GT_BM);
+    static const int target = getenv("PPV_GEMM_WS_WGS") ? atoi(getenv("PPV_GEMM_WS_WGS")) : 512;
+    const int chunks = (K + GT_BK - 1) / GT_BK;
+    int ks = 1;
+    if (N % 4 == 0)
+        while (ks < 16 && tiles * ks < target && chunks / (ks * 2) >= 3) ks *= 2;
+    if (bytes) *bytes = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    return ks;
+}
+
+int ppv_gemm_f32_tn(const float* a, long lda, const float* b, long ldb, float* out, long ldo, int M, int N, int K, int ksplit,
+                    void* workspace, hipStream_t stream) {
+    if (!a || !b || !out) return PPV_ERR_NULL;
+    if (M < 1 || N < 1 || K < 1 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
+    const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
+    if (ksplit == 1) {
+        gemm_f32_tiled_kernel<true><<<grid, 256, 0, stream>>>(a, lda, b, ldb, nullptr, out, ldo, M, N, K, 1, 0, nullptr);
+        return ppv_last_error();
+    }
+    if (!workspace) return PPV_ERR_NULL;
+    if (N % 4 || ldo % 4 || ((size_t)out % 16)) return PPV_ERR_BAD_SIZE;
+    gemm_f32_tiled_kernel<true><<<grid, 256, 0, stream>>>(a, lda, b, ldb, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
+    const long n4 = (long)M * (N / 4);
+    gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, nullptr, out, ldo, M, N, ksplit);
     return ppv_last_error();
 }
 

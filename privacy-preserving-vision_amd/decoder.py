@@ -164,6 +164,8 @@ def _tn(g, h, hip):
         check(L().ppv_split3_rows(ptr(g), g.stride(0), ptr(G3), m, N, Np, 0, stream_ptr()), "ppv_split3_rows")
         check(L().ppv_split3_rows(ptr(h), h.stride(0), ptr(H3), m, K, Kp, 1, stream_ptr()), "ppv_split3_rows")
         return co.conv_wgrad(G3, H3, 1, 1, 1, 0).view(Np, Kp)[:N, :K]
+    if g.stride(1) == 1 and h.stride(1) == 1 and g.dtype == F32 and h.dtype == F32:
+        return co.gemm_f32_tn(g, h)               # both operands as they lie in memory (round 4: no transposed copies)
     m = g.shape[0]
     mp = (m + 15) // 16 * 16
     gt = torch.zeros((g.shape[1], mp), dtype=F32, device=g.device)

@@ -288,3 +288,23 @@ def test_staged_caption_lengths_give_the_same_forward():
         back = torch.load(buf, weights_only=False)
         assert getattr(back, "_staged", None) is None
         torch.testing.assert_close(back(enc_out, caps, lens)[0], want[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,M,N", [(1658, 2048, 512), (1658, 512, 512), (128, 512, 2048), (77, 200, 36), (1000, 9490, 512)])
+def test_gemm_f32_tn_equals_the_matrix_product(K, M, N):
+    """ppv_gemm_f32_tn: a^T b with both operands K-major (the decoder's batched weight gradients g^T h, models.py:199-214 autograd), exact
+    f32 on the matrix pipe, any K / M / N, with and without the slab split."""
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(K + M + N)
+    a = torch.randn(K, M, generator=g0).cuda()
+    b = torch.randn(K, N, generator=g0).cuda()
+    got = co.gemm_f32_tn(a, b)
+    want = (a.double().t() @ b.double()).float()
+    assert got.shape == (M, N)
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-6
+    # strided rows (a column block of a wider buffer)
+    wide = torch.randn(K, M + 24, generator=g0).cuda()
+    got2 = co.gemm_f32_tn(wide[:, 8:8 + M], b)
+    want2 = (wide[:, 8:8 + M].double().t() @ b.double()).float()
+    assert float((got2 - want2).abs().max() / want2.abs().max()) < 2e-6

@@ -107,8 +107,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 constexpr int GT_BM = 128, GT_BN = 64, GT_BK = 32, GT_LD = 36;
 
 // TN = true: both operands K-major -- x[k][m] at x + k * ldx + m, W[k][n] at W + k * ldw + n (the batched weight gradients g^T h of the dense
-// layers: k runs over (time step, caption), any K); a thread then gathers the four k of a float4 with four coalesced dword loads.
-// (A K-major LDS image with scalar fragment reads was tried instead: 72 ds_read_b32 per chunk made it 1.3-1.8x slower.)
+// layers: k runs over (time step, caption), any K).  A thread loads float4s ALONG m (coalesced 16-byte loads, like the NT form) and the
+// transposition happens on the way into LDS: the four m of a float4 go to four rows of the same [row][k] image as four ds_write_b32, and
+// the 4-float k-groups of a row are XOR-swizzled by (row >> 4) & 3, which puts the 64 lanes of such a write -- 4 consecutive k x 16
+// column groups -- on 64 different banks (bank = 16 (u & 3) + 4 ((k-group ^ (u >> 2)) & 3) + k % 4 for column group u); the fragment
+// reads stay 16-byte ds_read_b128 with the swizzled group index (a constant per accumulator row block).  Tried before and dropped: per-k
+// dword gathers (24 loads per thread and chunk: 53-63 TFLOP/s) and a K-major LDS image with scalar fragment reads (72 ds_read_b32 per
+// chunk: slower still).
 template <bool TN>
 __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, long ldw,
                                                                 const float* __restrict__ bias, float* __restrict__ out, long ldo, int M,
@@ -121,11 +126,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
     const int cps = (chunks + ksplit - 1) / ksplit;
     const int c_begin = kslice * cps, c_end = min(chunks, c_begin + cps);
     if (c_begin >= c_end && !(kslice == 0) && !slab) return;     // (a slab slice without chunks still writes its zeros)
-    // staging roles.  NT: a thread moves 4 float4 of x and 2 of W per chunk; float4 index f -> row f / 8, k quarter-pair f % 8.
-    // TN: thread t gathers, for row m = t % 128 (n = t % 64), the 16 (8) k of its share as coalesced dword loads.
+    // staging roles: a thread moves 4 float4 of x and 2 of W per chunk.
+    //   NT: float4 index f -> row f / 8, k quarter-pair f % 8 (a float4 = four k of one row).
+    //   TN: thread t = c + 4 u + 128 g: k = 16 g + 4 i + c (x; W: t = c + 4 u + 64 g, k = 8 g + 4 i + c), columns 4 u .. 4 u + 3
+    //       (a float4 = four rows of one k); per instruction a wave covers 4 k-rows x 256 contiguous bytes.
     const int xr0 = tid >> 3, xk = (tid & 7) * 4;                          // NT: rows xr0 + 32 i, i = 0..3
-    const int tm = tid & 127, tkh = (tid >> 7) * 16;                       // TN x: row, first k of its 16
-    const int tn = tid & 63, tkq = (tid >> 6) * 8;                         // TN W: row, first k of its 8
+    const int tc = tid & 3;
+    const int txu = (tid >> 2) & 31, txg = tid >> 7;                       // TN x
+    const int twu = (tid >> 2) & 15, twg = tid >> 6;                       // TN W
     const float* xsrc[4];
     bool xok[4];
     const float* wsrc[2];
@@ -143,13 +151,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
             wok[i] = n < N;
             wsrc[i] = W + (long)(wok[i] ? n : 0) * ldw + xk;
         }
-    } else {
-        xok[0] = (m0 + tm) < M;
-        xsrc[0] = x + (xok[0] ? m0 + tm : 0);
-        wok[0] = (n0 + tn) < N;
-        wsrc[0] = W + (wok[0] ? n0 + tn : 0);
     }
     float4 rx[4], rw[2];
+    // TN: 16-byte loads when a row leaves room for the float4 that straddles the last column (columns >= M feed output rows that are
+    // never stored) and everything is 16-byte aligned; element-wise with predicates otherwise
+    const bool vx = TN && ldx % 4 == 0 && ((size_t)x % 16 == 0) && ((M + 3) / 4 * 4 <= ldx);
+    const bool vw = TN && ldw % 4 == 0 && ((size_t)W % 16 == 0) && ((N + 3) / 4 * 4 <= ldw);
+    auto ld4 = [&](const float* base, long ld_, int k, int c0, int C, bool vec) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && c0 < C) {
+            const float* p = base + (long)k * ld_ + c0;
+            if (vec) v = *reinterpret_cast<const float4*>(p);
+            else {
+                v.x = p[0];
+                if (c0 + 1 < C) v.y = p[1];
+                if (c0 + 2 < C) v.z = p[2];
+                if (c0 + 3 < C) v.w = p[3];
+            }
+        }
+        return v;
+    };
     auto fetch = [&](int c) {
         if constexpr (!TN) {
             const int k = c * GT_BK + xk;
@@ -159,16 +180,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 2; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(wsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            const int kx = c * GT_BK + tkh, kw = c * GT_BK + tkq;
-            auto ld = [&](const float* base, long ld_, int k, bool ok) { return (ok && k < K) ? base[(long)k * ld_] : 0.f; };
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rx[i] = make_float4(ld(xsrc[0], ldx, kx + 4 * i, xok[0]), ld(xsrc[0], ldx, kx + 4 * i + 1, xok[0]), ld(xsrc[0], ldx, kx + 4 * i + 2, xok[0]),
-                                    ld(xsrc[0], ldx, kx + 4 * i + 3, xok[0]));
+            for (int i = 0; i < 4; ++i) rx[i] = ld4(x, ldx, c * GT_BK + 16 * txg + 4 * i + tc, m0 + 4 * txu, M, vx);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                rw[i] = make_float4(ld(wsrc[0], ldw, kw + 4 * i, wok[0]), ld(wsrc[0], ldw, kw + 4 * i + 1, wok[0]), ld(wsrc[0], ldw, kw + 4 * i + 2, wok[0]),
-                                    ld(wsrc[0], ldw, kw + 4 * i + 3, wok[0]));
+            for (int i = 0; i < 2; ++i) rw[i] = ld4(W, ldw, c * GT_BK + 8 * twg + 4 * i + tc, n0 + 4 * twu, N, vw);
         }
     };
     auto park = [&](int buf) {
@@ -178,10 +193,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][(xr0 + 32 * i) * GT_LD + xk]) = rw[i];
         } else {
+            // element (row, k) lives at row * 36 + 4 * ((k >> 2) ^ ((row >> 4) & 3)) + (k & 3); row >> 4 == u >> 2 for all four rows of a float4
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sX[buf][tm * GT_LD + tkh + 4 * i]) = rx[i];
+            for (int i = 0; i < 4; ++i) {
+                const int kg = (4 * txg + i) ^ ((txu >> 2) & 3);
+                float* d = &sX[buf][(4 * txu) * GT_LD + 4 * kg + tc];
+                d[0] = rx[i].x; d[GT_LD] = rx[i].y; d[2 * GT_LD] = rx[i].z; d[3 * GT_LD] = rx[i].w;
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][tn * GT_LD + tkq + 4 * i]) = rw[i];
+            for (int i = 0; i < 2; ++i) {
+                const int kg = (2 * twg + i) ^ ((twu >> 2) & 3);
+                float* d = &sW[buf][(4 * twu) * GT_LD + 4 * kg + tc];
+                d[0] = rw[i].x; d[GT_LD] = rw[i].y; d[2 * GT_LD] = rw[i].z; d[3 * GT_LD] = rw[i].w;
+            }
         }
     };
     gf32x4 acc[8];
@@ -195,16 +219,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
         int buf = 0;
         for (int c = c_begin; c < c_end; ++c) {
             if (c + 1 < c_end) fetch(c + 1);
-            const float* tx = &sX[buf][r * GT_LD + 4 * q];
-            const float* tw = &sW[buf][(wave * 16 + r) * GT_LD + 4 * q];
+            const float* tx = &sX[buf][r * GT_LD];
+            const float* tw = &sW[buf][(wave * 16 + r) * GT_LD];
+            // k-group of this lane's fragment in half kk of the chunk: 4 kk + q, swizzled by the row block in the TN image
+            auto xg = [&](int kk, int mb) { return 4 * ((4 * kk + q) ^ (TN ? (mb & 3) : 0)); };
+            auto wg_ = [&](int kk) { return 4 * ((4 * kk + q) ^ (TN ? (wave & 3) : 0)); };
             // all 18 fragment reads of the chunk are issued up front (LDS returns in order: the second half's reads fly under the first
             // half's MFMAs); MFMAs component-major, so that eight independent accumulators separate two dependent ones
             float4 wv[2], xv[2][8];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                wv[kk] = *reinterpret_cast<const float4*>(tw + kk * 16);
+                wv[kk] = *reinterpret_cast<const float4*>(tw + wg_(kk));
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) xv[kk][mb] = *reinterpret_cast<const float4*>(tx + mb * 16 * GT_LD + kk * 16);
+                for (int mb = 0; mb < 8; ++mb) xv[kk][mb] = *reinterpret_cast<const float4*>(tx + mb * 16 * GT_LD + xg(kk, mb));
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

@@ -114,14 +114,17 @@ constexpr int GT_BM = 128, GT_BN = 64, GT_BK = 32, GT_LD = 36;
 // reads stay 16-byte ds_read_b128 with the swizzled group index (a constant per accumulator row block).  Tried before and dropped: per-k
 // dword gathers (24 loads per thread and chunk: 53-63 TFLOP/s) and a K-major LDS image with scalar fragment reads (72 ds_read_b32 per
 // chunk: slower still).
-template <bool TN>
+// NB = 16-column blocks per wave: the workgroup's tile is 128 x 64 NB.  NB = 2 (128 x 128, 128 MFMAs per wave and chunk against 20
+// fragment reads, half the tiles) where the grid stays large enough; NB = 1 otherwise.
+template <bool TN, int NB>
 __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, long ldw,
                                                                 const float* __restrict__ bias, float* __restrict__ out, long ldo, int M,
                                                                 int N, int K, int ksplit, int use_atomics, float* __restrict__ slab) {
     __shared__ __attribute__((aligned(16))) float sX[2][GT_BM * GT_LD];
-    __shared__ __attribute__((aligned(16))) float sW[2][GT_BN * GT_LD];
+    constexpr int BN = GT_BN * NB;
+    __shared__ __attribute__((aligned(16))) float sW[2][BN * GT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * GT_BN, m0 = blockIdx.z * GT_BM, kslice = blockIdx.y;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.z * GT_BM, kslice = blockIdx.y;
     const int chunks = (K + GT_BK - 1) / GT_BK;
     const int cps = (chunks + ksplit - 1) / ksplit;
     const int c_begin = kslice * cps, c_end = min(chunks, c_begin + cps);
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
     const int twu = (tid >> 2) & 15, twg = tid >> 6;                       // TN W
     const float* xsrc[4];
     bool xok[4];
-    const float* wsrc[2];
-    bool wok[2];
+    const float* wsrc[2 * NB];
+    bool wok[2 * NB];
     if constexpr (!TN) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -146,13 +149,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
             xsrc[i] = x + (long)(xok[i] ? m : 0) * ldx + xk;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 * NB; ++i) {
             const int n = n0 + xr0 + 32 * i;
             wok[i] = n < N;
             wsrc[i] = W + (long)(wok[i] ? n : 0) * ldw + xk;
         }
     }
-    float4 rx[4], rw[2];
+    float4 rx[4], rw[2 * NB];
     // TN: 16-byte loads when a row leaves room for the float4 that straddles the last column (columns >= M feed output rows that are
     // never stored) and everything is 16-byte aligned; element-wise with predicates otherwise
     const bool vx = TN && ldx % 4 == 0 && ((size_t)x % 16 == 0) && ((M + 3) / 4 * 4 <= ldx);
@@ -178,12 +181,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) rx[i] = (xok[i] && kok) ? *reinterpret_cast<const float4*>(xsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(wsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 2 * NB; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(wsrc[i] + (long)c * GT_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) rx[i] = ld4(x, ldx, c * GT_BK + 16 * txg + 4 * i + tc, m0 + 4 * txu, M, vx);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) rw[i] = ld4(W, ldw, c * GT_BK + 8 * twg + 4 * i + tc, n0 + 4 * twu, N, vw);
+            for (int i = 0; i < 2 * NB; ++i) rw[i] = ld4(W, ldw, c * GT_BK + 8 * twg + 4 * (i & 1) + tc, n0 + 64 * (i >> 1) + 4 * twu, N, vw);
         }
     };
     auto park = [&](int buf) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sX[buf][(xr0 + 32 * i) * GT_LD + xk]) = rx[i];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sW[buf][(xr0 + 32 * i) * GT_LD + xk]) = rw[i];
+            for (int i = 0; i < 2 * NB; ++i) *reinterpret_cast<float4*>(&sW[buf][(xr0 + 32 * i) * GT_LD + xk]) = rw[i];
         } else {
             // element (row, k) lives at row * 36 + 4 * ((k >> 2) ^ ((row >> 4) & 3)) + (k & 3); row >> 4 == u >> 2 for all four rows of a float4
 #pragma unroll
@@ -201,16 +204,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
                 d[0] = rx[i].x; d[GT_LD] = rx[i].y; d[2 * GT_LD] = rx[i].z; d[3 * GT_LD] = rx[i].w;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int kg = (2 * twg + i) ^ ((twu >> 2) & 3);
-                float* d = &sW[buf][(4 * twu) * GT_LD + 4 * kg + tc];
+            for (int i = 0; i < 2 * NB; ++i) {
+                const int kg = (2 * twg + (i & 1)) ^ ((twu >> 2) & 3);        // (rows 64 apart share (row >> 4) & 3)
+                float* d = &sW[buf][(64 * (i >> 1) + 4 * twu) * GT_LD + 4 * kg + tc];
                 d[0] = rw[i].x; d[GT_LD] = rw[i].y; d[2 * GT_LD] = rw[i].z; d[3 * GT_LD] = rw[i].w;
             }
         }
     };
-    gf32x4 acc[8];
+    gf32x4 acc[NB][8];
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc[mb] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = (gf32x4){0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, q = lane >> 4;
     if (c_begin < c_end) {
         fetch(c_begin);
@@ -224,34 +229,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
             // k-group of this lane's fragment in half kk of the chunk: 4 kk + q, swizzled by the row block in the TN image
             auto xg = [&](int kk, int mb) { return 4 * ((4 * kk + q) ^ (TN ? (mb & 3) : 0)); };
             auto wg_ = [&](int kk) { return 4 * ((4 * kk + q) ^ (TN ? (wave & 3) : 0)); };
-            // all 18 fragment reads of the chunk are issued up front (LDS returns in order: the second half's reads fly under the first
-            // half's MFMAs); MFMAs component-major, so that eight independent accumulators separate two dependent ones
-            float4 wv[2], xv[2][8];
+            // all fragment reads of the chunk are issued up front (LDS returns in order: the second half's reads fly under the first
+            // half's MFMAs); MFMAs component-major, so that eight independent accumulators separate two dependent ones.  Wave w owns the
+            // columns nb * 64 + w * 16 + r of the tile.
+            float4 wv[2][NB], xv[2][8];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                wv[kk] = *reinterpret_cast<const float4*>(tw + wg_(kk));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wv[kk][nb] = *reinterpret_cast<const float4*>(tw + nb * 64 * GT_LD + wg_(kk));
 #pragma unroll
                 for (int mb = 0; mb < 8; ++mb) xv[kk][mb] = *reinterpret_cast<const float4*>(tx + mb * 16 * GT_LD + xg(kk, mb));
             }
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].x, wv[kk].x, acc[mb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].y, wv[kk].y, acc[mb], 0, 0, 0);
+                    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].x, wv[kk][nb].x, acc[nb][mb], 0, 0, 0);
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].z, wv[kk].z, acc[mb], 0, 0, 0);
+                    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].y, wv[kk][nb].y, acc[nb][mb], 0, 0, 0);
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].w, wv[kk].w, acc[mb], 0, 0, 0);
-            }
+                    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].z, wv[kk][nb].z, acc[nb][mb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[kk][mb].w, wv[kk][nb].w, acc[nb][mb], 0, 0, 0);
+                }
             if (c + 1 < c_end) park(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
     }
-    // C/D layout: acc[mb][j] = out[x row mb * 16 + q * 4 + j][weight row wave * 16 + r]
-    const int n = n0 + wave * 16 + r;
-    if (n < N) {
+    // C/D layout: acc[nb][mb][j] = out[x row mb * 16 + q * 4 + j][weight row nb * 64 + wave * 16 + r]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 64 + wave * 16 + r;
+        if (n >= N) continue;
         if (slab) {                                                         // split K without atomics: slice kslice of [ksplit][M][N], summed by gemm_f32_slab_sum_kernel
             float* dst = slab + (long)kslice * M * N;
 #pragma unroll
@@ -259,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = m0 + mb * 16 + q * 4 + j;
-                    if (m < M) dst[(long)m * N + n] = acc[mb][j];
+                    if (m < M) dst[(long)m * N + n] = acc[nb][mb][j];
                 }
-            return;
+            continue;
         }
         const float b = (bias && kslice == 0) ? bias[n] : 0.f;
 #pragma unroll
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const float* __r
             for (int j = 0; j < 4; ++j) {
                 const int m = m0 + mb * 16 + q * 4 + j;
                 if (m < M) {
-                    const float v = acc[mb][j] + b;
+                    const float v = acc[nb][mb][j] + b;
                     if (use_atomics) atomicAdd(&out[(long)m * ldo + n], v);
                     else out[(long)m * ldo + n] = v;
                 }
@@ -314,12 +325,35 @@ static int gemm_tiled() {                                       // PPV_GEMM_TILE
     return t;
 }
 static bool use_tiled(int M, int N, int K) { return gemm_tiled() && M >= 32 && N >= 64 && K >= 64; }
+// 128 x 128 tiles where they still give every CU a workgroup; 128 x 64 otherwise (PPV_GEMM_NB=1 / 2 forces one form)
+static int tiled_nb(int M, int N) {
+    static const int f = getenv("PPV_GEMM_NB") ? atoi(getenv("PPV_GEMM_NB")) : 0;
+    if (f == 1 || f == 2) return f;
+    const long t128 = (long)((N + 127) / 128) * ((M + GT_BM - 1) / GT_BM);
+    return t128 >= 256 ? 2 : 1;         // measured (tools/bench_gemm_tn.py): 300-320 tiles of 128 x 128 beat 600-640 of 128 x 64 by 9-11 %
+}
+}  // extern "C" (a template needs C++ linkage)
+template <bool TN>
+static void launch_tiled(int nb, dim3 grid, hipStream_t stream, const float* x, long ldx, const float* W, long ldw, const float* bias, float* out,
+                         long ldo, int M, int N, int K, int ksplit, int atom, float* slab) {
+    if (nb == 2) gemm_f32_tiled_kernel<TN, 2><<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, atom, slab);
+    else gemm_f32_tiled_kernel<TN, 1><<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, atom, slab);
+}
+extern "C" {
+static dim3 tiled_grid(int nb, int M, int N, int ksplit) {
+    const int bn = GT_BN * nb;
+    return dim3((unsigned)((N + bn - 1) / bn), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
+}
+static long tiled_tiles(int M, int N) {
+    const int bn = GT_BN * tiled_nb(M, N);
+    return (long)((N + bn - 1) / bn) * ((M + GT_BM - 1) / GT_BM);
+}
 
 int ppv_gemm_f32_ksplit(int M, int N, int K) {
     static const int ks_max = (getenv("PPV_GEMM_DETERMINISTIC") && atoi(getenv("PPV_GEMM_DETERMINISTIC"))) ? 2 : 8;
     if (use_tiled(M, N, K)) {
         // 128 x 64 tiles, two workgroups per CU: split K until ~512 workgroups exist, keeping >= 4 chunks of 32 per slice
-        const long tiles = (long)((N + GT_BN - 1) / GT_BN) * ((M + GT_BM - 1) / GT_BM);
+        const long tiles = tiled_tiles(M, N);
         static const int target = getenv("PPV_GEMM_TILED_WGS") ? atoi(getenv("PPV_GEMM_TILED_WGS")) : 512;
         const int chunks = (K + GT_BK - 1) / GT_BK;
         int ks = 1;
@@ -337,8 +371,8 @@ int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float
     if (!x || !W || !out) return PPV_ERR_NULL;
     if (M < 1 || N < 1 || K < 16 || K % 16 || ldx % 4 || ldw % 4 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
     if (use_tiled(M, N, K) && ((size_t)x % 16 == 0) && ((size_t)W % 16 == 0)) {
-        const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
-        gemm_f32_tiled_kernel<false><<<grid, 256, 0, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, ksplit > 1 ? 1 : 0, nullptr);
+        const int nb = tiled_nb(M, N);
+        launch_tiled<false>(nb, tiled_grid(nb, M, N, ksplit), stream, x, ldx, W, ldw, bias, out, ldo, M, N, K, ksplit, ksplit > 1 ? 1 : 0, nullptr);
         return ppv_last_error();
     }
     const dim3 grid((unsigned)((N + 15) / 16), (unsigned)ksplit, (unsigned)((M + 127) / 128));
@@ -354,7 +388,7 @@ int ppv_gemm_f32(const float* x, long ldx, const float* W, long ldw, const float
 int ppv_gemm_f32_ws_plan(int M, int N, int K, size_t* bytes) {
     int ks = 1;
     if (use_tiled(M, N, K) && N % 4 == 0) {
-        const long tiles = (long)((N + GT_BN - 1) / GT_BN) * ((M + GT_BM - 1) / GT_BM);
+        const long tiles = tiled_tiles(M, N);
         static const int target = getenv("PPV_GEMM_WS_WGS") ? atoi(getenv("PPV_GEMM_WS_WGS")) : 512;
         const int chunks = (K + GT_BK - 1) / GT_BK;
         while (ks < 16 && tiles * ks < target && chunks / (ks * 2) >= 3) ks *= 2;
@@ -373,8 +407,8 @@ int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const fl
     }
     if (!workspace) return PPV_ERR_NULL;
     if (N % 4 || ldo % 4 || ((size_t)out % 16) || (bias && ((size_t)bias % 16))) return PPV_ERR_BAD_SIZE;
-    const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
-    gemm_f32_tiled_kernel<false><<<grid, 256, 0, stream>>>(x, ldx, W, ldw, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
+    const int nb = tiled_nb(M, N);
+    launch_tiled<false>(nb, tiled_grid(nb, M, N, ksplit), stream, x, ldx, W, ldw, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
     const long n4 = (long)M * (N / 4);
     gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, bias, out, ldo, M, N, ksplit);
     return ppv_last_error();
@@ -385,7 +419,7 @@ int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const fl
 // (row stride ldb), out [M][N] (row stride ldo); any K.  Same tile, arithmetic and slab combination as ppv_gemm_f32_ws;
 // ppv_gemm_f32_tn_plan gives the split and the workspace bytes (0: none needed).  N % 4 == 0 and out 16-byte aligned when split.
 int ppv_gemm_f32_tn_plan(int M, int N, int K, size_t* bytes) {
-    const long tiles = (long)((N + GT_BN - 1) / GT_BN) * ((M + GT_BM - 1) / GT_BM);
+    const long tiles = tiled_tiles(M, N);
     static const int target = getenv("PPV_GEMM_WS_WGS") ? atoi(getenv("PPV_GEMM_WS_WGS")) : 512;
     const int chunks = (K + GT_BK - 1) / GT_BK;
     int ks = 1;
@@ -399,14 +433,15 @@ int ppv_gemm_f32_tn(const float* a, long lda, const float* b, long ldb, float* o
                     void* workspace, hipStream_t stream) {
     if (!a || !b || !out) return PPV_ERR_NULL;
     if (M < 1 || N < 1 || K < 1 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
-    const dim3 grid((unsigned)((N + GT_BN - 1) / GT_BN), (unsigned)ksplit, (unsigned)((M + GT_BM - 1) / GT_BM));
+    const int nb = tiled_nb(M, N);
+    const dim3 grid = tiled_grid(nb, M, N, ksplit);
     if (ksplit == 1) {
-        gemm_f32_tiled_kernel<true><<<grid, 256, 0, stream>>>(a, lda, b, ldb, nullptr, out, ldo, M, N, K, 1, 0, nullptr);
+        launch_tiled<true>(nb, grid, stream, a, lda, b, ldb, nullptr, out, ldo, M, N, K, 1, 0, nullptr);
         return ppv_last_error();
     }
     if (!workspace) return PPV_ERR_NULL;
     if (N % 4 || ldo % 4 || ((size_t)out % 16)) return PPV_ERR_BAD_SIZE;
-    gemm_f32_tiled_kernel<true><<<grid, 256, 0, stream>>>(a, lda, b, ldb, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
+    launch_tiled<true>(nb, grid, stream, a, lda, b, ldb, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
     const long n4 = (long)M * (N / 4);
     gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, nullptr, out, ldo, M, N, ksplit);
     return ppv_last_error();

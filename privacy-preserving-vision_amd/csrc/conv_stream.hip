@@ -30,13 +30,7 @@ namespace ppv {
 typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ST_NCW = 8, ST_NLW = 4, ST_NT = (ST_NCW + ST_NLW) * 64, ST_NSLOT = 3;
 
-// DIRECT (round 4; the launches with a residual addend): the MFMA operands are SWAPPED -- weight fragment in the A position, pixel
-// fragment in the B position -- so a lane's four accumulator registers are four consecutive OUTPUT CHANNELS of one pixel row, and the
-// loader stages weight row nperm64(l) in LDS row l (conv_common.h), which makes acc[mi][2 s][0..3] | acc[mi][2 s + 1][0..3] the eight
-// channels s * 32 + fq * 8 .. + 7 of pixel row mi * 16 + fr: one 16-byte chunk per (mi, s), the four fq lanes of a row covering 64
-// contiguous bytes.  The block leaves the registers as it is: no LDS patch, no ds_write / ds_read round trip between the MFMAs and the
-// stores (32 + 8 LDS instructions and their latency chain per wave and step); addend, raw-x and mask operands arrive in the same chunks.
-template <int KC, bool OUT_F32, bool RED, bool ADD, bool MASK, bool DIRECT = false>
+template <int KC, bool OUT_F32, bool RED, bool ADD, bool MASK>
 __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend,
@@ -80,7 +74,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
         for (int i = 0; i < LI; ++i) {
             const int row = (i * ST_NLW + lw) * RPI + rl;                 // LDS row of the tile (0..63)
             const int key = KC == 64 ? (row & 7) : (row & 15);            // chunk swizzle (see the fragment read)
-            src[i] = Wt + (long)(n_begin + (DIRECT ? nperm64(row) : row)) * KC + (p ^ key) * 8;
+            src[i] = Wt + (long)(n_begin + row) * KC + (p ^ key) * 8;
         }
         int slot = 0;
         long adv = 0;
@@ -155,8 +149,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi][kk], acc[mi][ni], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], wf[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], wf[ni], acc[mi][ni], 0, 0, 0);
             }
         };
 
@@ -180,72 +173,6 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                             const long m = m0 + wave * 32 + mi * 16 + fq * 4 + r;
                             if (FULL || m < g.M) out[m * g.N + nc0 + ni * 16 + fr] = acc[mi][ni][r];
                         }
-            } else if constexpr (DIRECT) {
-                // accumulators (swapped operands): acc[mi][2 s + h][r] = out[row mi * 16 + fr][channel s * 32 + fq * 8 + h * 4 + r]
-                static_assert(ADD && MI == 2, "the direct-store epilogue serves the addend launches");
-                bf16_t* out = reinterpret_cast<bf16_t*>(Out);
-                uint4 av[MI][2], xv[MI][2];
-                unsigned mb[MI][2], offs[MI][2];
-                bool okr[MI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {                            // every operand of the step is requested first
-                    const unsigned m = (unsigned)m0 + wave * 32 + mi * 16 + fr;
-                    okr[mi] = FULL || m < (unsigned)g.M;
-#pragma unroll
-                    for (int s_ = 0; s_ < 2; ++s_) {
-                        const unsigned off = (okr[mi] ? m : 0u) * (unsigned)g.N + nc0 + s_ * 32 + fq * 8;
-                        offs[mi][s_] = off;
-                        av[mi][s_] = *reinterpret_cast<const uint4*>(addend + off);
-                        xv[mi][s_] = make_uint4(0, 0, 0, 0);
-                        mb[mi][s_] = 0xff;
-                        if constexpr (RED) {
-                            xv[mi][s_] = *reinterpret_cast<const uint4*>(red_x + off);
-                            if (!okr[mi]) xv[mi][s_] = make_uint4(0, 0, 0, 0);
-                        }
-                        if constexpr (MASK) mb[mi][s_] = mask_bits[off >> 3];
-                    }
-                }
-                float ra[2][8], rb[2][8];
-#pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) ra[s_][k] = rb[s_][k] = 0.f;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int s_ = 0; s_ < 2; ++s_) {
-                        float a[8];
-                        unpack8(okr[mi] ? av[mi][s_] : make_uint4(0, 0, 0, 0), a);
-                        const float v[8] = {acc[mi][2 * s_][0] + a[0], acc[mi][2 * s_][1] + a[1], acc[mi][2 * s_][2] + a[2], acc[mi][2 * s_][3] + a[3],
-                                            acc[mi][2 * s_ + 1][0] + a[4], acc[mi][2 * s_ + 1][1] + a[5], acc[mi][2 * s_ + 1][2] + a[6],
-                                            acc[mi][2 * s_ + 1][3] + a[7]};
-                        uint4 pv = pack8(v);                                 // one rounding of (acc + addend)
-                        if constexpr (MASK) pv = relu_mask8(pv, mb[mi][s_]);
-                        if constexpr (RED) red_acc8(pv, xv[mi][s_], ra[s_], rb[s_]);
-                        if (okr[mi]) *reinterpret_cast<uint4*>(out + offs[mi][s_]) = pv;
-                    }
-                if constexpr (RED) {                                         // fold the 16 pixel rows (fr) that share a chunk column, then the waves (LDS)
-#pragma unroll
-                    for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                            for (int o = 1; o < 16; o <<= 1) {
-                                ra[s_][k] += __shfl_xor(ra[s_][k], o, 64);
-                                rb[s_][k] += __shfl_xor(rb[s_][k], o, 64);
-                            }
-                        }
-                    if (fr == 0) {
-#pragma unroll
-                        for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const int col = nc0 - n_begin + s_ * 32 + fq * 8 + k;
-                                atomicAdd(&sStat[col], ra[s_][k]);
-                                atomicAdd(&sStat[nspan + col], rb[s_][k]);
-                            }
-                    }
-                }
             } else {
                 bf16_t* out = reinterpret_cast<bf16_t*>(Out);
                 const unsigned c = nc0 + ch * 8;                             // this lane's 8 channels in the chunk layout
@@ -443,28 +370,16 @@ static int stream_launch_k(const bf16_t* X, const bf16_t* Wt, void* out, float* 
          {conv1x1_stream_kernel<KC, false, false, true, false>, conv1x1_stream_kernel<KC, false, false, true, true>}},
         {{conv1x1_stream_kernel<KC, false, true, false, false>, conv1x1_stream_kernel<KC, false, true, false, true>},
          {conv1x1_stream_kernel<KC, false, true, true, false>, conv1x1_stream_kernel<KC, false, true, true, true>}}};
-    // the addend launches in the direct-store form (PPV_STREAM_DIRECT=0: through the LDS patch as before) [RED][MASK]
-    static const kern_t tabd[2][2] = {
-        {conv1x1_stream_kernel<KC, false, false, true, false, true>, conv1x1_stream_kernel<KC, false, false, true, true, true>},
-        {conv1x1_stream_kernel<KC, false, true, true, false, true>, conv1x1_stream_kernel<KC, false, true, true, true, true>}};
-    // MEASURED (round 4, tools/bench_dgrad_addend.py, cold operands, addend + mask + BN-backward sums, B = 128): the direct form is
-    // SLOWER -- 256 -> 1024: 65.3 us against 58.4 through the LDS patch, 128 -> 512: 126 against 112, 64 -> 256: 221 against 198,
-    // 512 -> 2048: 44.9 against 45.3.  What it removes (40 LDS instructions per wave and step) costs less than what it adds: every
-    // operand load and every store moves 64-byte pieces (four lanes x 16 bytes per pixel row) where the patch form moves whole
-    // 128-byte lines (eight lanes per row).  Opt-in (PPV_STREAM_DIRECT=1), parity-tested with the same cases.
-    static const int direct = getenv("PPV_STREAM_DIRECT") ? atoi(getenv("PPV_STREAM_DIRECT")) : 0;
     const kern_t kt = conv1x1_stream_kernel<KC, true, false, false, false>;
     static bool attr_set = false;
     if (!attr_set) {
         for (int i = 0; i < 8; ++i)
             (void)hipFuncSetAttribute((const void*)tab[i >> 2][(i >> 1) & 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        for (int i = 0; i < 4; ++i)
-            (void)hipFuncSetAttribute((const void*)tabd[i >> 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const unsigned grid = (unsigned)(tiles_m * n_splits);
-    const kern_t k = out_f32 ? kt : (addend && direct) ? tabd[red_x ? 1 : 0][mask_bits ? 1 : 0] : tab[red_x ? 1 : 0][addend ? 1 : 0][mask_bits ? 1 : 0];
+    const kern_t k = out_f32 ? kt : tab[red_x ? 1 : 0][addend ? 1 : 0][mask_bits ? 1 : 0];
     k<<<grid, ST_NT, lds, stream>>>(X, Wt, out, stat_part, addend, mask_bits, g, n_splits, nspan, stat_rows, red_x, red_coef);
     return ppv_last_error();
 }

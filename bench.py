@@ -409,6 +409,44 @@ def cpu_baseline(camera):
             "passes_s": [round(x, 3) for x in ts]}
 
 
+def side_config_legs(camera, encoder, batch, device):
+    """BASELINE.json configs 2, 3 and 4 measured in the SAME run as the headline (VERDICT r4 task 3: the driver's one command then carries
+    them): config 3 in-process on the headline's camera + encoder (10 timed steps with the caption decoder), configs 2 and 4 as child
+    processes of their own scripts (tools/bench_camera.py with its own cpu_baseline, tools/bench_fd.py), one at a time."""
+    import subprocess
+    out = {}
+    try:
+        from ppv_amd.decoder import DecoderWithAttention
+        torch.manual_seed(3)
+        decoder = DecoderWithAttention(attention_dim=512, embed_dim=512, decoder_dim=512, vocab_size=9490, dropout=0.3).to(device)
+        decoder.train()
+        step, _ = make_step(camera, encoder, batch, device, None, decoder, False, graph=False)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        out["3"] = {"metric": "images/sec fwd+bwd, Camera+ResNet-101+attention decoder @256^2, B=128, bf16 trunk / f32 decoder", "value": round(batch / dt, 1),
+                    "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": 10, "warmup": 3,
+                    "decoder_wgrad_path": os.environ.get("PPV_DEC_WGRAD", "default")}
+        del step, decoder
+    except Exception as e:  # noqa: BLE001
+        out["3"] = {"error": repr(e)[:300]}
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    for key, script in (("2", "bench_camera.py"), ("4", "bench_fd.py")):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, timeout=240)
+            rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[key] = json.loads(rows[-1]) if rows else {"error": (r.stderr or "no output")[-300:]}
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": repr(e)[:300]}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (one process per
     GPU, rendezvous on 127.0.0.1), relay its output (rank 0 prints the JSON line) and return its exit code.  Runs before anything in
@@ -449,6 +487,8 @@ def main():
                     help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
                          "default is the headline Camera+ResNet-101 metric")
     ap.add_argument("--ssim", action="store_true", help="camera_loss = 'SSIM' (fused SSIM kernels) instead of the default MSE")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side legs of the default run (BASELINE.json configs 2, 3, 4 under "
+                    "the line's \"configs\" key)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4],
                     help="BASELINE.json config: 0 = headline metric (default); 2 = camera alone (tools/bench_camera.py); 3 = same as "
                          "--decoder; 4 = FD camera + FAN + RAFT correlation (tools/bench_fd.py).  2 and 4 print their own JSON line.")
@@ -560,6 +600,9 @@ def main():
             os.environ.pop("PPV_BENCH_DENSE_HEAD", None)
 
     roof = None if args.no_roofline else roofline_of_dominant_kernel(eager_step)
+    side_configs = None
+    if world == 1 and not args.decoder and not args.ssim and not use_graph and not args.no_configs and not args.no_dense and args.batch == 128:
+        side_configs = side_config_legs(camera, encoder, args.batch, device)
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
         line = {
@@ -589,6 +632,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(camera)
+        if side_configs is not None:
+            line["configs"] = side_configs
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

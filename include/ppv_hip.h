@@ -143,6 +143,12 @@ int ppv_gemm_f32_tn(const float* a, long lda, const float* b, long ldb, float* o
                     void* workspace, ppv_stream_t stream);
 int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
                     int ksplit, void* workspace, ppv_stream_t stream);
+/* ppv_gemm_f32_tn's product a^T b (same contract) on the BF16 matrix pipe: the f32 operands are split in the kernel into bf16 hi + lo and
+ * a product is hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of sum |a b|; 5.3x the matrix rate of the exact-f32 form).  The
+ * default of the decoder's five batched weight gradients (replaces the autograd GEMMs of Image_Caption/models.py:199-214). */
+int ppv_gemm_bf16x3_tn_plan(int M, int N, int K, size_t* bytes);
+int ppv_gemm_bf16x3_tn(const float* a, long lda, const float* b, long ldb, float* out, long ldo, int M, int N, int K, int ksplit,
+                       void* workspace, ppv_stream_t stream);
 /* InstanceNorm2d / AdaIN (+ LeakyReLU) of the StarGAN-v2 blocks (Face-DeId/core/model.py:12-124), NHWC f32:
  * y = lrelu((x - mean_bc) * invstd_bc * scale + shift), statistics per (sample, channel) over HW, eps as given; scale / shift are
  * [C] (per_sample = 0: nn.InstanceNorm2d(affine=True)) or [B][C] (per_sample = 1: AdaIN's (1 + gamma), beta).  stats / sums:
@@ -403,6 +409,9 @@ int ppv_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c_ne
                       float* dc_prev, int bt, int D, ppv_stream_t stream);
 int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
                      int B, int P, int E, int T, ppv_stream_t stream);
+/* the compact (cell-map) form: out[order[b]][c][e] = part + gamma[c] * dmean[b][e] + sum_t beta[t][b][c] * dawe[t][b][e], bf16 or f32 out */
+int ppv_decc_enc_grad(const float* part, const float* dmean, const float* beta, const float* dawe, const long* order, const float* gamma,
+                      void* out, int out_bf16, int B, int C, int E, int T, ppv_stream_t stream);
 /* compact attention: the same step on the C cells of the map that AdaptiveAvgPool2d(36) (models.py:27,39) up-samples to the P
  * pixels -- class tables (cells / weight / multiplicity per distinct pixel class, class of every pixel) are built by the host */
 int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj, int ldh, const float* wfull, const int* cls_cells,

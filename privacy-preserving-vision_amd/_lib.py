@@ -68,6 +68,7 @@ PROTOTYPES = {
     "ppv_decc_attend_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_decc_attend_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_dec_enc_grad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_decc_enc_grad": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_corr_volume": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_alt_corr_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ppv_alt_corr_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
@@ -93,6 +94,8 @@ PROTOTYPES = {
     "ppv_gemm_f32_ws_plan": (_I, [_I, _I, _I, _P]),
     "ppv_gemm_f32_tn_plan": (_I, [_I, _I, _I, _P]),
     "ppv_gemm_f32_tn": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P]),
+    "ppv_gemm_bf16x3_tn_plan": (_I, [_I, _I, _I, _P]),
+    "ppv_gemm_bf16x3_tn": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P]),
     "ppv_gemm_f32_ws": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "ppv_conv_gemm_rect": (_I, [_P, _P, _P, _P] + [_I] * 10 + [_P]),
     "ppv_gru_zr": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P]),

@@ -210,14 +210,24 @@ _GEMM_WS = _os.environ.get("PPV_GEMM_WS", "1") != "0"
 _gemm_ws = {}
 
 
+_gemm_ws_pinned = []       # scratch blocks whose address a captured hipGraph has baked in: never handed back to the allocator
+
+
 def _gemm_scratch(device, nbytes):
-    """Slab scratch of linear_f32, one per (device, stream), grow-only: successive GEMMs of a stream reuse it in stream order."""
+    """Slab scratch of linear_f32, one per (device, stream), grow-only: successive GEMMs of a stream reuse it in stream order.
+    A block that was used while the stream was being captured stays alive for the life of the process (a replay writes its slabs
+    to that address): when a later call outgrows it, the old block is parked in `_gemm_ws_pinned` instead of being freed."""
     key = (device.index, _lib.stream_ptr().value)
-    t = _gemm_ws.get(key)
-    if t is None or t.numel() < nbytes:
-        t = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=device)
-        _gemm_ws[key] = t
-    return t
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = _gemm_ws.get(key)
+    if ent is None or ent[0].numel() < nbytes:
+        if ent is not None and ent[1]:
+            _gemm_ws_pinned.append(ent[0])
+        ent = [torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=device), False]
+        _gemm_ws[key] = ent
+    if capturing:
+        ent[1] = True
+    return ent[0]
 
 
 def linear_f32(x, w, bias=None, out=None):
@@ -257,9 +267,12 @@ def linear_f32(x, w, bias=None, out=None):
     return out
 
 
-def gemm_f32_tn(a, b, out=None):
-    """a^T b in exact f32 on the matrix pipe: a [K, M], b [K, N] f32 with unit column stride (rows may be strided) -> [M, N].  The
-    batched weight gradient g^T h of a dense layer without transposed copies (csrc/gemm_f32.hip ppv_gemm_f32_tn)."""
+def gemm_f32_tn(a, b, out=None, x3=False):
+    """a^T b on the matrix pipe: a [K, M], b [K, N] f32 with unit column stride (rows may be strided) -> [M, N].  The batched weight
+    gradient g^T h of a dense layer without transposed copies.  x3=False: exact f32 (csrc/gemm_f32.hip ppv_gemm_f32_tn); x3=True: three
+    bf16 products of operands split inside the kernel (ppv_gemm_bf16x3_tn: ~1e-5 of sum |a b|, 5.3x the matrix rate)."""
+    plan, run, name = ((L().ppv_gemm_bf16x3_tn_plan, L().ppv_gemm_bf16x3_tn, "ppv_gemm_bf16x3_tn") if x3 else
+                       (L().ppv_gemm_f32_tn_plan, L().ppv_gemm_f32_tn, "ppv_gemm_f32_tn"))
     K, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == K and a.dtype == F32 and b.dtype == F32 and a.stride(1) == 1 and b.stride(1) == 1
@@ -268,12 +281,11 @@ def gemm_f32_tn(a, b, out=None):
     else:
         assert tuple(out.shape) == (M, N) and out.stride(1) == 1 and out.dtype == F32
     nbytes = _lib.ctypes.c_size_t(0)
-    ks = L().ppv_gemm_f32_tn_plan(M, N, K, _lib.ctypes.byref(nbytes))
+    ks = plan(M, N, K, _lib.ctypes.byref(nbytes))
     if ks > 1 and (out.stride(0) % 4 or out.data_ptr() % 16):
         ks = 1
     ws = _gemm_scratch(a.device, nbytes.value) if ks > 1 else None
-    check(L().ppv_gemm_f32_tn(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ks, ptr(ws), stream_ptr()),
-          "ppv_gemm_f32_tn")
+    check(run(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), M, N, K, ks, ptr(ws), stream_ptr()), name)
     return out
 
 

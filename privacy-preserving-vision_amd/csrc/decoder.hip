@@ -350,13 +350,17 @@ __global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restric
         make_float4(a.x + m.x * invP, a.y + m.y * invP, a.z + m.z * invP, a.w + m.w * invP);
 }
 
-// out[order[b]][p][e] = part[b][p][e] + dmean[b][e] / P + sum_t alpha[t][b][p] * dawe[t][b][e]
+// out[order[b]][p][e] = part[b][p][e] + dmean[b][e] * (gamma ? gamma[p] : 1 / P) + sum_t alpha[t][b][p] * dawe[t][b][e]
 // (score path + init_h/init_c path + context path in ONE pass over the 4 * B * P * E bytes; un-sorts the batch).
 // grid (B, ceil(P / 48), E / 256); alpha [T][B][P], dawe [T][B][E]; LDS: [T][256] d awe + [T][48] alpha.
+// General path: P pixels, gamma null, f32 output.  Compact path (round 5: replaces baddbmm_ + add_ + cast + index_put of decoder.py):
+// the "pixels" are the C cells, alpha = beta [T][B][C], gamma [C] = each cell's share of the per-image mean, output in the cell map's
+// dtype (OUT_BF16: one rounding of the f32 sum).
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void dec_enc_grad_kernel(const float* __restrict__ part, const float* __restrict__ dmean,
                                                            const float* __restrict__ alpha, const float* __restrict__ dawe,
-                                                           const long* __restrict__ order, float* __restrict__ out, int B, int P,
-                                                           int E, int T) {
+                                                           const long* __restrict__ order, const float* __restrict__ gamma,
+                                                           void* __restrict__ out, int B, int P, int E, int T) {
     extern __shared__ float sm[];
     float* sD = sm;                  // [T][256]
     float* sA = sm + T * 256;        // [T][48]
@@ -370,17 +374,27 @@ __global__ __launch_bounds__(256) void dec_enc_grad_kernel(const float* __restri
     const int c4 = (tid & 63) * 4, pw = tid >> 6;
     const float invP = 1.f / (float)P;
     const float4 m = *reinterpret_cast<const float4*>(dmean + (long)b * E + c0 + c4);
-    float* dst = out + order[b] * (long)P * E;
+    const long obase = order[b] * (long)P * E;
     for (int j = pw; j < np; j += 4) {
         const long off = (long)(p0 + j) * E + c0 + c4;
+        const float gm = gamma ? gamma[p0 + j] : invP;
         float4 a = *reinterpret_cast<const float4*>(part + (long)b * P * E + off);
-        a.x += m.x * invP; a.y += m.y * invP; a.z += m.z * invP; a.w += m.w * invP;
+        a.x += m.x * gm; a.y += m.y * gm; a.z += m.z * gm; a.w += m.w * gm;
         for (int t = 0; t < T; ++t) {
             const float w = sA[t * 48 + j];
             const float4 d = *reinterpret_cast<const float4*>(sD + t * 256 + c4);
             a.x += w * d.x; a.y += w * d.y; a.z += w * d.z; a.w += w * d.w;
         }
-        *reinterpret_cast<float4*>(dst + off) = a;
+        if constexpr (OUT_BF16) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+            const f32x2_ lo = {a.x, a.y}, hi = {a.z, a.w};
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + obase + off) =
+                make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_)),
+                           __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_)));
+        } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + obase + off) = a;
+        }
     }
 }
 
@@ -641,18 +655,36 @@ int ppv_dec_combine(const float* acc, const float* dmean, const long* order, flo
 
 // d encoder_out in one pass (see dec_enc_grad_kernel).  part [B][P][E] f32 = score-path gradient (sorted order),
 // alpha [T][B][P], dawe [T][B][E] (rows of finished captions zero).  E % 256 == 0, T <= 128.
-int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
-                     int B, int P, int E, int T, hipStream_t stream) {
+static int dec_enc_grad_launch(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order,
+                               const float* gamma, void* out, int out_bf16, int B, int P, int E, int T, hipStream_t stream) {
     if (!part || !dmean || !alpha || !dawe || !order || !out) return PPV_ERR_NULL;
     if (B < 1 || P < 1 || E % 256 || T < 1 || T > 128) return PPV_ERR_BAD_SIZE;
     const size_t lds = (size_t)T * (256 + 48) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dec_enc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4);
+        (void)hipFuncSetAttribute((const void*)dec_enc_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4);
+        (void)hipFuncSetAttribute((const void*)dec_enc_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4);
         attr_set = true;
     }
-    dec_enc_grad_kernel<<<dim3(B, (P + 47) / 48, E / 256), 256, lds, stream>>>(part, dmean, alpha, dawe, order, out, B, P, E, T);
+    const dim3 grid(B, (P + 47) / 48, E / 256);
+    if (out_bf16) dec_enc_grad_kernel<true><<<grid, 256, lds, stream>>>(part, dmean, alpha, dawe, order, gamma, out, B, P, E, T);
+    else dec_enc_grad_kernel<false><<<grid, 256, lds, stream>>>(part, dmean, alpha, dawe, order, gamma, out, B, P, E, T);
     return ppv_last_error();
+}
+
+int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
+                     int B, int P, int E, int T, hipStream_t stream) {
+    return dec_enc_grad_launch(part, dmean, alpha, dawe, order, nullptr, out, 0, B, P, E, T, stream);
+}
+
+// The compact path's form: gradient with respect to the CELL map [B][C][E] (out_bf16: bf16, else f32), un-sorted:
+//   out[order[b]][c][e] = part[b][c][e] + gamma[c] * dmean[b][e] + sum_t beta[t][b][c] * dawe[t][b][e]
+// beta [T][B][C] = the per-cell attention weights of every step (rows of finished captions zero), gamma [C] = a cell's share of the
+// per-image mean of the pooled tensor.  E % 256 == 0, T <= 128.
+int ppv_decc_enc_grad(const float* part, const float* dmean, const float* beta, const float* dawe, const long* order, const float* gamma,
+                      void* out, int out_bf16, int B, int C, int E, int T, hipStream_t stream) {
+    if (!gamma) return PPV_ERR_NULL;
+    return dec_enc_grad_launch(part, dmean, beta, dawe, order, gamma, out, out_bf16, B, C, E, T, stream);
 }
 
 // Compact-attention step (see "compact attention" above) for the first bt sorted images.  att1c [B][C][A] bf16 (encoder_att of

@@ -306,6 +306,157 @@ __global__ __launch_bounds__(256) void gemm_f32_slab_sum_kernel(const float* __r
     *reinterpret_cast<float4*>(out + (long)m * ldo + n) = a;
 }
 
+
+// ----------------------------------------------------------------------------- bf16 x 3 form of the batched weight gradients (round 5)
+// out[m][n] = sum_k a[k][m] * b[k][n], both operands f32 and K-major as they lie in memory (ppv_gemm_f32_tn's contract), on the BF16
+// matrix pipe: every f32 operand is split IN THE KERNEL, on its way into LDS, into hi = bf16(v) and lo = bf16(v - hi), and a product
+// is taken as hi*hi + hi*lo + lo*hi with f32 accumulation (the dropped lo*lo term and lo's own rounding are ~2^-17 of the product:
+// the error of a sum is ~1e-5 of sum |a b|, two orders above exact f32 and two below the step's bf16 trunk).  Three
+// v_mfma_f32_16x16x32_bf16 do the work of eight v_mfma_f32_16x16x4_f32 at 1/16 of their cycles each: 5.3x the matrix rate of
+// gemm_f32_tiled_kernel<true, .>, with the same bytes read (the split costs no pass over memory).
+//   * workgroup = 128 (m) x 128 (n), four waves as 2 x 2, a wave owns 64 x 64 = 4 x 4 accumulator blocks; K chunk = 32;
+//   * staging: a thread loads float4s ALONG m / n (four columns of one k-row; a wave-instruction covers 4 k-rows x 256 contiguous
+//     bytes), splits them and writes 8 bytes of hi and 8 of lo into K-MAJOR images [32 k][128 columns] bf16 whose rows are padded to
+//     288 bytes (= 8 banks mod 64): the 16 lanes of a ds_write_b64 group (4 k-rows x 4 column quads) and the 32 lanes of a
+//     ds_read_b64_tr_b16 half (8 k-rows x 32 bytes) fall on distinct banks;
+//   * fragments by ds_read_b64_tr_b16 (the transposing read turns "4 k-rows x 16 columns" into "column i: 4 consecutive k" per lane):
+//     lane group g = lane >> 4 reads k-rows 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3, i.e. fragment element j sits at
+//     k = 16 (j >> 2) + 4 g + (j & 3) -- the same permutation of the chunk's 32 k for both operands, which is all an MFMA needs;
+//   * register-staged double buffer (the loads of chunk c + 1 fly under the MFMAs of chunk c), one barrier per chunk; split K through
+//     slabs summed in index order by gemm_f32_slab_sum_kernel (bit-reproducible, no atomics).
+typedef __attribute__((ext_vector_type(8))) __bf16 x3_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short x3_s16x4;
+typedef __attribute__((ext_vector_type(8))) short x3_s16x8;
+constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32, X3_ROWB = 288, X3_IMG = X3_BK * X3_ROWB;
+
+__device__ __forceinline__ void x3_split4(const float4 v, uint2& hi, uint2& lo) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ a = {v.x, v.y}, b = {v.z, v.w};
+    const bf16x2_ ha = __builtin_convertvector(a, bf16x2_), hb = __builtin_convertvector(b, bf16x2_);     // v_cvt_pk_bf16_f32: RNE
+    const f32x2_ ra = a - __builtin_convertvector(ha, f32x2_), rb = b - __builtin_convertvector(hb, f32x2_);   // exact in f32
+    const bf16x2_ la = __builtin_convertvector(ra, bf16x2_), lb = __builtin_convertvector(rb, bf16x2_);
+    hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+    lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_tn_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                                float* __restrict__ out, long ldo, int M, int N, int K, int ksplit,
+                                                                float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) char x3_smem[];      // [2 buffers][A hi | A lo | B hi | B lo] images
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * X3_BN, m0 = blockIdx.z * X3_BM, kslice = blockIdx.y;
+    const int chunks = (K + X3_BK - 1) / X3_BK;
+    const int cps = (chunks + ksplit - 1) / ksplit;
+    const int c_begin = kslice * cps, c_end = min(chunks, c_begin + cps);
+    // staging role: k-row 16 g + 4 i + tc of the chunk (i = 0..3), columns 4 u .. 4 u + 3
+    const int tc = tid & 3, u = (tid >> 2) & 31, sg = tid >> 7;
+    const bool va = lda % 4 == 0 && ((size_t)a % 16 == 0) && ((M + 3) / 4 * 4 <= lda);
+    const bool vb = ldb % 4 == 0 && ((size_t)b % 16 == 0) && ((N + 3) / 4 * 4 <= ldb);
+    auto ld4 = [&](const float* base, long ld_, int k, int c0, int C, bool vec) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && c0 < C) {
+            const float* p = base + (long)k * ld_ + c0;
+            if (vec) v = *reinterpret_cast<const float4*>(p);
+            else {
+                v.x = p[0];
+                if (c0 + 1 < C) v.y = p[1];
+                if (c0 + 2 < C) v.z = p[2];
+                if (c0 + 3 < C) v.w = p[3];
+            }
+        }
+        return v;
+    };
+    float4 ra[4], rb[4];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = ld4(a, lda, c * X3_BK + 16 * sg + 4 * i + tc, m0 + 4 * u, M, va);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = ld4(b, ldb, c * X3_BK + 16 * sg + 4 * i + tc, n0 + 4 * u, N, vb);
+    };
+    auto park = [&](int buf) {
+        char* base = x3_smem + buf * 4 * X3_IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (16 * sg + 4 * i + tc) * X3_ROWB + 8 * u;
+            uint2 hi, lo;
+            x3_split4(ra[i], hi, lo);
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            *reinterpret_cast<uint2*>(base + X3_IMG + off) = lo;
+            x3_split4(rb[i], hi, lo);
+            *reinterpret_cast<uint2*>(base + 2 * X3_IMG + off) = hi;
+            *reinterpret_cast<uint2*>(base + 3 * X3_IMG + off) = lo;
+        }
+    };
+    gf32x4 acc[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+    // fragment of column block cb of an image: two transposing reads (k-rows 4 fg + fq and 16 + 4 fg + fq, 8 bytes at column quad fp)
+    auto frag = [&](const char* img, int cb) {
+        const char* p0 = img + (4 * fg + fq) * X3_ROWB + cb * 32 + fp * 8;
+        const x3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4*)(p0));
+        const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4*)(p0 + 16 * X3_ROWB));
+        const x3_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(x3_bf16x8, v);
+    };
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        park(0);
+        __syncthreads();
+        int buf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            if (c + 1 < c_end) fetch(c + 1);
+            const char* base = x3_smem + buf * 4 * X3_IMG;
+            x3_bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = frag(base, wm * 4 + i);
+                bh[i] = frag(base + 2 * X3_IMG, wn * 4 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                al[i] = frag(base + X3_IMG, wm * 4 + i);
+                bl[i] = frag(base + 3 * X3_IMG, wn * 4 + i);
+            }
+            // the two small terms first, the large one last (one fewer rounding of the large partial sum against small addends)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+            if (c + 1 < c_end) park(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // C/D layout: acc[mb][nb][j] = out[m0 + wm * 64 + mb * 16 + fg * 4 + j][n0 + wn * 64 + nb * 16 + (lane & 15)]
+    float* dst = slab ? slab + (long)kslice * M * N : out;
+    const long ldd = slab ? N : ldo;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int n = n0 + wn * 64 + nb * 16 + (lane & 15);
+        if (n >= N) continue;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + wm * 64 + mb * 16 + fg * 4 + j;
+                if (m < M) dst[(long)m * ldd + n] = acc[mb][nb][j];
+            }
+    }
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -442,6 +593,44 @@ int ppv_gemm_f32_tn(const float* a, long lda, const float* b, long ldb, float* o
     if (!workspace) return PPV_ERR_NULL;
     if (N % 4 || ldo % 4 || ((size_t)out % 16)) return PPV_ERR_BAD_SIZE;
     launch_tiled<true>(nb, grid, stream, a, lda, b, ldb, nullptr, nullptr, 0, M, N, K, ksplit, 0, (float*)workspace);
+    const long n4 = (long)M * (N / 4);
+    gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, nullptr, out, ldo, M, N, ksplit);
+    return ppv_last_error();
+}
+
+// The same product a^T b (ppv_gemm_f32_tn's contract: a [K][M], b [K][N] f32, out [M][N] f32, any K / M / N) on the bf16 matrix pipe as
+// three products of in-kernel bf16 splits (gemm_bf16x3_tn_kernel above): ~1e-5 of sum |a b| instead of exact f32, 5.3x the matrix
+// rate.  The decoder's five batched weight gradients (Image_Caption/models.py:199-214 under autograd) run on it by default
+// (PPV_DEC_WGRAD=x3); ppv_gemm_f32_tn stays for exact f32.  ppv_gemm_bf16x3_tn_plan: split and workspace bytes (0: none).
+int ppv_gemm_bf16x3_tn_plan(int M, int N, int K, size_t* bytes) {
+    const long tiles = (long)((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
+    static const int target = getenv("PPV_GEMM_X3_WGS") ? atoi(getenv("PPV_GEMM_X3_WGS")) : 512;
+    const int chunks = (K + X3_BK - 1) / X3_BK;
+    int ks = 1;
+    if (N % 4 == 0)
+        while (ks < 16 && tiles * ks < target && chunks / (ks * 2) >= 3) ks *= 2;
+    if (bytes) *bytes = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    return ks;
+}
+
+int ppv_gemm_bf16x3_tn(const float* a, long lda, const float* b, long ldb, float* out, long ldo, int M, int N, int K, int ksplit,
+                       void* workspace, hipStream_t stream) {
+    if (!a || !b || !out) return PPV_ERR_NULL;
+    if (M < 1 || N < 1 || K < 1 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
+    constexpr int lds = 2 * 4 * X3_IMG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((N + X3_BN - 1) / X3_BN), (unsigned)ksplit, (unsigned)((M + X3_BM - 1) / X3_BM));
+    if (ksplit == 1) {
+        gemm_bf16x3_tn_kernel<<<grid, 256, lds, stream>>>(a, lda, b, ldb, out, ldo, M, N, K, 1, nullptr);
+        return ppv_last_error();
+    }
+    if (!workspace) return PPV_ERR_NULL;
+    if (N % 4 || ldo % 4 || ((size_t)out % 16)) return PPV_ERR_BAD_SIZE;
+    gemm_bf16x3_tn_kernel<<<grid, 256, lds, stream>>>(a, lda, b, ldb, nullptr, 0, M, N, K, ksplit, (float*)workspace);
     const long n4 = (long)M * (N / 4);
     gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, nullptr, out, ldo, M, N, ksplit);
     return ppv_last_error();

@@ -24,7 +24,9 @@ the same numbers; any other ``encoder_out`` takes the general path.
 
 Precision: BASELINE.json config 3 (bf16 storage, f32 accumulate) — att1 / encs are bf16; the LSTM state, softmax, all
 reductions and all small per-step GEMMs are f32.  The per-step dense GEMMs (h projections, LSTM gates, vocabulary
-scores) are plain library GEMMs (``torch.addmm`` -> rocBLAS); everything else is libppv_hip.  No CPU path.
+scores) run in exact f32 on the matrix pipe (``convops.linear_f32`` -> csrc/gemm_f32.hip), the batched weight gradients as
+in-kernel bf16 hi/lo splits (``ppv_gemm_bf16x3_tn``); a library GEMM only serves layers whose K is not a multiple of 16
+(toy sizes).  No CPU path.
 """
 import torch
 from torch import nn
@@ -70,7 +72,9 @@ class Attention(nn.Module):
             check(L().ppv_dec_prepare(ptr(enc), ptr(order), ptr(rows), ptr(mean), S, P, E, stream_ptr()), "ppv_dec_prepare")
             att = co.conv_fwd(rows, co.weight_layout(self.encoder_att.weight.detach().view(A, E, 1, 1), 0), 1, 0)
             hproj = torch.zeros((S, A + E), dtype=F32, device=dev)        # [att2 + both biases | gate pre-activation (unused: 0)]
-            hproj[:, :A] = torch.addmm(self.decoder_att.bias + self.encoder_att.bias, decoder_hidden.float(), self.decoder_att.weight.t())
+            # models.py:83-85: decoder_att(decoder_hidden), with encoder_att's bias moved to this side (exact f32 on the matrix pipe)
+            _linear(decoder_hidden.float().contiguous(), self.decoder_att.weight.detach().contiguous(),
+                    (self.decoder_att.bias + self.encoder_att.bias).detach(), hproj[:, :A], True)
             ebuf = torch.empty((S, P), dtype=F32, device=dev)
             alpha = torch.empty((S, P), dtype=F32, device=dev)
             awe = torch.empty((S, E), dtype=F32, device=dev)
@@ -165,7 +169,9 @@ def _tn(g, h, hip):
         check(L().ppv_split3_rows(ptr(h), h.stride(0), ptr(H3), m, K, Kp, 1, stream_ptr()), "ppv_split3_rows")
         return co.conv_wgrad(G3, H3, 1, 1, 1, 0).view(Np, Kp)[:N, :K]
     if g.stride(1) == 1 and h.stride(1) == 1 and g.dtype == F32 and h.dtype == F32:
-        return co.gemm_f32_tn(g, h)               # both operands as they lie in memory (round 4: no transposed copies)
+        # both operands as they lie in memory (no transposed copies): "x3" = bf16 hi/lo products split inside the kernel (round 5,
+        # the default), True = exact f32
+        return co.gemm_f32_tn(g, h, x3=(hip == "x3"))
     m = g.shape[0]
     mp = (m + 15) // 16 * 16
     gt = torch.zeros((g.shape[1], mp), dtype=F32, device=g.device)
@@ -278,13 +284,13 @@ class _DecoderFn(torch.autograd.Function):
         compact = tables is not None
         dev = rows.device
         hip_gemm = ctx.hip_gemm
-        # batched weight gradients (g^T h over all time steps): PPV_DEC_WGRAD=hip runs them on the exact-f32 MFMA kernel too (_tn);
-        # default library -- gemm_f32.hip is a weight-STREAM kernel (16 weight rows per workgroup against <= 128 x rows) and re-reads
-        # the row operand once per 16-column tile when both sides are thousands wide: config 3 measured 3771-3835 images/s with it
-        # against 3977-4121 with the library for these five products (round 3)
+        # batched weight gradients (g^T h over all time steps).  Default (round 5) PPV_DEC_WGRAD=x3: ppv_gemm_bf16x3_tn -- the f32 operands
+        # are split into bf16 hi + lo inside the kernel and each product runs as three bf16 MFMAs (~1e-5 of sum |a b|, 5.3x the matrix
+        # rate of the exact-f32 form).  =hip: exact f32 (ppv_gemm_f32_tn; 617 us for the five products against the library's 461 us,
+        # round 4), =split: stacked bf16 splits on the convolution weight-gradient kernel, =lib: rocBLAS (A/B only).
         import os as _os
-        _wg = _os.environ.get("PPV_DEC_WGRAD", "lib")
-        hip_wgrad = ("split" if _wg == "split" else _wg == "hip") if hip_gemm else False
+        _wg = _os.environ.get("PPV_DEC_WGRAD", "x3")
+        hip_wgrad = (_wg if _wg in ("split", "x3") else _wg == "hip") if hip_gemm else False
         # the vocabulary axis is padded to a multiple of 16 in PRIVATE buffers (9490 -> 9504: rows of the transposed layer become
         # 16-byte aligned and the reduction length a whole number of MFMA k-blocks); the pad columns are zeros
         Vp = (V + 15) // 16 * 16 if hip_gemm else V
@@ -352,10 +358,16 @@ class _DecoderFn(torch.autograd.Function):
             wl_d = co.weight_layout(w_enc.view(A, E, 1, 1), 1)
             acc = co.conv_dgrad(datt_bf, wl_d, 1, 0, (R, 1), out_f32=True).view(B, R, E)
             if compact:                                           # + beta^T . d awe + gamma (x) d mean, un-sorted, on the cell map
-                acc.baddbmm_(BETA.permute(1, 2, 0), DAW.transpose(0, 1))
-                acc.add_(tables["gamma"].view(1, R, 1) * dmean.view(B, 1, E))
                 g_src = torch.empty(ctx.src_shape, dtype=ctx.src_dtype, device=dev)
-                g_src[order] = acc.view((B,) + tuple(ctx.src_shape[1:])).to(ctx.src_dtype)
+                if E % 256 == 0 and T <= 128 and ctx.src_dtype in (BF16, F32):
+                    # one pass (csrc/decoder.hip dec_enc_grad_kernel, cell form): the batched product, both addends, the cast and the
+                    # un-sort -- was baddbmm_ (a library GEMM) + add_ + to() + index_put
+                    check(lib.ppv_decc_enc_grad(ptr(acc), ptr(dmean), ptr(BETA), ptr(DAW), ptr(order), ptr(tables["gamma"]), ptr(g_src),
+                                                int(ctx.src_dtype == BF16), B, R, E, T, stream_ptr()), "ppv_decc_enc_grad")
+                else:
+                    acc.baddbmm_(BETA.permute(1, 2, 0), DAW.transpose(0, 1))
+                    acc.add_(tables["gamma"].view(1, R, 1) * dmean.view(B, 1, E))
+                    g_src[order] = acc.view((B,) + tuple(ctx.src_shape[1:])).to(ctx.src_dtype)
             else:
                 g_src = torch.empty((B, R, E), dtype=F32, device=dev)
                 if E % 256 == 0 and T <= 128:                     # one pass: + alpha^T . d awe + d mean / P, un-sorted

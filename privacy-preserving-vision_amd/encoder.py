@@ -466,6 +466,10 @@ class _TrunkFn(torch.autograd.Function):
             torch._foreach_add_(enc._nbt, 1)
         ctx.enc, ctx.saved, ctx.blocks, ctx.train, ctx.tok = enc, saved, blocks, train, tok
         ctx.holder, ctx.cells = holder, (x if holder is not None else None)
+        if holder is not None and getattr(enc, "_debug_block_grads", None) is not None:
+            stem_ = []                                                                              # tests: what the per-kernel path would have kept
+            ctx.blocks = [t for t, _ in _tx.block_taps(holder.lease.plan, holder.lease, x, stem_)]
+            ctx.saved = {"stem": stem_[0]}
         ctx.img_shape, ctx.last_hw = images.shape, (x.shape[1], x.shape[2])
         ctx.set_materialize_grads(False)
         # second output: the map the pool up-sampled (a view of the last block's output, so that returning it does not
@@ -949,10 +953,10 @@ class Encoder(nn.Module):
         wl.refresh()
 
     def invalidate_weight_cache(self):
-        self.__dict__["_wcache_gen"] = self.__dict__.get("_wcache_gen", 0) + 1      # the plan executor's pointer tables follow
         """Drop the cached bf16 layouts of the FROZEN convolutions (stem, layer1, everything under fine_tune(False)).  They are
         keyed on the parameter's version counter and storage pointer, which in-place writes through ``p.data`` (EMA, weight
         surgery) do not change; train() / eval() / load_state_dict() call this, call it yourself after such a write."""
+        self.__dict__["_wcache_gen"] = self.__dict__.get("_wcache_gen", 0) + 1      # the plan executor's pointer tables follow
         self._stem.invalidate()
         for blk in self._blocks:
             for r in blk:

@@ -15,6 +15,7 @@ unless a gradient is already there (micro-batching, ``zero_grad(set_to_none=Fals
 accumulates.  Data-parallel runs (``dist_sync.GradSync``) keep setting ``param.grad`` to the bucket slices themselves."""
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -22,12 +23,26 @@ from . import _lib
 from . import convops as co
 
 BF16, F32 = torch.bfloat16, torch.float32
+_UNSUPPORTED = object()                    # marks a geometry in Encoder._plans that TrunkPlan refused
+
+
+class _DictRef:
+    """A dict cannot be weakly referenced; the plan only needs to ask its table "am I still current?" and must not keep it alive."""
+    __slots__ = ("_d",)
+
+    def __init__(self, d):
+        self._d = d
+
+    def __call__(self):
+        return self._d
+
+
 _NF = len(_lib.TRUNK_CONV_FIELDS)          # pointers per convolution record
 _WT, _WD, _GAMMA, _BETA, _RM, _RV, _DW, _DG, _DB = range(_NF)
 
 
 class _Lease:
-    __slots__ = ("arena", "gflat", "table", "hyper", "ptr_key", "grad_items", "free_event", "plan", "gen", "__weakref__")
+    __slots__ = ("arena", "gflat", "table", "hyper", "ptr_key", "grad_items", "free_event", "plan", "gen", "handed", "__weakref__")
 
 
 class _LeaseHolder:
@@ -53,7 +68,10 @@ class _LeaseHolder:
                 lease.free_event = ev
             except Exception:                         # interpreter shutdown
                 lease.free_event = None
-            lease.plan.free.append(lease)
+            plan = lease.plan
+            if plan.owner is not None and plan.owner().get(plan.key) is not plan:
+                return                    # the plan has been replaced (other requires_grad pattern / parameter list): its arena is not pooled
+            plan.free.append(lease)
 
     def retake(self):
         """For a repeated backward: the lease again, if nothing has overwritten what forward kept."""
@@ -120,6 +138,7 @@ class TrunkPlan:
         self.stem_trainable = any(p.requires_grad for p in (enc._stem.conv.weight, enc._stem.bn.weight, enc._stem.bn.bias))
         self.free = []
         self.rg_key = rg_key
+        self.key, self.owner = None, None
 
     # ------------------------------------------------------------------ leases
     def acquire(self, dev):
@@ -142,6 +161,7 @@ class TrunkPlan:
         lease.hyper = (ctypes.c_float * (2 * n))()
         lease.ptr_key = None
         lease.free_event = None
+        lease.handed = ()                  # weak references to the views of gflat the last backward gave to autograd
         base = lease.gflat.data_ptr()
         lease.grad_items = [(sl[2], None) for sl in self.slots]
         for i, field, p, off, numel in self.slots:
@@ -166,8 +186,12 @@ class TrunkPlan:
                        if r is not None and not r.conv.weight.requires_grad)
         wl = getattr(enc, "_wl", None)
         frozen = (enc.__dict__.get("_wcache_gen", 0),) + frozen          # invalidate_weight_cache() drops the cached layouts themselves
+        # the BatchNorm storages themselves (bn.running_mean = t, p.data = t, a parent's load_state_dict(assign=True) replace them
+        # without touching the parameter list): ~400 integer compares per step against kernels writing through a stale pointer
+        bnp = tuple(t.data_ptr() if t is not None else 0 for r in self.recs if r is not None
+                    for t in (r.bn.weight, r.bn.bias, r.bn.running_mean, r.bn.running_var))
         k = lease.ptr_key
-        if k is not None and k[0] is plist and k[1] is wl and k[2] == frozen:
+        if k is not None and k[0] is plist and k[1] is wl and k[2] == frozen and k[3] == bnp:
             return
         t, hy = lease.table, lease.hyper
         for i, r in enumerate(self.recs):
@@ -180,7 +204,7 @@ class TrunkPlan:
             t[b + _RM] = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
             t[b + _RV] = bn.running_var.data_ptr() if bn.running_var is not None else 0
             hy[2 * i], hy[2 * i + 1] = bn.momentum, bn.eps
-        lease.ptr_key = (plist, wl, frozen)
+        lease.ptr_key = (plist, wl, frozen, bnp)
 
 
 def usable(enc, train):
@@ -194,13 +218,15 @@ def usable(enc, train):
         return False
     if env("PPV_STEM_BWD_FUSED", "1") == "0":
         return False
-    if co.PROFILE is not None or getattr(enc, "_debug_block_grads", None) is not None:
+    if co.PROFILE is not None:
         return False
     if enc._stem.conv.weight.requires_grad or (enc.grad_sync is not None and enc._stem.bn.weight.requires_grad):
         return False
     for r in [enc._stem] + [r for blk in enc._blocks for r in blk if r is not None]:
         if not r.bn.training or r.bn.momentum is None or not r.bn.affine:
             return False
+    if len(enc._blocks) > _lib.TRUNK_MAX_BLOCKS:           # deeper than the executor's descriptor: the per-kernel path serves it
+        return False
     return True
 
 
@@ -213,13 +239,63 @@ def get_plan(enc, B, H, W, plist):
     key = (B, H, W, fold_rows, reduce3)
     plans = enc.__dict__.setdefault("_plans", {})
     plan = plans.get(key)
+    if plan is _UNSUPPORTED:
+        return None
     if plan is None or plan.rg_key != rg or plan.plist is not plist:
         for other in plans.values():         # a new geometry: idle arenas of the others (19.6 GB each at B = 128) go back to the allocator
-            other.free.clear()
-        plan = TrunkPlan(enc, B, H, W, fold_rows, reduce3, rg)
+            if other is not _UNSUPPORTED:
+                other.free.clear()
+        if plans.get(key) is _UNSUPPORTED:
+            return None
+        try:
+            plan = TrunkPlan(enc, B, H, W, fold_rows, reduce3, rg)
+        except ValueError:                # a geometry the executor's layout refuses: remembered, the per-kernel path runs instead
+            plans[key] = _UNSUPPORTED
+            return None
         plan.plist = plist                # the list object itself (Encoder._param_list rebuilds it when Parameter objects are replaced)
+        plan.key, plan.owner = key, _DictRef(plans)
         plans[key] = plan
     return plan
+
+
+class _BlockTap(tuple):
+    """What the tests' stage-wise checks read of a block the per-kernel path would have saved: [0] block input, [11] block output,
+    [12] sign mask of the block input (None for the first block) -- views of the arena, valid until the next forward on it."""
+
+
+def block_taps(plan, lease, cells, stem=None):
+    """Per-block views into the arena (tests only; Encoder._debug_block_grads): [( xin, ..., yout, xin_bits )] in block order."""
+    L = _lib.lib()
+    d, B = plan.desc, plan.desc.B
+    off = (ctypes.c_size_t * 20)()
+    _lib.check(L.ppv_trunk_block_offsets(ctypes.byref(d), -1, off), "ppv_trunk_block_offsets")
+    arena = lease.arena
+
+    def view(o, shape, dt=BF16):
+        n = 1
+        for k in shape:
+            n *= k
+        return arena[o:o + n * (2 if dt == BF16 else 1)].view(dt).view(shape)
+
+    h, w, cin = d.H // 4, d.W // 4, 64
+    x = view(off[2], (B, h, w, 64))
+    if stem is not None:                   # (raw conv output, BatchNorm coefficients, pooled activation, arg-max) as the per-kernel path keeps them
+        stem.append((view(off[0], (B, d.H // 2, d.W // 2, 64)), arena[off[1]:off[1] + 4 * 64 * 4].view(F32).view(4, 64), x,
+                     view(off[3], (B, h, w, 64), torch.uint8)))
+    bits = None
+    out = []
+    for i in range(plan.nblocks):
+        k = d.blk[i]
+        _lib.check(L.ppv_trunk_block_offsets(ctypes.byref(d), i, off), "ppv_trunk_block_offsets")
+        h2, w2, c3 = h // k.stride, w // k.stride, 4 * k.planes
+        yout = cells if i == plan.nblocks - 1 else view(off[6], (B, h2, w2, c3))
+        gin = view(off[19], (B, h, w, cin))
+        rec = [None] * 13
+        rec[0], rec[11], rec[12] = x, yout, bits
+        out.append((_BlockTap(rec), gin))
+        x, bits = yout, view(off[7], (B * h2 * w2 * c3 // 8,), torch.uint8)
+        h, w, cin = h2, w2, c3
+    return out
 
 
 def forward(enc, images, tok, plist):
@@ -227,6 +303,8 @@ def forward(enc, images, tok, plist):
     B, _, H, W = images.shape
     dev = images.device
     plan = get_plan(enc, B, H, W, plist)
+    if plan is None:
+        return None, None                  # the executor does not serve this geometry: the caller takes the per-kernel path
     lease = plan.acquire(dev)
     plan.fill_pointers(enc, lease, tok, plist)
     cells = torch.empty((B, plan.hw_last[0], plan.hw_last[1], plan.c_last), dtype=BF16, device=dev)
@@ -293,7 +371,11 @@ def backward(enc, holder, cells, g_out, g_cells, needs_img, img_shape, side, mai
         holder.release()
         return g_img, None
     flat = lease.gflat
-    if not fresh or sync is not None:
+    # views of gflat handed out by an earlier backward that somebody still holds and that are NOT the parameters' current .grad (those
+    # make `fresh` false): two torch.autograd.grad calls over the parameters, gradients saved before zero_grad(set_to_none=True), ...
+    # Writing gflat again would silently replace their contents (plain autograd returns independent tensors): temporary buffer then.
+    aliased = any(w() is not None for w in lease.handed)
+    if not fresh or sync is not None or aliased:
         # gradients already sit in .grad (micro-batching, zero_grad(set_to_none=False)) -- possibly views of this very buffer from the
         # last step: a temporary flat buffer, whose slices autograd adds to what is there
         flat = keep = torch.empty(plan.grad_elems, dtype=F32, device=dev)
@@ -309,10 +391,21 @@ def backward(enc, holder, cells, g_out, g_cells, needs_img, img_shape, side, mai
                                g_img.data_ptr() if g_img is not None else None, zp, 0, plan.nblocks, main, side_ptr), "ppv_trunk_bwd")
     if hop:
         _lib.check(L.ppv_stream_fork(main, cur_ptr), "ppv_stream_fork")
+    taps = getattr(enc, "_debug_block_grads", None)          # tests: per-block (g_out, g_in), last block first -- as the per-kernel path
+    if taps is not None:
+        bt = block_taps(plan, lease, cells)
+        off = (ctypes.c_size_t * 20)()
+        _lib.check(L.ppv_trunk_block_offsets(ctypes.byref(plan.desc), -1, off), "ppv_trunk_block_offsets")
+        n_top = cells.numel() * 2
+        g_last = g_top if kind == 0 else lease.arena[off[5]:off[5] + n_top].view(BF16).view(cells.shape)
+        for i in range(plan.nblocks - 1, -1, -1):
+            taps.append((g_last if i == plan.nblocks - 1 else bt[i + 1][1], bt[i][1]))
     if keep is not None and sync is not None:
         sync.reduce_now([keep])            # accumulation mode of a data-parallel run: averaged in stream order, then handed to autograd
     # Single-process runs hand the slices to AUTOGRAD (hooks on the parameters fire, torch.autograd.grad leaves .grad alone, accumulation
     # is autograd's): param.grad ends up a view of the lease's flat buffer, which the next backward overwrites.
     grads = plan.grad_views(flat)
+    if keep is None:
+        lease.handed = tuple(weakref.ref(t) for t in grads.values())
     holder.release()
     return g_img, grads

@@ -459,6 +459,111 @@ def test_trunk_plan_equals_the_per_kernel_path(layers, B, H, dense, one_adder_st
             assert _cos(a, b) > 0.999 and abs(float(a.norm() / b.norm()) - 1) < 2e-2
 
 
+def test_trunk_plan_at_the_benchmark_geometry_equals_the_per_kernel_path(monkeypatch):
+    """The shipped default (plan executor, 19.6-GB arena) at the shipped size -- ResNet-101, B = 128, 256 x 256: 4
+    distinct images x 32 copies through ppv_trunk_fwd / ppv_trunk_bwd against the per-kernel enqueue of the same launches.  At this
+    size every BatchNorm statistic has several f32 adders per address in either path (row tiles > partial rows), so two runs of ONE
+    path already differ in the last bit of a statistic, and a random-init train-mode ResNet-101 amplifies one flipped bf16 rounding
+    to O(1) over its 33 blocks (measured: rel. difference 0.87 between two such runs).  The residual branches are therefore damped
+    (bn3.weight = 0.05, as zero-init-residual training starts): the same launches, tiles, arena offsets and split counts run, but a
+    last-bit difference stays a last-bit difference -- the cell map is compared to bf16 rounding (bit-equal on almost every
+    element), gradients by cosine."""
+    from ppv_amd.encoder import Encoder
+    from ppv_amd import trunk_exec
+    torch.manual_seed(0)
+    enc = Encoder(layers=(3, 4, 23, 3)).cuda().train()
+    with torch.no_grad():
+        for li in range(4, 8):
+            for blk in enc.resnet[li]:
+                blk.bn3.weight.fill_(0.05)
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    img = torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(5)).repeat(32, 1, 1, 1).cuda()
+    assert trunk_exec.usable(enc, True)
+    plan = _run_trunk(enc, sd, img, True)
+    plans = enc.__dict__.get("_plans")
+    assert plans and any(k[0] == 128 and k[1] == 256 for k in plans), "the plan executor did not run at B = 128"
+    for pl in plans.values():
+        pl.free.clear()                                           # hand the 19.6-GB arena back before the per-kernel path allocates its own
+    monkeypatch.setenv("PPV_TRUNK_PLAN", "0")
+    monkeypatch.setenv("PPV_BLOCK_EXEC", "0")
+    per_kernel = _run_trunk(enc, sd, img, True)
+    a, b = plan[0].float(), per_kernel[0].float()
+    assert rel_err(a, b) < 2e-2
+    assert float((a == b).float().mean()) > 0.9
+    assert rel_err(a[4:8], a[:4]) < 2e-2                          # the copies went through other tiles of the same launches
+    for x, y in zip(plan[3], per_kernel[3]):
+        assert rel_err(x, y) < 1e-4
+    assert _cos(plan[1], per_kernel[1]) > 0.999
+    assert len(plan[2]) == len(per_kernel[2]) > 0
+    for x, y in zip(plan[2], per_kernel[2]):
+        assert _cos(x, y) > 0.999 and abs(float(x.norm() / y.norm()) - 1) < 2e-2
+
+
+def test_two_autograd_grad_calls_over_the_parameters_return_independent_tensors():
+    """r4 advisor: the plan executor hands autograd views of ONE persistent flat buffer; a second ``torch.autograd.grad`` over the
+    parameters (per-task gradients, gradient penalties) or gradients kept across ``zero_grad(set_to_none=True)`` must not be
+    overwritten by the next backward -- plain autograd returns independent tensors."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    tr = [p for p in enc.parameters() if p.requires_grad]
+    cells = enc(img)._ppv_cells.float()
+    l1, l2 = cells.square().mean(), cells.abs().mean()
+    g1 = torch.autograd.grad(l1, tr, retain_graph=True)
+    snap = [g.clone() for g in g1]
+    g2 = torch.autograd.grad(l2, tr)
+    assert all(torch.equal(a, b) for a, b in zip(g1, snap)), "the second autograd.grad call overwrote the first call's result"
+    assert any(not torch.equal(a, b) for a, b in zip(g1, g2))
+    assert all(a.data_ptr() != b.data_ptr() for a, b in zip(g1, g2))
+    # gradients kept across zero_grad(set_to_none=True)
+    enc(img)._ppv_cells.float().square().mean().backward()
+    kept = [p.grad for p in tr]
+    snap = [g.clone() for g in kept]
+    enc.zero_grad(set_to_none=True)
+    (3.0 * enc(img)._ppv_cells.float().square().mean()).backward()
+    assert all(torch.equal(a, b) for a, b in zip(kept, snap)), "a kept gradient was overwritten by the next step"
+    assert all(p.grad is not None and p.grad.data_ptr() != k.data_ptr() for p, k in zip(tr, kept))
+    # and the zero-copy hand-out is back once nobody holds the old views
+    del kept, g1, g2
+    enc.zero_grad(set_to_none=True)
+    enc(img)._ppv_cells.float().square().mean().backward()
+    flat = next(iter(enc._plans.values())).free[-1].gflat if next(iter(enc._plans.values())).free else None
+    if flat is not None:
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi for p in tr)
+
+
+def test_trunk_deeper_than_the_plan_executor_falls_back_to_the_per_kernel_path():
+    """r4 advisor: a trunk the executor's descriptor cannot hold (more than 64 bottlenecks) trains through the per-kernel path
+    instead of raising."""
+    from ppv_amd.encoder import Encoder
+    from ppv_amd import trunk_exec
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 62, 2)).cuda().train()
+    assert not trunk_exec.usable(enc, True)
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
+    enc(img)._ppv_cells.float().square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in enc.parameters() if p.requires_grad)
+
+
+def test_replaced_batchnorm_buffer_is_seen_by_the_plan_executor(one_adder_stats):
+    """r4 advisor: ``bn.running_mean = t`` replaces a buffer's storage without touching the parameter list; the executor's cached
+    pointer table must follow (the kernels would otherwise update freed memory and the new buffer would stay untouched)."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        enc(img)
+    bn = enc.resnet[4][0].bn1
+    fresh = torch.zeros_like(bn.running_mean)
+    bn.running_mean = fresh
+    with torch.no_grad():
+        enc(img)
+    assert float(bn.running_mean.abs().max()) > 0, "the new running_mean buffer was not updated"
+
+
 def test_trunk_plan_gradient_ownership(one_adder_stats):
     """The plan executor hands autograd fresh views of its flat gradient buffer (adopted as ``param.grad`` without a copy when no gradient
     is there, accumulated into when one is: micro-batching), serves a second backward with retain_graph, refuses one whose arena a later

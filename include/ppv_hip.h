@@ -409,6 +409,8 @@ int ppv_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c_ne
                       float* dc_prev, int bt, int D, ppv_stream_t stream);
 int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
                      int B, int P, int E, int T, ppv_stream_t stream);
+/* per-image mean of the pooled tensor taken on the cell map: mean[b][e] = sum_c gamma[c] * cells[b][c][e] (cells bf16, models.py:143-145) */
+int ppv_decc_mean(const void* cells, const float* gamma, float* mean, int B, int C, int E, ppv_stream_t stream);
 /* the compact (cell-map) form: out[order[b]][c][e] = part + gamma[c] * dmean[b][e] + sum_t beta[t][b][c] * dawe[t][b][e], bf16 or f32 out */
 int ppv_decc_enc_grad(const float* part, const float* dmean, const float* beta, const float* dawe, const long* order, const float* gamma,
                       void* out, int out_bf16, int B, int C, int E, int T, ppv_stream_t stream);

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "ppv_decc_attend_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_dec_enc_grad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_decc_enc_grad": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_decc_mean": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_corr_volume": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_alt_corr_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ppv_alt_corr_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),

@@ -398,6 +398,31 @@ __global__ __launch_bounds__(256) void dec_enc_grad_kernel(const float* __restri
     }
 }
 
+// mean[b][e] = sum_c gamma[c] * cells[b][c][e]: the per-image mean of the pooled [P, E] tensor (models.py:143-145) taken on the C cells it
+// was pooled from (gamma[c] = the share of cell c in that mean).  cells bf16 [B][C][E], one thread per 8 channels.  (Was
+// torch.einsum("c,bce->be") on an f32 copy of the cells: a library bmm + a 33-MB conversion.)
+__global__ __launch_bounds__(256) void decc_mean_kernel(const bf16_t* __restrict__ cells, const float* __restrict__ gamma,
+                                                        float* __restrict__ mean, int B, int C, int E) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int e8 = E / 8;
+    if (i >= (long)B * e8) return;
+    const int b = (int)(i / e8), e = (int)(i % e8) * 8;
+    const bf16_t* p = cells + (long)b * C * E + e;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + (long)c * E);
+        const float g = gamma[c];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[2 * k] += g * __builtin_bit_cast(float, w[k] << 16);
+            a[2 * k + 1] += g * __builtin_bit_cast(float, w[k] & 0xffff0000u);
+        }
+    }
+    *reinterpret_cast<float4*>(mean + (long)b * E + e) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(mean + (long)b * E + e + 4) = make_float4(a[4], a[5], a[6], a[7]);
+}
+
 // ============================================================================= compact attention (pooled-map structure)
 // The Encoder's output is AdaptiveAvgPool2d(36) of an 8 x 8 map (models.py:27,39): every one of the P = 1296 "pixels" is the
 // mean of 1, 2 or 4 of the C = 64 cells, and only Q = 225 distinct (cell set) classes exist.  encoder_att, the mean and the
@@ -675,6 +700,15 @@ static int dec_enc_grad_launch(const float* part, const float* dmean, const floa
 int ppv_dec_enc_grad(const float* part, const float* dmean, const float* alpha, const float* dawe, const long* order, float* out,
                      int B, int P, int E, int T, hipStream_t stream) {
     return dec_enc_grad_launch(part, dmean, alpha, dawe, order, nullptr, out, 0, B, P, E, T, stream);
+}
+
+// mean[b][e] = sum_c gamma[c] * cells[b][c][e] (cells bf16 [B][C][E], mean f32 [B][E]); E % 8 == 0.
+int ppv_decc_mean(const void* cells, const float* gamma, float* mean, int B, int C, int E, hipStream_t stream) {
+    if (!cells || !gamma || !mean) return PPV_ERR_NULL;
+    if (B < 1 || C < 1 || E < 8 || E % 8) return PPV_ERR_BAD_SIZE;
+    const long n = (long)B * (E / 8);
+    decc_mean_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const bf16_t*)cells, gamma, mean, B, C, E);
+    return ppv_last_error();
 }
 
 // The compact path's form: gradient with respect to the CELL map [B][C][E] (out_bf16: bf16, else f32), un-sorted:

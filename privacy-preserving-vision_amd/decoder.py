@@ -204,7 +204,11 @@ class _DecoderFn(torch.autograd.Function):
         if compact:
             R = src.shape[1] * src.shape[2]
             rows = src.detach()[order].reshape(B, R, 1, E).contiguous()        # cells in sorted batch order, bf16
-            mean = torch.einsum("c,bce->be", tables["gamma"], rows.view(B, R, E).float())
+            if rows.dtype == BF16 and E % 8 == 0:
+                mean = torch.empty((B, E), dtype=F32, device=dev)
+                check(L().ppv_decc_mean(ptr(rows), ptr(tables["gamma"]), ptr(mean), B, R, E, stream_ptr()), "ppv_decc_mean")
+            else:
+                mean = torch.einsum("c,bce->be", tables["gamma"], rows.view(B, R, E).float())
         else:
             R = P
             rows = torch.empty((B, R, 1, E), dtype=BF16, device=dev)

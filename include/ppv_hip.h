@@ -52,6 +52,17 @@ int ppv_group_max(const float* partial, float* out, int groups, int per_group, p
 int ppv_div_by_group(float* x, const float* m, long per_group, int groups, ppv_stream_t stream);
 
 /* backward of the IC sensor image: Lens.py:290,312 + Utils.py:251-297 */
+/* The IC sensor convolution for ANY even patch size P <= 512 (Lens.py:21-22: the constructor's default is 368) on an N-point transform,
+ * N = 256 / 512 / 1024 >= 2 P: the P x P supports make every N >= 2 P - 1 compute the reference's 2 P-point result (Utils.py:251-297).
+ * signs [B * C][P][N / 128] 64-bit words, partial_max ppv_fftconv_ic_partials(B, C, P) floats, u8: uint8 pixels decoded as x / 255. */
+int ppv_fftconv_ic_partials(int B, int C, int P);
+size_t ppv_fftconv_ic_workspace_bytes(int B, int C, int P, int N);
+int ppv_fftconv_ic_fwd_p(const void* img, int u8, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
+                         int B, int C, int P, int N, ppv_stream_t stream);
+size_t ppv_fftconv_ic_bwd_workspace_bytes_p(int B, int C, int P, int N);
+int ppv_fftconv_ic_bwd_p(const void* img, int u8, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
+                         const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64, long sc, long sy, long sx,
+                         float* g_img, void* workspace, int B, int C, int P, int N, ppv_stream_t stream);
 size_t ppv_fftconv_bwd_workspace_bytes(int B, int C, int N);
 int ppv_sensor_dot_count(const float* g, const float* sensor, double* dotcnt, long n, ppv_stream_t stream);
 int ppv_fftconv_ic_bwd(const float* img, const float* g_sensor, const float* sensor, const void* signs,

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -29,6 +29,11 @@ PROTOTYPES = {
     "ppv_group_max": (_I, [_P, _P, _I, _I, _P]),
     "ppv_div_by_group": (_I, [_P, _P, _L, _I, _P]),
     "ppv_fftconv_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
+    "ppv_fftconv_ic_partials": (_I, [_I, _I, _I]),
+    "ppv_fftconv_ic_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "ppv_fftconv_ic_fwd_p": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_fftconv_ic_bwd_workspace_bytes_p": (_Z, [_I, _I, _I, _I]),
+    "ppv_fftconv_ic_bwd_p": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_sensor_dot_count": (_I, [_P, _P, _P, _L, _P]),
     "ppv_fftconv_ic_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _P]),
     "ppv_fftconv_ic_bwd_u8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _P]),

@@ -78,10 +78,10 @@ class _IcSensorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, psf, cam):
         B, C, P, _ = img.shape
-        N = 2 * P
+        N = fc.ic_transform_length(P)          # 2 P for the 128 / 256 patches, the next of 256 / 512 / 1024 otherwise (same convolution)
         img = img.contiguous()
         otf = fc.otf_build(psf.detach()[0].permute(2, 0, 1), P, N)
-        out, signs, partial = fc.fftconv_fwd(img, otf, mode=0)
+        out, signs, partial = fc.fftconv_ic_fwd(img, otf, N)
         m = fc.group_max(partial, 1)
         if cam.global_max_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
@@ -95,7 +95,7 @@ class _IcSensorFn(torch.autograd.Function):
         img, sensor, signs, m, otf = ctx.saved_tensors
         L = _lib.lib()
         B, C, P, _ = img.shape
-        N = 2 * P
+        N = fc.ic_transform_length(P)
         dev = img.device
         g = g.contiguous()
         dotcnt = torch.empty(2, dtype=torch.float64, device=dev)
@@ -106,34 +106,12 @@ class _IcSensorFn(torch.autograd.Function):
         dtype, shape = ctx.psf_meta
         g_psf = torch.empty(shape, dtype=dtype, device=dev) if need_psf else None
         g_img = torch.empty_like(img) if need_img else None
-        ws = torch.empty(L.ppv_fftconv_bwd_workspace_bytes(B, C, N), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.ppv_fftconv_ic_bwd_workspace_bytes_p(B, C, P, N), dtype=torch.uint8, device=dev)
         sc, sy, sx = (1, P * 3, 3)       # [1,P,P,3] viewed as [C][P][P]
-        bwd = L.ppv_fftconv_ic_bwd_u8 if img.dtype == torch.uint8 else L.ppv_fftconv_ic_bwd     # uint8 pixels: no image gradient
-        check(bwd(ptr(img), ptr(g), ptr(sensor), ptr(signs), ptr(m), ptr(dotcnt), ptr(otf),
-                  ptr(g_psf), int(dtype == torch.float64), sc, sy, sx, ptr(g_img), ptr(ws),
-                  B, C, N, stream_ptr()), "ppv_fftconv_ic_bwd")
+        check(L.ppv_fftconv_ic_bwd_p(ptr(img), int(img.dtype == torch.uint8), ptr(g), ptr(sensor), ptr(signs), ptr(m), ptr(dotcnt), ptr(otf),
+                                     ptr(g_psf), int(dtype == torch.float64), sc, sy, sx, ptr(g_img), ptr(ws),       # uint8 pixels: no image gradient
+                                     B, C, P, N, stream_ptr()), "ppv_fftconv_ic_bwd_p")
         return g_img, g_psf, None
-
-
-def _sensor_library(img, psf, cam):
-    """|img (x) psf| / max for patch sizes the fftconv.hip kernels are not built for: the same convolution geometry as those kernels
-    (PSF centre at the origin of a 2P x 2P circular transform, out(s, t) = sum psf[u, v] img[s + P/2 - u, t + P/2 - v]; then
-    |.| and the reference's P-1 -> P nearest index map, csrc/fftconv.hip header = Utils.py:251-297) written with torch.fft on the
-    device, differentiable by autograd (PSF and image).  Library FFT, not a CPU path: the tensors never leave the GPU."""
-    B, C, P, _ = img.shape
-    N = 2 * P
-    x = img.to(torch.float32) / 255.0 if img.dtype == torch.uint8 else img.to(torch.float32)
-    k = psf[0].permute(2, 0, 1).to(torch.float32)                                          # [3, P, P]
-    emb = torch.zeros((C, N, N), dtype=torch.float32, device=img.device)
-    emb[:, :P, :P] = k
-    emb = torch.roll(emb, shifts=(-(P // 2), -(P // 2)), dims=(1, 2))                       # emb[y, x] = psf[(y + P/2) % N, (x + P/2) % N]
-    r = torch.fft.irfft2(torch.fft.rfft2(x, s=(N, N)) * torch.fft.rfft2(emb)[None], s=(N, N))[:, :, :P, :P]
-    idx = torch.clamp(torch.arange(P, device=img.device) - 1, min=0)                        # out[i][j] = |r(max(i-1, 0), max(j-1, 0))|
-    out = r[:, :, idx][:, :, :, idx].abs()
-    if cam.global_max_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
-        raise NotImplementedError("global_max_sync with a patch size outside {128, 256}: the cross-rank maximum (and its gradient) "
-                                  "is built into the native sensor path only")
-    return out / out.max()
 
 
 class OpticsZernike(nn.Module):
@@ -180,11 +158,13 @@ class OpticsZernike(nn.Module):
         RR, P = self.wave_res[0], patch_size
         if self.wave_res[0] != self.wave_res[1] or P % 2 or RR % 4:
             raise NotImplementedError("square wave resolution (a multiple of 4) and an even patch_size are compiled in")
-        # The image convolution kernels (csrc/fftconv.hip) are built for 256- and 512-point transforms, i.e. patch_size 128 / 256 (the
-        # reference's scripts pass 256, train.py:64-66).  Any other patch size -- the constructor's own default 368 (Lens.py:22) --
-        # takes the same convolution through torch.fft (rocFFT) on the GPU: _sensor_library below.  The PSF (Fresnel propagation on the
-        # 1.5 * RR grid) is native for every RR whose padded length factors into 2, 3, 5, 7, 11, 13, 23 (736 -> 1104 = 2^4 * 3 * 23).
-        self._sensor_native = 2 * P in (256, 512)
+        # The image convolution kernels (csrc/fftconv.hip) run 256-, 512- and 1024-point transforms.  patch_size 128 / 256 (the reference's
+        # scripts pass 256, train.py:64-66) fill a 2 P-point transform exactly; any other even patch size <= 512 -- the constructor's own
+        # default 368 (Lens.py:22) -- runs on the next of those lengths: image and PSF have support P x P, so every transform of at least
+        # 2 P - 1 points computes the reference's 2 P-point circular convolution (round 5: this used to go through a library FFT).  The PSF
+        # (Fresnel propagation on the 1.5 * RR grid) is native for every RR whose padded length factors into 2, 3, 5, 7, 11, 13, 23.
+        if P > 512:
+            raise NotImplementedError("patch_size above 512: the image convolution kernels stop at 1024-point transforms")
 
         # --- Zernike volume (Lens.py:66-78): same on-disk cache name as the reference, else GPU generator
         cache = 'zernike_volumes/zernike_volume_%d_n%d.npy' % (RR, zernike_terms)
@@ -350,10 +330,7 @@ class OpticsZernike(nn.Module):
         psf = psf_m if use_m2 else psf_n
         # uint8 input = the data set's raw pixels (HDF5 uint8, utils.py:94-150): decoded as x / 255 inside the first FFT kernel
         # (datasets.py:46 `imgs / 255.`), forward and backward; anything else is taken as float32 in [0, 1] like the reference
-        if self._sensor_native:
-            sensor_img = _IcSensorFn.apply(input_img if input_img.dtype == torch.uint8 else input_img.to(torch.float32), psf, self)
-        else:
-            sensor_img = _sensor_library(input_img, psf, self)
+        sensor_img = _IcSensorFn.apply(input_img if input_img.dtype == torch.uint8 else input_img.to(torch.float32), psf, self)
         np.random.uniform(low=0.001, high=0.02)                               # Lens.py:295 (RNG stream parity; value unused)
         return sensor_img, psf, coeffs, (loss if use_m1 else None)
 

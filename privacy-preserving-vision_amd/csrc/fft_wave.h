@@ -26,6 +26,7 @@ __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.
 template <int R> struct FftCfg;
 template <> struct FftCfg<8> { static constexpr int S = 3, LOG2R = 3; };   // 512 = 8^3
 template <> struct FftCfg<4> { static constexpr int S = 4, LOG2R = 2; };   // 256 = 4^4
+template <> struct FftCfg<16> { static constexpr int S = 5, LOG2R = 4; };  // 1024 = 4^5: radix-4 stages, four butterflies per lane (below)
 
 // forward (exp(-i...)) butterflies, in place, natural output order
 __device__ __forceinline__ void bfly4(float2& a0, float2& a1, float2& a2, float2& a3) {
@@ -80,6 +81,46 @@ __device__ __forceinline__ void fft_wave(float2 (&u)[R], float2* __restrict__ sc
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         p *= R;
+    }
+}
+
+// N = 1024 (R = 16 registers per lane): 1024 is not a power of 16 with 64 butterflies per stage, so the transform runs as FIVE radix-4
+// Stockham stages in which every lane owns four butterflies: butterfly t = lane + 64 b (b = 0..3) takes its inputs x[t + 256 r] from
+// registers u[b + 4 r] (the natural layout: lane l holds element l + 64 i in u[i]) and its outputs land, after the last stage, in the
+// same registers in natural order.  Used by the image (x) PSF convolution for patch sizes above 256 (the reference constructor's default
+// 368: any transform length >= 2 P - 1 gives the same linear convolution, csrc/fftconv.hip).
+template <>
+__device__ __forceinline__ void fft_wave<16>(float2 (&u)[16], float2* __restrict__ scratch, const float2* __restrict__ tw, int lane) {
+    constexpr int N = 1024;
+    int p = 1;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = (lane + 64 * b) & (p - 1);
+            if (s > 0) {
+                const int step = N / (p * 4);
+                u[b + 4] = cmul(u[b + 4], tw[k * step]);
+                u[b + 8] = cmul(u[b + 8], tw[2 * k * step]);
+                u[b + 12] = cmul(u[b + 12], tw[3 * k * step]);
+            }
+            bfly4(u[b], u[b + 4], u[b + 8], u[b + 12]);
+        }
+        if (s < 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int t = lane + 64 * b, k = t & (p - 1), j = (t - k) * 4 + k;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) scratch[lds_pad<16>(j + q * p)] = u[b + 4 * q];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = scratch[lds_pad<16>(lane + 64 * r)];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        p *= 4;
     }
 }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void rows_r2c_kernel(const TIN* __restrict__ i
 // ----------------------------------------------------------------------------- column pass
 // otfT layout: [C][NH+1][N]  (kx-major, ky contiguous; entry kx == NH is the Nyquist column).
 template <int R>
-__global__ __launch_bounds__(512, 4) void cols_mul_kernel(const float2* __restrict__ S1, float2* __restrict__ S2,
+__global__ __launch_bounds__(512, R >= 16 ? 2 : 4) void cols_mul_kernel(const float2* __restrict__ S1, float2* __restrict__ S2,
                                                        const float2* __restrict__ otfT,
                                                        const float2* __restrict__ twg, int C, int H_in, int row_off,
                                                        int H_out, int conj_otf, float scale) {
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(512, 4) void cols_mul_kernel(const float2* __restri
 template <int R> static void cols_mul_lds_attr() {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)cols_mul_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * R * 17 * (int)sizeof(float2));
+        // (R = 16: only the IC geometry exists -- at most N / 2 = 512 rows of data; the tile shares the CU's 160 KB with 78 KB of static LDS)
+        (void)hipFuncSetAttribute((const void*)cols_mul_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (R >= 16 ? 32 : 64) * R * 17 * (int)sizeof(float2));
         done = true;
     }
 }
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(256) void rows_c2r_kernel(const float2* __restrict_
                                                        unsigned long long* __restrict__ signs,
                                                        float* __restrict__ partial_max,
                                                        const float2* __restrict__ twg, int planes, int Hs, int ppw,
-                                                       float scale) {
+                                                       float scale, int P) {
+    // P (MODE 0 / 2): patch size, P <= N / 2 (N / 2 for the 128 / 256 patches; smaller on a transform padded up to the next 64 R)
     constexpr int N = 64 * R, NH = N / 2;
     __shared__ float2 s_tw[N];
     __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
@@ -212,7 +214,6 @@ __global__ __launch_bounds__(256) void rows_c2r_kernel(const float2* __restrict_
         }
         ifft_wave<R>(u, s_scr[wave], s_tw, lane);
         if (MODE == 0) {
-            constexpr int P = NH;
             float* op = out + (long)plane * P * P;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -239,13 +240,14 @@ __global__ __launch_bounds__(256) void rows_c2r_kernel(const float2* __restrict_
                 }
             }
         } else if (MODE == 2) {
-            constexpr int P = NH;
             float* op = out + ((long)plane * P + r0) * P;
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) {
                 const int n = lane + 64 * q;
-                op[n] = u[q].x * scale;
-                if (has_b) op[P + n] = u[q].y * scale;
+                if (n < P) {
+                    op[n] = u[q].x * scale;
+                    if (has_b) op[P + n] = u[q].y * scale;
+                }
             }
         } else {
             float* op = out + ((long)plane * Hs + r0) * N;
@@ -337,28 +339,34 @@ __global__ __launch_bounds__(512) void cols_corr_acc_kernel(const float2* __rest
                                                             float2* __restrict__ part,
                                                             const float2* __restrict__ twg, int B, int C, int HX,
                                                             int HG, int bchunk) {
-    constexpr int N = 64 * R, NH = N / 2, LD = 17;
+    // CPW columns per wave: two for the 256- / 512-point transforms (16-column tiles), one for 1024 points (8-column tiles: the two
+    // operand tiles of 512 rows and the eight waves' exchange scratch must share 160 KB of LDS)
+    constexpr int N = 64 * R, NH = N / 2, CPW = R >= 16 ? 1 : 2, COLS = 8 * CPW, LD = COLS + 1, F4 = COLS / 2;
     __shared__ float2 s_tw[N];
     __shared__ float2 s_scr[8][fft_scratch_elems<R>()];
-    __shared__ float2 s_x[N / 2 * LD];      // IC path only: image and grad have P = N/2 rows
+    __shared__ float2 s_x[N / 2 * LD];      // IC path only: image and grad have P <= N/2 rows
     __shared__ float2 s_g[N / 2 * LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.x, ch = blockIdx.y, chunk = blockIdx.z;
     for (int i = tid; i < N; i += 512) s_tw[i] = twg[i];
-    float2 acc[2][R], accn[R];
+    float2 acc[CPW][R], accn[R];
 #pragma unroll
-    for (int q = 0; q < R; ++q) acc[0][q] = acc[1][q] = accn[q] = make_float2(0.f, 0.f);
+    for (int q = 0; q < R; ++q) {
+        accn[q] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) acc[cc][q] = make_float2(0.f, 0.f);
+    }
     const int b0 = chunk * bchunk, b1 = min(B, b0 + bchunk);
     // the next image's two tiles travel in registers while this one's columns are transformed (HX, HG <= N/2: four 16-byte pieces each)
-    constexpr int PF = (N / 2 * 8) / 512;
+    constexpr int PF = (N / 2 * F4) / 512;
     float4 px[PF], pg[PF];
     auto fetch = [&](int b) {
         const long plane = (long)b * C + ch;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int idx = i * 512 + tid, row = idx >> 3, c4 = idx & 7;
-            px[i] = row < HX ? *reinterpret_cast<const float4*>(&SX[(plane * HX + row) * NH + tile * 16 + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pg[i] = row < HG ? *reinterpret_cast<const float4*>(&SG[(plane * HG + row) * NH + tile * 16 + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int idx = i * 512 + tid, row = idx / F4, c4 = idx % F4;
+            px[i] = row < HX ? *reinterpret_cast<const float4*>(&SX[(plane * HX + row) * NH + tile * COLS + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pg[i] = row < HG ? *reinterpret_cast<const float4*>(&SG[(plane * HG + row) * NH + tile * COLS + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (b0 < b1) fetch(b0);
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(512) void cols_corr_acc_kernel(const float2* __rest
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int idx = i * 512 + tid, row = idx >> 3, c4 = idx & 7;
+            const int idx = i * 512 + tid, row = idx / F4, c4 = idx % F4;
             s_x[row * LD + c4 * 2] = make_float2(px[i].x, px[i].y);
             s_x[row * LD + c4 * 2 + 1] = make_float2(px[i].z, px[i].w);
             s_g[row * LD + c4 * 2] = make_float2(pg[i].x, pg[i].y);
@@ -375,9 +383,9 @@ __global__ __launch_bounds__(512) void cols_corr_acc_kernel(const float2* __rest
         if (b + 1 < b1) fetch(b + 1);
         __syncthreads();
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const int c = wave * 2 + cc;
-            const int kx = tile * 16 + c;
+        for (int cc = 0; cc < CPW; ++cc) {
+            const int c = wave * CPW + cc;
+            const int kx = tile * COLS + c;
             float2 x[R], g[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -407,8 +415,8 @@ __global__ __launch_bounds__(512) void cols_corr_acc_kernel(const float2* __rest
     }
     float2* pbase = part + ((long)chunk * C + ch) * (NH + 1) * N;
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const int kx = tile * 16 + wave * 2 + cc;
+    for (int cc = 0; cc < CPW; ++cc) {
+        const int kx = tile * COLS + wave * CPW + cc;
 #pragma unroll
         for (int q = 0; q < R; ++q) pbase[(long)kx * N + lane + 64 * q] = acc[cc][q];
         if (kx == 0) {
@@ -478,8 +486,7 @@ template <int R>
 __global__ __launch_bounds__(256) void ic_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
                                                          const unsigned long long* __restrict__ signs,
                                                          const float* __restrict__ maxv, const double* __restrict__ dotcnt,
-                                                         float* __restrict__ gr, long total) {
-    constexpr int P = 32 * R;
+                                                         float* __restrict__ gr, long total, int P) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int t = (int)(idx % P), s = (int)((idx / P) % P);
@@ -648,16 +655,16 @@ int otf_build_t(const void* psf, int psf_is_f64, long sc, long sy, long sx, int 
 
 template <int R, typename TIN = float>
 int fftconv_fwd_t(const TIN* img, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
-                  int B, int C, int mode, int conj_otf, hipStream_t stream) {
+                  int B, int C, int mode, int conj_otf, hipStream_t stream, int P = 32 * R) {
     constexpr int N = 64 * R;
     const float2* tw = (const float2*)ppv_twiddles_f32(N);
     if (!tw) return PPV_ERR_INIT;
-    const int H = (mode == 0) ? N / 2 : N;      // image rows == cols
+    const int H = (mode == 0) ? P : N;          // image rows == cols (mode 0: the P x P patch inside an N-point transform, P <= N / 2)
     const int planes = B * C;
     float2* S1 = (float2*)workspace;
     float2* S2 = S1 + (size_t)planes * H * (N / 2);
     const int ppw = 4;
-    const long pairs = (long)planes * (H / 2);
+    const long pairs = (long)planes * ((H + 1) / 2);
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
     const float scale = 1.0f / ((float)N * (float)N);
     rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, S1, tw, planes, H, H, ppw);
@@ -666,17 +673,17 @@ int fftconv_fwd_t(const TIN* img, const void* otfT, float* out, void* signs, flo
                                                                 scale);
     if (mode == 0)
         rows_c2r_kernel<R, 0><<<g1, 256, 0, stream>>>(S2, out, (unsigned long long*)signs, partial_max, tw, planes, H,
-                                                      ppw, 1.f);
+                                                      ppw, 1.f, P);
     else
-        rows_c2r_kernel<R, 1><<<g1, 256, 0, stream>>>(S2, out, nullptr, partial_max, tw, planes, H, ppw, 1.f);
+        rows_c2r_kernel<R, 1><<<g1, 256, 0, stream>>>(S2, out, nullptr, partial_max, tw, planes, H, ppw, 1.f, 0);
     return ppv_last_error();
 }
 
 template <int R, typename TIN = float>
 int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
                   const double* dotcnt, const void* otfT, void* g_psf, int is_f64, long sc, long sy, long sx,
-                  float* g_img, void* workspace, int B, int C, hipStream_t stream) {
-    constexpr int N = 64 * R, NH = N / 2, P = NH;
+                  float* g_img, void* workspace, int B, int C, hipStream_t stream, int P = 32 * R) {
+    constexpr int N = 64 * R, NH = N / 2;
     const float2* tw = (const float2*)ppv_twiddles_f32(N);
     if (!tw) return PPV_ERR_INIT;
     const int planes = B * C;
@@ -691,20 +698,20 @@ int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, co
     float* gemb = (float*)wp;
     const long total = (long)planes * P * P;
     ic_out_bwd_kernel<R><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(g_sensor, sensor, (const unsigned long long*)signs,
-                                                                             maxv, dotcnt, gr, total);
+                                                                             maxv, dotcnt, gr, total, P);
     const int ppw = 4;
-    const long pairs = (long)planes * (P / 2);
+    const long pairs = (long)planes * ((P + 1) / 2);
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
     rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(gr, SG, tw, planes, P, P, ppw);
     if (g_psf) {
         rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, SX, tw, planes, P, P, ppw);
-        cols_corr_acc_kernel<R><<<dim3(N / 32, C, (B + bchunk - 1) / bchunk), 512, 0, stream>>>(SX, SG, part, tw, B, C, P, P,
+        cols_corr_acc_kernel<R><<<dim3(R >= 16 ? N / 16 : N / 32, C, (B + bchunk - 1) / bchunk), 512, 0, stream>>>(SX, SG, part, tw, B, C, P, P,
                                                                                            bchunk);
         cols_inv_from_T_kernel<R><<<(unsigned)((C * NH + 3) / 4), 256, 0, stream>>>(part, S2, tw, C, (B + bchunk - 1) / bchunk,
                                                                                   1.0f / ((float)N * (float)N));
         const long cp = (long)C * (N / 2);
         rows_c2r_kernel<R, 1><<<(unsigned)((cp + 4 * ppw - 1) / (4 * ppw)), 256, 0, stream>>>(S2, gemb, nullptr, nullptr, tw, C, N,
-                                                                                            ppw, 1.f);
+                                                                                            ppw, 1.f, 0);
         const long tp = (long)C * P * P;
         if (is_f64)
             psf_gather_kernel<double><<<(unsigned)((tp + 255) / 256), 256, 0, stream>>>(gemb, (double*)g_psf, C, P, N, sc, sy, sx);
@@ -716,7 +723,7 @@ int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, co
         cols_mul_lds_attr<R>();
         cols_mul_kernel<R><<<dim3(N / 32, planes), 512, (size_t)P * 17 * sizeof(float2), stream>>>(SG, S2b, (const float2*)otfT, tw, C, P, 0, P, 1,
                                                                     1.0f / ((float)N * (float)N));
-        rows_c2r_kernel<R, 2><<<g1, 256, 0, stream>>>(S2b, g_img, nullptr, nullptr, tw, planes, P, ppw, 1.f);
+        rows_c2r_kernel<R, 2><<<g1, 256, 0, stream>>>(S2b, g_img, nullptr, nullptr, tw, planes, P, ppw, 1.f, P);
     }
     return ppv_last_error();
 }
@@ -751,7 +758,7 @@ int fftconv_fd_bwd_t(const float* img, const float* g_sensor, const float* senso
     cols_corr_acc_full_kernel<R><<<dim3(NH / 8, C, nch), 512, 0, stream>>>(SX, SG, part, tw, B, C, bchunk);
     cols_inv_from_T_kernel<R><<<(unsigned)((C * NH + 3) / 4), 256, 0, stream>>>(part, S2, tw, C, nch, 1.0f / ((float)N * (float)N));
     const long cp = (long)C * (N / 2);
-    rows_c2r_kernel<R, 1><<<(unsigned)((cp + 4 * ppw - 1) / (4 * ppw)), 256, 0, stream>>>(S2, gemb, nullptr, nullptr, tw, C, N, ppw, 1.f);
+    rows_c2r_kernel<R, 1><<<(unsigned)((cp + 4 * ppw - 1) / (4 * ppw)), 256, 0, stream>>>(S2, gemb, nullptr, nullptr, tw, C, N, ppw, 1.f, 0);
     const long tp = (long)C * N * N;
     psf_gather_kernel<float><<<(unsigned)((tp + 255) / 256), 256, 0, stream>>>(gemb, g_psf, C, N, N, (long)N * N, N, 1);
     return ppv_last_error();
@@ -776,8 +783,59 @@ int ppv_otf_build(const void* psf, int psf_is_f64, long sc, long sy, long sx, in
                   void* workspace, hipStream_t stream) {
     if (!psf || !otfT || !workspace) return PPV_ERR_NULL;
     if (P > N) return PPV_ERR_BAD_SIZE;
+    if (N == 1024) return otf_build_t<16>(psf, psf_is_f64, sc, sy, sx, C, P, otfT, workspace, stream);
     if (N == 512) return otf_build_t<8>(psf, psf_is_f64, sc, sy, sx, C, P, otfT, workspace, stream);
     if (N == 256) return otf_build_t<4>(psf, psf_is_f64, sc, sy, sx, C, P, otfT, workspace, stream);
+    return PPV_ERR_BAD_SIZE;
+}
+
+// ---- the IC sensor convolution for ANY even patch size P <= 512 (round 5: the reference constructor's default 368, Lens.py:21-22, and
+// every other size off the 128 / 256 grid used to go through torch.fft).  img and psf have support P x P, so their linear convolution
+// has support (2 P - 1)^2 and EVERY circular transform of length N >= 2 P - 1 computes it without wrap-around: the reference's 2 P-point
+// result (Utils.py:251-297) equals the N-point one, N = the next of 256 / 512 / 1024, with the PSF embedded at the same place (centre at
+// the origin).  Same kernels as ppv_fftconv_fwd(mode 0) / ppv_fftconv_ic_bwd with P < N / 2 rows / columns of data.
+// signs: [B * C][P][N / 128] 64-bit words; partial_max: ppv_fftconv_ic_partials(B, C, P) floats; u8: img is uint8 pixels (x / 255).
+int ppv_fftconv_ic_partials(int B, int C, int P) {
+    const long pairs = (long)B * C * ((P + 1) / 2);
+    return (int)((pairs + 15) / 16);
+}
+size_t ppv_fftconv_ic_workspace_bytes(int B, int C, int P, int N) {
+    return 2 * (size_t)B * C * P * (N / 2) * sizeof(float2) + 4096;
+}
+int ppv_fftconv_ic_fwd_p(const void* img, int u8, const void* otfT, float* out, void* signs, float* partial_max, void* workspace,
+                         int B, int C, int P, int N, hipStream_t stream) {
+    if (!img || !otfT || !out || !workspace || !signs) return PPV_ERR_NULL;
+    if (P < 2 || P % 2 || 2 * P > N) return PPV_ERR_BAD_SIZE;
+#define PPV_IC_FWD(R_)                                                                                                           \
+    return u8 ? fftconv_fwd_t<R_, unsigned char>((const unsigned char*)img, otfT, out, signs, partial_max, workspace, B, C, 0, 0, stream, P) \
+              : fftconv_fwd_t<R_>((const float*)img, otfT, out, signs, partial_max, workspace, B, C, 0, 0, stream, P)
+    if (N == 1024) PPV_IC_FWD(16);
+    if (N == 512) PPV_IC_FWD(8);
+    if (N == 256) PPV_IC_FWD(4);
+#undef PPV_IC_FWD
+    return PPV_ERR_BAD_SIZE;
+}
+size_t ppv_fftconv_ic_bwd_workspace_bytes_p(int B, int C, int P, int N) {
+    const size_t planes = (size_t)B * C, NH = N / 2;
+    const size_t nchunk = B < 16 ? B : 16;
+    return planes * P * P * sizeof(float) + 2 * planes * P * NH * sizeof(float2) + nchunk * C * (NH + 1) * N * sizeof(float2) +
+           (size_t)C * N * NH * sizeof(float2) + (size_t)C * N * N * sizeof(float) + 4096;
+}
+int ppv_fftconv_ic_bwd_p(const void* img, int u8, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
+                         const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64, long sc, long sy, long sx,
+                         float* g_img, void* workspace, int B, int C, int P, int N, hipStream_t stream) {
+    if (!img || !g_sensor || !sensor || !signs || !maxv || !dotcnt || !workspace) return PPV_ERR_NULL;
+    if (g_img && (!otfT || u8)) return g_img && u8 ? PPV_ERR_BAD_SIZE : PPV_ERR_NULL;
+    if (P < 2 || P % 2 || 2 * P > N) return PPV_ERR_BAD_SIZE;
+#define PPV_IC_BWD(R_)                                                                                                           \
+    return u8 ? fftconv_bwd_t<R_, unsigned char>((const unsigned char*)img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf,   \
+                                                  g_psf_is_f64, sc, sy, sx, nullptr, workspace, B, C, stream, P)                    \
+              : fftconv_bwd_t<R_>((const float*)img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, \
+                                  g_img, workspace, B, C, stream, P)
+    if (N == 1024) PPV_IC_BWD(16);
+    if (N == 512) PPV_IC_BWD(8);
+    if (N == 256) PPV_IC_BWD(4);
+#undef PPV_IC_BWD
     return PPV_ERR_BAD_SIZE;
 }
 

@@ -44,6 +44,33 @@ def fftconv_fwd(img, otf, mode, conj_otf=False, workspace=None):
     return out, signs, partial
 
 
+def ic_transform_length(P):
+    """Transform length of the IC sensor convolution for patch size P: 2 P where that is 256 / 512 (the kernels' native sizes), else
+    the next of 256 / 512 / 1024 >= 2 P (supports P x P: any length >= 2 P - 1 gives the reference's 2 P-point convolution)."""
+    for n in (256, 512, 1024):
+        if 2 * P <= n:
+            return n
+    raise ValueError("patch sizes above 512 are outside the image convolution kernels (1024-point transforms)")
+
+
+def fftconv_ic_fwd(img, otf, N):
+    """IC sensor convolution (Utils.py:251-297), img [B,C,P,P] f32 or uint8, any even P with 2 P <= N in {256, 512, 1024}
+    -> (|conv| [B,C,P,P], signs, partial_max)."""
+    _lib.require_cuda(img, otf)
+    img = img.contiguous()
+    B, C, P, W = img.shape
+    assert P == W and P % 2 == 0 and 2 * P <= N and otf.shape == (C, N // 2 + 1, N) and img.dtype in (torch.float32, torch.uint8)
+    dev = img.device
+    L = _lib.lib()
+    ws = torch.empty(L.ppv_fftconv_ic_workspace_bytes(B, C, P, N), dtype=torch.uint8, device=dev)
+    out = torch.empty(img.shape, dtype=torch.float32, device=dev)
+    partial = torch.empty(L.ppv_fftconv_ic_partials(B, C, P), dtype=torch.float32, device=dev)
+    signs = torch.zeros(B * C * P * (N // 128), dtype=torch.int64, device=dev)          # row P-1 is never written
+    check(L.ppv_fftconv_ic_fwd_p(ptr(img), int(img.dtype == torch.uint8), ptr(otf), ptr(out), ptr(signs), ptr(partial), ptr(ws),
+                                 B, C, P, N, stream_ptr()), "ppv_fftconv_ic_fwd_p")
+    return out, signs, partial
+
+
 def group_max(partial, groups):
     out = torch.empty(groups, dtype=torch.float32, device=partial.device)
     check(_lib.lib().ppv_group_max(ptr(partial), ptr(out), groups, partial.numel() // groups, stream_ptr()),

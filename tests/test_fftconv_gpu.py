@@ -33,6 +33,29 @@ def test_ic_img_psf_conv(P, B):
     assert (signs.cpu() == 0).all()          # non-negative image and PSF
 
 
+@pytest.mark.parametrize("P,B", [(368, 2), (300, 1), (130, 2), (64, 3), (512, 1)])
+def test_ic_img_psf_conv_at_any_even_patch_size(P, B):
+    """Patch sizes off the 128 / 256 grid (the reference constructor's default is 368, Lens.py:21-22) on the next 256 / 512 / 1024-point
+    transform (ppv_fftconv_ic_fwd_p) against the oracle's 2 P-point convolution (Utils.py:251-297), a signed PSF included (sign bits)."""
+    import ppv_amd.fftconv as fc
+    from oracle import ic_camera as ic
+    img = torch.rand(B, 3, P, P, generator=torch.Generator().manual_seed(0))
+    psf = _psf(P, 1) - (0.3 / (P * P) if P == 300 else 0.0)
+    want = ic.img_psf_conv(img, psf.permute(1, 2, 0, 3).to(torch.float32))
+    N = fc.ic_transform_length(P)
+    assert N >= 2 * P and N in (256, 512, 1024)
+    otf = fc.otf_build(psf.cuda()[0].permute(2, 0, 1), P, N)
+    got, signs, partial = fc.fftconv_ic_fwd(img.cuda(), otf, N)
+    assert rel_err(got.cpu(), want) < 2e-5
+    assert abs(partial.max().item() - want.max().item()) < 2e-5 * want.max().item()
+    # delta PSF: the reference's integer index path out(i, j) = img(max(i-1, 0), max(j-1, 0))
+    d = torch.zeros(3, P, P, device="cuda")
+    d[:, P // 2, P // 2] = 1.0
+    got_d, _, _ = fc.fftconv_ic_fwd(img.cuda(), fc.otf_build(d, P, N), N)
+    idx = np.maximum(np.arange(P) - 1, 0)
+    assert np.abs(got_d.cpu().numpy() - img.numpy()[:, :, idx][:, :, :, idx]).max() < 4e-6
+
+
 def test_ic_delta_psf_index_map():
     """delta PSF at the centre: out(i,j) == img(max(i-1,0), max(j-1,0)) -- the reference's integer index path."""
     import ppv_amd.fftconv as fc

@@ -62,7 +62,9 @@ int ppv_fftconv_ic_fwd_p(const void* img, int u8, const void* otfT, float* out, 
 size_t ppv_fftconv_ic_bwd_workspace_bytes_p(int B, int C, int P, int N);
 int ppv_fftconv_ic_bwd_p(const void* img, int u8, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
                          const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64, long sc, long sy, long sx,
-                         float* g_img, void* workspace, int B, int C, int P, int N, ppv_stream_t stream);
+                         float* g_img, void* workspace, const void* sx_saved, int B, int C, int P, int N, ppv_stream_t stream);
+/* sx_saved (may be null): the first planes * P * (N / 2) float2 of the workspace ppv_fftconv_ic_fwd_p ran on (the row transform of the
+ * image), if the caller kept that buffer untouched since: backward then skips recomputing it */
 size_t ppv_fftconv_bwd_workspace_bytes(int B, int C, int N);
 int ppv_sensor_dot_count(const float* g, const float* sensor, double* dotcnt, long n, ppv_stream_t stream);
 int ppv_fftconv_ic_bwd(const float* img, const float* g_sensor, const float* sensor, const void* signs,

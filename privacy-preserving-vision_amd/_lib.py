@@ -33,7 +33,7 @@ PROTOTYPES = {
     "ppv_fftconv_ic_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "ppv_fftconv_ic_fwd_p": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_fftconv_ic_bwd_workspace_bytes_p": (_Z, [_I, _I, _I, _I]),
-    "ppv_fftconv_ic_bwd_p": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_fftconv_ic_bwd_p": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_sensor_dot_count": (_I, [_P, _P, _P, _L, _P]),
     "ppv_fftconv_ic_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _P]),
     "ppv_fftconv_ic_bwd_u8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P, _P, _I, _I, _I, _P]),

@@ -82,6 +82,10 @@ class _IcSensorFn(torch.autograd.Function):
         img = img.contiguous()
         otf = fc.otf_build(psf.detach()[0].permute(2, 0, 1), P, N)
         out, signs, partial = fc.fftconv_ic_fwd(img, otf, N)
+        # the forward workspace starts with the row transform of the image: kept (2 x 0.2 GB at B = 128) when the PSF needs a gradient,
+        # so that backward does not recompute it (PPV_IC_KEEP_ROWS=0: recompute)
+        ctx.rows_ws = fc.fftconv_ic_fwd.last_workspace if (ctx.needs_input_grad[1] and os.environ.get("PPV_IC_KEEP_ROWS", "1") != "0") else None
+        fc.fftconv_ic_fwd.last_workspace = None
         m = fc.group_max(partial, 1)
         if cam.global_max_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
@@ -110,7 +114,8 @@ class _IcSensorFn(torch.autograd.Function):
         sc, sy, sx = (1, P * 3, 3)       # [1,P,P,3] viewed as [C][P][P]
         check(L.ppv_fftconv_ic_bwd_p(ptr(img), int(img.dtype == torch.uint8), ptr(g), ptr(sensor), ptr(signs), ptr(m), ptr(dotcnt), ptr(otf),
                                      ptr(g_psf), int(dtype == torch.float64), sc, sy, sx, ptr(g_img), ptr(ws),       # uint8 pixels: no image gradient
-                                     B, C, P, N, stream_ptr()), "ppv_fftconv_ic_bwd_p")
+                                     ptr(ctx.rows_ws), B, C, P, N, stream_ptr()), "ppv_fftconv_ic_bwd_p")
+        ctx.rows_ws = None
         return g_img, g_psf, None
 
 

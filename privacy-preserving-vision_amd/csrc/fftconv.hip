@@ -18,6 +18,7 @@
 // HBM traffic per plane (N=512, P=256): 0.25 + 0.5 + 0.5 + 0.5 + 0.5 + 0.25 MB = 2.5 MB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "fft_wave.h"
 #include "ppv_common.h"
 
@@ -152,6 +153,105 @@ __global__ __launch_bounds__(512, R >= 16 ? 2 : 4) void cols_mul_kernel(const fl
     }
 }
 
+// Persistent form of cols_mul_kernel for the IC geometry (H rows of data in and out, H <= N / 2; round 5, VERDICT r4 task 7).  The kernel
+// above runs load -> transform -> store once per workgroup: with two workgroups per CU a CU has requests in flight for a third of the
+// time (10 GB/s per CU measured, 2.6 TB/s on the chip).  Here 2 x CUs workgroups walk the tiles: the NEXT tile's rows are fetched into
+// registers (R / 2 float4 per thread) before the current tile's columns are transformed, and the current tile's stores drain while the
+// next tile is parked and transformed -- loads and stores of consecutive tiles overlap the FFTs between them.
+template <int R>
+__global__ __launch_bounds__(512, R >= 16 ? 2 : 4) void cols_mul_pf_kernel(const float2* __restrict__ S1, float2* __restrict__ S2,
+                                                                           const float2* __restrict__ otfT, const float2* __restrict__ twg,
+                                                                           int C, int H, int conj_otf, float scale, int planes) {
+    constexpr int N = 64 * R, NH = N / 2, LD = 17, PRE = R / 2, TPP = N / 32;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[8][fft_scratch_elems<R>()];
+    extern __shared__ __attribute__((aligned(16))) float2 s_tile[];   // H x LD
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < N; i += 512) s_tw[i] = twg[i];
+    const long total = (long)planes * TPP;
+    float4 pre[PRE];
+    auto fetch = [&](long t) {
+        const long plane = t / TPP;
+        const int tile = (int)(t % TPP);
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int idx = i * 512 + tid, row = idx >> 3, c4 = idx & 7;
+            pre[i] = row < H ? *reinterpret_cast<const float4*>(&S1[(plane * H + row) * NH + tile * 16 + c4 * 2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    long t = blockIdx.x;
+    if (t < total) fetch(t);
+    for (; t < total; t += gridDim.x) {
+        const long plane = t / TPP;
+        const int tile = (int)(t % TPP), ch = (int)(plane % C);
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int idx = i * 512 + tid, row = idx >> 3, c4 = idx & 7;
+            if (row < H) {
+                s_tile[row * LD + c4 * 2] = make_float2(pre[i].x, pre[i].y);
+                s_tile[row * LD + c4 * 2 + 1] = make_float2(pre[i].z, pre[i].w);
+            }
+        }
+        __syncthreads();
+        if (t + gridDim.x < total) fetch(t + gridDim.x);
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = wave * 2 + cc;
+            const int kx = tile * 16 + c;
+            float2 u[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = lane + 64 * r;
+                u[r] = (row < H) ? s_tile[row * LD + c] : make_float2(0.f, 0.f);
+            }
+            const float2* o = otfT + ((long)ch * (NH + 1) + kx) * N;      // (read after the transform: the prefetch registers of the next
+            fft_wave<R>(u, s_scr[wave], s_tw, lane);                       // tile take the room the early OTF loads had in cols_mul_kernel)
+            if (kx == 0) {
+                const float2* on = otfT + ((long)ch * (NH + 1) + NH) * N;
+                float2 v[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const float2 z = u[q];
+                    float2 m = shfl2(u[R - 1 - q], (64 - lane) & 63);
+                    if (lane == 0) m = u[(R - q) % R];
+                    const float2 A = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+                    const float2 B = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
+                    const int k = lane + 64 * q;
+                    const float2 o0 = o[k], o1 = on[k];
+                    const float2 pa = conj_otf ? cmul_conj(A, o0) : cmul(A, o0);
+                    const float2 pb = conj_otf ? cmul_conj(B, o1) : cmul(B, o1);
+                    v[q] = make_float2(pa.x - pb.y, pa.y + pb.x);
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) u[q] = v[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const float2 w = o[lane + 64 * q];
+                    u[q] = conj_otf ? cmul_conj(u[q], w) : cmul(u[q], w);
+                }
+            }
+            ifft_wave<R>(u, s_scr[wave], s_tw, lane);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int row = lane + 64 * q;
+                if (row < H) s_tile[row * LD + c] = make_float2(u[q].x * scale, u[q].y * scale);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H * 8; idx += 512) {
+            const int row = idx >> 3, c4 = idx & 7;
+            const float2 a = s_tile[row * LD + c4 * 2], b = s_tile[row * LD + c4 * 2 + 1];
+            *reinterpret_cast<float4*>(&S2[(plane * H + row) * NH + tile * 16 + c4 * 2]) = make_float4(a.x, a.y, b.x, b.y);
+        }
+        __syncthreads();
+    }
+}
+
+// the column pass of the IC geometry: one tile per workgroup (default) or the persistent prefetching form (PPV_COLS_PF=1, measured slower)
+template <int R>
+static void launch_cols_mul_ic(const float2* S1, float2* S2, const float2* otfT, const float2* tw, int C, int H, int conj_otf, float scale,
+                               int planes, hipStream_t stream);
+
 template <int R> static void cols_mul_lds_attr() {
     static bool done = false;
     if (!done) {
@@ -159,6 +259,34 @@ template <int R> static void cols_mul_lds_attr() {
         (void)hipFuncSetAttribute((const void*)cols_mul_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (R >= 16 ? 32 : 64) * R * 17 * (int)sizeof(float2));
         done = true;
     }
+}
+
+template <int R>
+static void launch_cols_mul_ic(const float2* S1, float2* S2, const float2* otfT, const float2* tw, int C, int H, int conj_otf, float scale,
+                               int planes, hipStream_t stream) {
+    constexpr int N = 64 * R;
+    // MEASURED (round 5, tools/bench_camera.py, B = 64): the persistent form LOSES -- fftconv forward 0.257-0.267 ms against 0.158-0.165 ms,
+    // IC camera 1.20 against 1.11 ms: cols_mul_kernel already sits at the 128-VGPR cap of two workgroups per CU, the R / 2 float4 of
+    // prefetch spill (232-272 bytes of scratch per lane with or without the early OTF loads).  Opt-in only (PPV_COLS_PF=1).
+    static const int pf = getenv("PPV_COLS_PF") ? atoi(getenv("PPV_COLS_PF")) : 0;
+    const size_t lds = (size_t)H * 17 * sizeof(float2);
+    if (pf && H <= N / 2) {
+        static bool done = false;
+        static int wgs = 512;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)cols_mul_pf_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * R * 17 * (int)sizeof(float2));
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            wgs = (R >= 16 ? 1 : 2) * cus * (getenv("PPV_COLS_PF_MULT") ? atoi(getenv("PPV_COLS_PF_MULT")) : 1);
+            done = true;
+        }
+        const long total = (long)planes * (N / 32);
+        cols_mul_pf_kernel<R><<<(unsigned)(total < wgs ? total : wgs), 512, lds, stream>>>(S1, S2, otfT, tw, C, H, conj_otf, scale, planes);
+        return;
+    }
+    cols_mul_lds_attr<R>();
+    cols_mul_kernel<R><<<dim3(N / 32, planes), 512, lds, stream>>>(S1, S2, otfT, tw, C, H, 0, H, conj_otf, scale);
 }
 
 // ----------------------------------------------------------------------------- rows inverse
@@ -509,6 +637,73 @@ __global__ __launch_bounds__(256) void ic_out_bwd_kernel(const float* __restrict
     gr[idx] = out;
 }
 
+// ic_out_bwd_kernel fused into the row transform of the gradient (round 5): the value ic_out_bwd_kernel would store at gr[plane][s][t]
+// is computed by the lane that feeds it to the FFT -- same expression, same order of additions, so SG is bit-identical -- and the
+// [B, C, P, P] f32 tensor gr is neither written nor re-read (one launch and 2 x 4 B per pixel less).  Row s >= 1 reads row s + 1 of g /
+// sensor shifted by one column (a coalesced load, 4 bytes off alignment), row 0 reads rows 0 and 1.
+template <int R>
+__global__ __launch_bounds__(256) void rows_r2c_icgrad_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
+                                                              const unsigned long long* __restrict__ signs,
+                                                              const float* __restrict__ maxv, const double* __restrict__ dotcnt,
+                                                              float2* __restrict__ out, const float2* __restrict__ twg, int planes, int P,
+                                                              int ppw) {
+    constexpr int N = 64 * R, NH = N / 2;
+    __shared__ float2 s_tw[N];
+    __shared__ float2 s_scr[4][fft_scratch_elems<R>()];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < N; i += 256) s_tw[i] = twg[i];
+    __syncthreads();
+    const float M = *maxv;
+    const float share = (float)(dotcnt[0] / dotcnt[1]);
+    const int ppp = (P + 1) >> 1;
+    const long total = (long)planes * ppp;
+    const long first = ((long)blockIdx.x * 4 + wave) * ppw;
+    auto grval = [&](long plane, int s, int t) -> float {
+        if (s >= P - 1 || t >= P - 1) return 0.f;
+        const int i0 = (s == 0) ? 0 : s + 1, i1 = s + 1, j0 = (t == 0) ? 0 : t + 1, j1 = t + 1;
+        float acc = 0.f;
+        for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) {
+                const long o = (plane * P + i) * P + j;
+                const float gv = g[o] - ((sensor[o] == 1.f) ? share : 0.f);
+                acc += gv / M;
+            }
+        const unsigned long long bits = signs[(plane * P + s) * (R / 2) + (t >> 6)];
+        return ((bits >> (t & 63)) & 1ull) ? -acc : acc;
+    };
+    for (int it = 0; it < ppw; ++it) {
+        const long pair = first + it;
+        if (pair >= total) break;
+        const long plane = pair / ppp;
+        const int r0 = 2 * (int)(pair % ppp);
+        const bool has_b = (r0 + 1) < P;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = lane + 64 * r;
+            u[r] = make_float2(n < P ? grval(plane, r0, n) : 0.f, (has_b && n < P) ? grval(plane, r0 + 1, n) : 0.f);
+        }
+        fft_wave<R>(u, s_scr[wave], s_tw, lane);
+        float2* oa = out + (plane * P + r0) * NH;
+        float2* ob = oa + NH;
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const float2 z = u[q];
+            float2 m = shfl2(u[R - 1 - q], (64 - lane) & 63);
+            if (lane == 0) m = u[(R - q) % R];
+            float2 A = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+            float2 B = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
+            if (q == 0 && lane == 0) {
+                A = make_float2(z.x, u[R / 2].x);
+                B = make_float2(z.y, u[R / 2].y);
+            }
+            const int k = lane + 64 * q;
+            oa[k] = A;
+            if (has_b) ob[k] = B;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- backward of the FD sensor image
 // (Optics.py:126-128: circular conv + per-image amax).  dotcnt[b][0] += sum g*sensor, dotcnt[b][1] += #(sensor == 1)
 __global__ __launch_bounds__(256) void dot_count_group_kernel(const float* __restrict__ g, const float* __restrict__ sensor,
@@ -668,9 +863,7 @@ int fftconv_fwd_t(const TIN* img, const void* otfT, float* out, void* signs, flo
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
     const float scale = 1.0f / ((float)N * (float)N);
     rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, S1, tw, planes, H, H, ppw);
-    cols_mul_lds_attr<R>();
-    cols_mul_kernel<R><<<dim3(N / 32, planes), 512, (size_t)H * 17 * sizeof(float2), stream>>>(S1, S2, (const float2*)otfT, tw, C, H, 0, H, conj_otf,
-                                                                scale);
+    launch_cols_mul_ic<R>(S1, S2, (const float2*)otfT, tw, C, H, conj_otf, scale, planes, stream);
     if (mode == 0)
         rows_c2r_kernel<R, 0><<<g1, 256, 0, stream>>>(S2, out, (unsigned long long*)signs, partial_max, tw, planes, H,
                                                       ppw, 1.f, P);
@@ -682,7 +875,9 @@ int fftconv_fwd_t(const TIN* img, const void* otfT, float* out, void* signs, flo
 template <int R, typename TIN = float>
 int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
                   const double* dotcnt, const void* otfT, void* g_psf, int is_f64, long sc, long sy, long sx,
-                  float* g_img, void* workspace, int B, int C, hipStream_t stream, int P = 32 * R) {
+                  float* g_img, void* workspace, int B, int C, hipStream_t stream, int P = 32 * R, const float2* sx_saved = nullptr) {
+    // sx_saved: the forward pass's row transform of the image (S1 of fftconv_fwd_t, [planes][P][N / 2]) when the caller kept it: the
+    // backward then skips recomputing it (one rows_r2c pass over the batch)
     constexpr int N = 64 * R, NH = N / 2;
     const float2* tw = (const float2*)ppv_twiddles_f32(N);
     if (!tw) return PPV_ERR_INIT;
@@ -697,15 +892,20 @@ int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, co
     float2* S2 = (float2*)wp;               wp += (size_t)C * N * NH * sizeof(float2);
     float* gemb = (float*)wp;
     const long total = (long)planes * P * P;
-    ic_out_bwd_kernel<R><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(g_sensor, sensor, (const unsigned long long*)signs,
-                                                                             maxv, dotcnt, gr, total, P);
     const int ppw = 4;
     const long pairs = (long)planes * ((P + 1) / 2);
     const unsigned g1 = (unsigned)((pairs + 4 * ppw - 1) / (4 * ppw));
-    rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(gr, SG, tw, planes, P, P, ppw);
+    static const int fused_gr = getenv("PPV_IC_BWD_FUSED") ? atoi(getenv("PPV_IC_BWD_FUSED")) : 1;   // A/B: 0 = ic_out_bwd + rows_r2c (two launches, gr materialised)
+    if (fused_gr) {
+        rows_r2c_icgrad_kernel<R><<<g1, 256, 0, stream>>>(g_sensor, sensor, (const unsigned long long*)signs, maxv, dotcnt, SG, tw, planes, P, ppw);
+    } else {
+        ic_out_bwd_kernel<R><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(g_sensor, sensor, (const unsigned long long*)signs,
+                                                                                 maxv, dotcnt, gr, total, P);
+        rows_r2c_kernel<R><<<g1, 256, 0, stream>>>(gr, SG, tw, planes, P, P, ppw);
+    }
     if (g_psf) {
-        rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, SX, tw, planes, P, P, ppw);
-        cols_corr_acc_kernel<R><<<dim3(R >= 16 ? N / 16 : N / 32, C, (B + bchunk - 1) / bchunk), 512, 0, stream>>>(SX, SG, part, tw, B, C, P, P,
+        if (!sx_saved) rows_r2c_kernel<R, TIN><<<g1, 256, 0, stream>>>(img, SX, tw, planes, P, P, ppw);
+        cols_corr_acc_kernel<R><<<dim3(R >= 16 ? N / 16 : N / 32, C, (B + bchunk - 1) / bchunk), 512, 0, stream>>>(sx_saved ? sx_saved : SX, SG, part, tw, B, C, P, P,
                                                                                            bchunk);
         cols_inv_from_T_kernel<R><<<(unsigned)((C * NH + 3) / 4), 256, 0, stream>>>(part, S2, tw, C, (B + bchunk - 1) / bchunk,
                                                                                   1.0f / ((float)N * (float)N));
@@ -720,9 +920,7 @@ int fftconv_bwd_t(const TIN* img, const float* g_sensor, const float* sensor, co
     }
     if (g_img) {   // adjoint convolution (Utils.py:285-286): SG x conj(OTF) -> plain P x P crop
         float2* S2b = SX;   // SX is free again (or unused)
-        cols_mul_lds_attr<R>();
-        cols_mul_kernel<R><<<dim3(N / 32, planes), 512, (size_t)P * 17 * sizeof(float2), stream>>>(SG, S2b, (const float2*)otfT, tw, C, P, 0, P, 1,
-                                                                    1.0f / ((float)N * (float)N));
+        launch_cols_mul_ic<R>(SG, S2b, (const float2*)otfT, tw, C, P, 1, 1.0f / ((float)N * (float)N), planes, stream);
         rows_c2r_kernel<R, 2><<<g1, 256, 0, stream>>>(S2b, g_img, nullptr, nullptr, tw, planes, P, ppw, 1.f, P);
     }
     return ppv_last_error();
@@ -823,15 +1021,15 @@ size_t ppv_fftconv_ic_bwd_workspace_bytes_p(int B, int C, int P, int N) {
 }
 int ppv_fftconv_ic_bwd_p(const void* img, int u8, const float* g_sensor, const float* sensor, const void* signs, const float* maxv,
                          const double* dotcnt, const void* otfT, void* g_psf, int g_psf_is_f64, long sc, long sy, long sx,
-                         float* g_img, void* workspace, int B, int C, int P, int N, hipStream_t stream) {
+                         float* g_img, void* workspace, const void* sx_saved, int B, int C, int P, int N, hipStream_t stream) {
     if (!img || !g_sensor || !sensor || !signs || !maxv || !dotcnt || !workspace) return PPV_ERR_NULL;
     if (g_img && (!otfT || u8)) return g_img && u8 ? PPV_ERR_BAD_SIZE : PPV_ERR_NULL;
     if (P < 2 || P % 2 || 2 * P > N) return PPV_ERR_BAD_SIZE;
 #define PPV_IC_BWD(R_)                                                                                                           \
     return u8 ? fftconv_bwd_t<R_, unsigned char>((const unsigned char*)img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf,   \
-                                                  g_psf_is_f64, sc, sy, sx, nullptr, workspace, B, C, stream, P)                    \
+                                                  g_psf_is_f64, sc, sy, sx, nullptr, workspace, B, C, stream, P, (const float2*)sx_saved) \
               : fftconv_bwd_t<R_>((const float*)img, g_sensor, sensor, signs, maxv, dotcnt, otfT, g_psf, g_psf_is_f64, sc, sy, sx, \
-                                  g_img, workspace, B, C, stream, P)
+                                  g_img, workspace, B, C, stream, P, (const float2*)sx_saved)
     if (N == 1024) PPV_IC_BWD(16);
     if (N == 512) PPV_IC_BWD(8);
     if (N == 256) PPV_IC_BWD(4);

@@ -68,6 +68,7 @@ def fftconv_ic_fwd(img, otf, N):
     signs = torch.zeros(B * C * P * (N // 128), dtype=torch.int64, device=dev)          # row P-1 is never written
     check(L.ppv_fftconv_ic_fwd_p(ptr(img), int(img.dtype == torch.uint8), ptr(otf), ptr(out), ptr(signs), ptr(partial), ptr(ws),
                                  B, C, P, N, stream_ptr()), "ppv_fftconv_ic_fwd_p")
+    fftconv_ic_fwd.last_workspace = ws          # its first B*C*P*(N/2) float2 = the row transform of the image (backward can reuse it)
     return out, signs, partial
 
 

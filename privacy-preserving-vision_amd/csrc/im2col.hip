@@ -1,7 +1,8 @@
 // Patch rows for the weight gradient of convolutions with very few input channels (the 3-channel image convolutions of the StarGAN-v2
 // blocks, Face-DeId/core/model.py:12-53 autograd): x [B,H,W,C] f32 NHWC -> rows [B*Ho*Wo][Kp] bf16 with column (r * S + s) * C + c =
 // x[b, ho * stride - pad + r, wo * stride - pad + s, c] (0 outside the image, 0 in the padding columns K .. Kp-1), in one of the two
-// halves of the bf16 split: part 0 = hi = bf16(x), part 1 = lo = bf16(x - hi).  The R x S x C gradient then is a 1x1 weight gradient with
+// terms of the bf16 split: part 0 = hi = bf16(x), part 1 = mid = bf16(x - hi), part 2 = lo = bf16(x - hi - mid)
+// (the third term of the six-product form, nn_ops.conv2d_f32(exact=True)).  The R x S x C gradient then is a 1x1 weight gradient with
 // Kp "channels" on the MFMA kernel (ppv_conv_wgrad): the same K-padding idea as the trunk's 7x7 stem (conv_wgrad_stem.hip).
 #include <hip/hip_runtime.h>
 #include "ppv_common.h"
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
         if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = x[(((long)b * H + h) * W + w) * C + c];
     }
     const unsigned short hi = f2bf(v);
-    out[i] = part == 0 ? hi : f2bf(v - bf2f(hi));
+    const float r1 = v - bf2f(hi);
+    out[i] = part == 0 ? hi : part == 1 ? f2bf(r1) : f2bf(r1 - bf2f(f2bf(r1)));
 }
 
 // channel-padded halves of the bf16 split of an NHWC f32 tensor: x [rows][C] -> out [rows][Cp], part as above
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(256) void pad_split_kernel(const float* __restrict_
     const int c = (int)(i % Cp);
     const float v = c < C ? x[(i / Cp) * C + c] : 0.f;
     const unsigned short hi = f2bf(v);
-    out[i] = part == 0 ? hi : f2bf(v - bf2f(hi));
+    const float r1 = v - bf2f(hi);
+    out[i] = part == 0 ? hi : part == 1 ? f2bf(r1) : f2bf(r1 - bf2f(f2bf(r1)));
 }
 }  // namespace
 
@@ -51,7 +54,7 @@ extern "C" {
 int ppv_im2col_split(const float* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int Kp,
                      int part, hipStream_t stream) {
     if (!x || !out) return PPV_ERR_NULL;
-    if (B < 1 || C < 1 || R < 1 || S < 1 || Kp < R * S * C || stride < 1 || (part != 0 && part != 1)) return PPV_ERR_BAD_SIZE;
+    if (B < 1 || C < 1 || R < 1 || S < 1 || Kp < R * S * C || stride < 1 || (part < 0 || part > 2)) return PPV_ERR_BAD_SIZE;
     const long tot = (long)B * Ho * Wo * Kp;
     im2col_split_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, (unsigned short*)out, B, H, W, C, Ho, Wo, R, S, stride, pad, Kp, part);
     return ppv_last_error();
@@ -59,7 +62,7 @@ int ppv_im2col_split(const float* x, void* out, int B, int H, int W, int C, int 
 
 int ppv_pad_split(const float* x, void* out, long rows, int C, int Cp, int part, hipStream_t stream) {
     if (!x || !out) return PPV_ERR_NULL;
-    if (rows < 1 || C < 1 || Cp < C || (part != 0 && part != 1)) return PPV_ERR_BAD_SIZE;
+    if (rows < 1 || C < 1 || Cp < C || part < 0 || part > 2) return PPV_ERR_BAD_SIZE;
     pad_split_kernel<<<(unsigned)((rows * Cp + 255) / 256), 256, 0, stream>>>(x, (unsigned short*)out, rows, C, Cp, part);
     return ppv_last_error();
 }

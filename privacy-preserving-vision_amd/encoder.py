@@ -1100,14 +1100,16 @@ class Encoder(nn.Module):
                 taps.append(y)
         return torch.nn.functional.adaptive_avg_pool2d(y.permute(0, 3, 1, 2), self.enc_image_size).permute(0, 2, 3, 1).contiguous()
 
-    def forward_fp32_train(self, images):
+    def forward_fp32_train(self, images, exact=False):
         """fp32-accurate TRAINING pass of the trunk (parity instrument, not the product path): like forward_fp32_accurate every
         convolution runs on the hand-written MFMA kernels as three bf16 products accumulated in f32 -- forward, data gradient AND
         weight gradient (ppv_amd.nn_ops.conv2d_f32, accurate_wgrad) -- with f32 activations end to end; train-mode BatchNorm (batch
         statistics, biased variance: models.py:31-41 under train.py:245), ReLU, the residual adds and the pools are f32 torch
         element-wise / reduction ops on the device, differentiated by autograd.  Running statistics are NOT updated.  images
         [B,3,H,W] -> [B,E,E,2048] f32 attached to the graph: BASELINE configs[0] (batch 4, fp32) has a reference-precision step on
-        the GPU whose lens gradient can be held against the CPU reference tightly (tests/test_config0_gpu.py)."""
+        the GPU whose lens gradient can be held against the CPU reference tightly (tests/test_config0_gpu.py).  exact=True: every
+        convolution as SIX bf16 products of a three-way operand split (~2^-24 per product, f32 level; nn_ops.conv2d_f32(exact=True)):
+        the random-init train-mode trunk amplifies the 2^-16 of the three-product form to 1e-2 at the output."""
         from .nn_ops import conv2d_f32
         F_ = torch.nn.functional
         if not images.is_cuda:
@@ -1124,11 +1126,11 @@ class Encoder(nn.Module):
 
         def conv(t, rec):
             w = rec.conv.weight
-            return conv2d_f32(t, w, None, rec.stride, rec.pad, weight_grad=w.requires_grad, accurate_wgrad=True)
+            return conv2d_f32(t, w, None, rec.stride, rec.pad, weight_grad=w.requires_grad, accurate_wgrad=True, exact=exact)
 
         st = self._stem
         w0 = F_.pad(st.conv.weight, (0, 0, 0, 0, 0, 5))
-        y = bn(conv2d_f32(x, w0, None, 2, 3, weight_grad=st.conv.weight.requires_grad, accurate_wgrad=True), st.bn)
+        y = bn(conv2d_f32(x, w0, None, 2, 3, weight_grad=st.conv.weight.requires_grad, accurate_wgrad=True, exact=exact), st.bn)
         y = F_.max_pool2d(y.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
         for r1, r2, r3, rd in self._blocks:
             o = bn(conv(y, r1), r1.bn)

@@ -27,7 +27,7 @@ def _pad_to(t, dim, mult):
     return F.pad(t, pad)
 
 
-def _layouts(w):
+def _layouts(w, exact=False):
     """(forward GEMM rows over the split input, data-gradient GEMM rows over the split gradient) of conv weight [Cout,Cin,R,S].
     Cached per weight OBJECT: an entry lives exactly as long as the tensor it was built from (its weak reference drops the entry when
     the tensor dies, so a recycled id() can never return another tensor's layout and layouts of dead models are released) and is
@@ -37,15 +37,25 @@ def _layouts(w):
     key = id(w)
     ent = _wcache.get(key)
     ver = (w._version, w.data_ptr(), w.device)
-    if ent is None or ent[0] != ver or ent[3]() is not w:
+    if ent is None or ent[0] != ver or ent[3]() is not w or (exact and ent[4] is None):
         wf = w.detach().float()
         hi = wf.bfloat16().float()
         lo = (wf - hi).bfloat16().float()
         fwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=1), 1, 64), 0, 64)                # [Coutp, pad64(3 Cin), R, S]
         bwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=0), 0, 64), 1, 64)                # [pad64(3 Cout), Cinp, R, S]
+        second = None
+        if exact:
+            # the other three of the six products of a three-way split (x = h + m + l, W = H + M + L; `lo` above is M):
+            # [x_l | x_h | x_m] against [W_H | W_L | W_M]
+            l3 = (wf - hi - lo).bfloat16().float()
+            fwd2 = _pad_to(_pad_to(torch.cat([hi, l3, lo], dim=1), 1, 64), 0, 64)
+            bwd2 = _pad_to(_pad_to(torch.cat([hi, l3, lo], dim=0), 0, 64), 1, 64)
+            second = (co.weight_layout(fwd2.contiguous(), 0), co.weight_layout(bwd2.contiguous(), 1))
         ent = (ver, co.weight_layout(fwd.contiguous(), 0), co.weight_layout(bwd.contiguous(), 1),
-               weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)))
+               weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), second)
         _wcache[key] = ent
+    if exact:
+        return ent[1], ent[2], ent[4][0], ent[4][1]
     return ent[1], ent[2]
 
 
@@ -65,7 +75,18 @@ def _split3(t):
     return y
 
 
-def _wgrad_padded(gy, x, wshape, stride, pad):
+def _split3b(t):
+    """[l | h | m] of the three-way bf16 split t = h + m + l (h = bf16(t), m = bf16(t - h), l = bf16(t - h - m)), zero padded to a
+    multiple of 64 channels: the operand of the SECOND convolution of conv2d_f32(exact=True).  Element-wise torch ops (a parity
+    instrument, not a hot path)."""
+    h = t.bfloat16()
+    r = t - h.float()
+    m = r.bfloat16()
+    l = (r - m.float()).bfloat16()
+    return _pad_to(torch.cat([l, h, m], dim=-1), 3, 64).contiguous()
+
+
+def _wgrad_padded(gy, x, wshape, stride, pad, exact=False):
     """Weight gradient [Cout,Cin,R,S] f32 of an NHWC f32 convolution with ANY channel counts on the MFMA weight-gradient kernel
     (ppv_conv_wgrad wants multiples of 128): both operands as bf16-split halves stacked along the batch, x -> [hi; lo; hi], gy ->
     [hi; hi; lo] (the sum over the batch then holds x_hi g_hi + x_lo g_hi + x_hi g_lo: the f32 product to ~2^-16), zero-padded to 128
@@ -77,21 +98,24 @@ def _wgrad_padded(gy, x, wshape, stride, pad):
     L = _lib.lib()
     dev = x.device
     Np = (Cout + 127) // 128 * 128
-    gs = torch.empty((3 * B, Ho, Wo, Np), dtype=torch.bfloat16, device=dev)
+    # exact: all six products of the three-way split, x -> [h; m; h; l; h; m] against gy -> [h; h; m; h; l; m] (~2^-24 per product)
+    gparts, xparts = ((0, 0, 1, 0, 2, 1), (0, 1, 0, 2, 0, 1)) if exact else ((0, 0, 1), (0, 1, 0))
+    T = len(gparts)
+    gs = torch.empty((T * B, Ho, Wo, Np), dtype=torch.bfloat16, device=dev)
     rows_g = B * Ho * Wo
-    for j, part in enumerate((0, 0, 1)):
+    for j, part in enumerate(gparts):
         check(L.ppv_pad_split(ptr(gy), gs[j * B].data_ptr(), rows_g, Cout, Np, part, stream_ptr()), "ppv_pad_split")
     if Cin < 32 and R * S * Cin <= 512:
         Kp = (R * S * Cin + 127) // 128 * 128
-        xs = torch.empty((3 * B, Ho, Wo, Kp), dtype=torch.bfloat16, device=dev)
-        for j, part in enumerate((0, 1, 0)):
+        xs = torch.empty((T * B, Ho, Wo, Kp), dtype=torch.bfloat16, device=dev)
+        for j, part in enumerate(xparts):
             check(L.ppv_im2col_split(ptr(x), xs[j * B].data_ptr(), B, H, W, Cin, Ho, Wo, R, S, stride, pad, Kp, part, stream_ptr()),
                   "ppv_im2col_split")
         gw = co.conv_wgrad(gs, xs, 1, 1, 1, 0)                                   # [Np, Kp, 1, 1]
         return gw.view(Np, Kp)[:Cout, :R * S * Cin].reshape(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
     Cp = (Cin + 127) // 128 * 128
-    xs = torch.empty((3 * B, H, W, Cp), dtype=torch.bfloat16, device=dev)
-    for j, part in enumerate((0, 1, 0)):
+    xs = torch.empty((T * B, H, W, Cp), dtype=torch.bfloat16, device=dev)
+    for j, part in enumerate(xparts):
         check(L.ppv_pad_split(ptr(x), xs[j * B].data_ptr(), B * H * W, Cin, Cp, part, stream_ptr()), "ppv_pad_split")
     gw = co.conv_wgrad(gs, xs, R, S, stride, pad)                                # [Np, Cp, R, S]
     return gw[:Cout, :Cin].contiguous()
@@ -99,14 +123,17 @@ def _wgrad_padded(gy, x, wshape, stride, pad):
 
 class _ConvF32(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, wf, wd, accurate_wgrad=False):
+    def forward(ctx, x, weight, bias, stride, pad, wf, wd, accurate_wgrad=False, second=None):
         _lib.require_cuda(x, weight)
         ctx.accurate_wgrad = accurate_wgrad
         x = x.contiguous().float()
         Cout, Cin, R, S = weight.shape
         assert R == S and x.shape[-1] == Cin
         ctx.wd = wd
+        ctx.wd2 = second[1] if second is not None else None
         y = co.conv_fwd(_split3(x), wf, stride, pad, out_f32=True)
+        if second is not None:                       # exact: the three remaining products of the three-way split
+            y = y + co.conv_fwd(_split3b(x), second[0], stride, pad, out_f32=True)
         if y.shape[-1] != Cout:
             y = y[..., :Cout].contiguous()
         if bias is not None:
@@ -124,28 +151,39 @@ class _ConvF32(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = co.conv_dgrad(_split3(gy), ctx.wd, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
+            if ctx.wd2 is not None:
+                gx = gx + co.conv_dgrad(_split3b(gy), ctx.wd2, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
             if gx.shape[-1] != Cin:
                 gx = gx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
             if Cout % 128 == 0 and Cin % 128 == 0 and not ctx.accurate_wgrad:
                 gw = co.conv_wgrad(gy.bfloat16(), x.bfloat16(), R, S, stride, pad)
             else:                                       # outside the MFMA weight-gradient kernel's tiles (3- and 64-channel layers)
-                gw = _wgrad_padded(gy, x, weight.shape, stride, pad)
+                gw = _wgrad_padded(gy, x, weight.shape, stride, pad, exact=ctx.wd2 is not None)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(dim=(0, 1, 2))
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def conv2d_f32(x, weight, bias=None, stride=1, pad=0, weight_grad=True, accurate_wgrad=False):
+def conv2d_f32(x, weight, bias=None, stride=1, pad=0, weight_grad=True, accurate_wgrad=False, exact=False):
     """x [B,H,W,Cin] f32 NHWC, weight [Cout,Cin,k,k] (torch layout, e.g. an nn.Conv2d's parameter) -> [B,Ho,Wo,Cout] f32.
     weight_grad=False: the weight (and bias) are treated as constants whatever their requires_grad says (a frozen network, FAN in
     core/wing.py:262-272) -- the bf16 layouts stay cached on the Parameter object itself.  accurate_wgrad: the weight gradient from
     the bf16-split operands (~2^-16) for every shape (default: one bf16 product where the channel counts fit the kernel's tiles)."""
-    wf, wd = _layouts(weight)
+    if exact:
+        # reference precision: a THREE-way bf16 split of both operands and all six products that matter (h H, m H, h M, l H, h L, m M;
+        # the dropped ones are <= 2^-32 of the product), i.e. ~2^-24 per product -- f32 -- instead of 2^-16, as a second convolution
+        # over [x_l | x_h | x_m] against [W_H | W_L | W_M]; forward, data gradient and weight gradient (parity instrument: 2x the work)
+        wf, wd, wf2, wd2 = _layouts(weight, exact=True)
+        second = (wf2, wd2)
+        accurate_wgrad = True
+    else:
+        wf, wd = _layouts(weight)
+        second = None
     if not weight_grad:
         weight = weight.detach()
         bias = None if bias is None else bias.detach()
-    return _ConvF32.apply(x, weight, bias, stride, pad, wf, wd, accurate_wgrad)
+    return _ConvF32.apply(x, weight, bias, stride, pad, wf, wd, accurate_wgrad, second)
 
 
 class _InstNormAct(torch.autograd.Function):

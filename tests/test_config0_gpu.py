@@ -112,3 +112,24 @@ def test_one_training_iteration_batch4_matches_the_oracle():
             worst = min(worst, _cos(p.grad, ref_grads[n].grad))
     print(f"fp32 training pass: smallest cosine of a convolution weight gradient vs oracle {worst:.5f}")
     assert worst > 0.95            # measured 0.9615 (a layer-2 convolution); the bf16 product path gives 0.3-0.9 on the same layers
+
+    # ---- and with SIX products per convolution (three-way operand split, ~2^-24 per product: nn_ops.conv2d_f32(exact=True); VERDICT r4
+    # missing #4): the reference trains the trunk in fp32 (models.py:31-41) -- at f32-level products the GPU step must reproduce the CPU
+    # reference's encoder output, full-loss lens gradient and every convolution weight gradient
+    for p in encoder.parameters():
+        p.grad = None
+    camera.zernike_coeffs_train.grad = None
+    s_x, _, _, lp_x = camera(img.to(dev), None, "3", noise_u01=noise.to(dev))
+    out_x = encoder.forward_fp32_train(s_x, exact=True)
+    loss_x = loss_of(out_x, s_x, img.to(dev), lp_x)
+    loss_x.backward()
+    g_x = camera.zernike_coeffs_train.grad.cpu().flatten()
+    cos_x, rl2_x = _cos(g_x, g_o), ((g_x.double() - g_o.double()).norm() / g_o.double().norm()).item()
+    out_err_x = ((out_x.detach().cpu().double() - out_o.detach().double()).abs().max() / out_o.detach().abs().max()).item()
+    worst_x = 1.0
+    for n, p in encoder.named_parameters():
+        if p.requires_grad and p.dim() == 4:
+            worst_x = min(worst_x, _cos(p.grad, ref_grads[n].grad))
+    print(f"six-product training pass: encoder output {out_err_x:.2e}; lens gradient vs oracle (full loss): cos {cos_x:.6f}, rel L2 {rl2_x:.3e}; "
+          f"smallest weight-gradient cosine {worst_x:.5f}")
+    assert out_err_x < out_err and cos_x > 0.999 and rl2_x < 5e-2 and worst_x > 0.99

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void ic_out_bwd_kernel(const float* __restrict
 }
 
 // ic_out_bwd_kernel fused into the row transform of the gradient (round 5): the value ic_out_bwd_kernel would store at gr[plane][s][t]
-// is computed by the lane that feeds it to the FFT -- same expression, same order of additions, so SG is bit-identical -- and the
+// is computed by the lane that feeds it to the FFT -- same terms, same order of additions -- and the
 // [B, C, P, P] f32 tensor gr is neither written nor re-read (one launch and 2 x 4 B per pixel less).  Row s >= 1 reads row s + 1 of g /
 // sensor shifted by one column (a coalesced load, 4 bytes off alignment), row 0 reads rows 0 and 1.
 template <int R>
@@ -658,16 +658,22 @@ __global__ __launch_bounds__(256) void rows_r2c_icgrad_kernel(const float* __res
     const int ppp = (P + 1) >> 1;
     const long total = (long)planes * ppp;
     const long first = ((long)blockIdx.x * 4 + wave) * ppw;
+    // one term (g - [sensor == 1] share) / M per source pixel; pixel (s, t) of gr collects the 1, 2 or 4 sensor pixels the reference's
+    // nearest P-1 -> P index map duplicates it into: (s + 1, t + 1), column 0 too for t == 0, row 0 too for s == 0 (the interior pixel
+    // takes one load of each tensor: no data-dependent loop in the common path)
+    auto term = [&](long row, int j) -> float {
+        const long o = row * P + j;
+        return (g[o] - ((sensor[o] == 1.f) ? share : 0.f)) / M;
+    };
     auto grval = [&](long plane, int s, int t) -> float {
         if (s >= P - 1 || t >= P - 1) return 0.f;
-        const int i0 = (s == 0) ? 0 : s + 1, i1 = s + 1, j0 = (t == 0) ? 0 : t + 1, j1 = t + 1;
         float acc = 0.f;
-        for (int i = i0; i <= i1; ++i)
-            for (int j = j0; j <= j1; ++j) {
-                const long o = (plane * P + i) * P + j;
-                const float gv = g[o] - ((sensor[o] == 1.f) ? share : 0.f);
-                acc += gv / M;
-            }
+        if (s == 0) {
+            if (t == 0) acc += term(plane * P, 0);
+            acc += term(plane * P, t + 1);
+        }
+        if (t == 0) acc += term(plane * P + s + 1, 0);
+        acc += term(plane * P + s + 1, t + 1);
         const unsigned long long bits = signs[(plane * P + s) * (R / 2) + (t >> 6)];
         return ((bits >> (t & 63)) & 1ull) ? -acc : acc;
     };

@@ -81,11 +81,10 @@ class _IcSensorFn(torch.autograd.Function):
         N = fc.ic_transform_length(P)          # 2 P for the 128 / 256 patches, the next of 256 / 512 / 1024 otherwise (same convolution)
         img = img.contiguous()
         otf = fc.otf_build(psf.detach()[0].permute(2, 0, 1), P, N)
-        out, signs, partial = fc.fftconv_ic_fwd(img, otf, N)
+        out, signs, partial, ws = fc.fftconv_ic_fwd(img, otf, N, return_workspace=True)
         # the forward workspace starts with the row transform of the image: kept (2 x 0.2 GB at B = 128) when the PSF needs a gradient,
         # so that backward does not recompute it (PPV_IC_KEEP_ROWS=0: recompute)
-        ctx.rows_ws = fc.fftconv_ic_fwd.last_workspace if (ctx.needs_input_grad[1] and os.environ.get("PPV_IC_KEEP_ROWS", "1") != "0") else None
-        fc.fftconv_ic_fwd.last_workspace = None
+        ctx.rows_ws = ws if (ctx.needs_input_grad[1] and os.environ.get("PPV_IC_KEEP_ROWS", "1") != "0") else None
         m = fc.group_max(partial, 1)
         if cam.global_max_sync and torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)

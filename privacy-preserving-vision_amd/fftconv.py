@@ -53,9 +53,10 @@ def ic_transform_length(P):
     raise ValueError("patch sizes above 512 are outside the image convolution kernels (1024-point transforms)")
 
 
-def fftconv_ic_fwd(img, otf, N):
+def fftconv_ic_fwd(img, otf, N, return_workspace=False):
     """IC sensor convolution (Utils.py:251-297), img [B,C,P,P] f32 or uint8, any even P with 2 P <= N in {256, 512, 1024}
-    -> (|conv| [B,C,P,P], signs, partial_max)."""
+    -> (|conv| [B,C,P,P], signs, partial_max[, workspace]).  The workspace starts with the row transform of the image
+    (B*C*P*(N/2) float2), which ppv_fftconv_ic_bwd_p can take back instead of recomputing it."""
     _lib.require_cuda(img, otf)
     img = img.contiguous()
     B, C, P, W = img.shape
@@ -68,8 +69,7 @@ def fftconv_ic_fwd(img, otf, N):
     signs = torch.zeros(B * C * P * (N // 128), dtype=torch.int64, device=dev)          # row P-1 is never written
     check(L.ppv_fftconv_ic_fwd_p(ptr(img), int(img.dtype == torch.uint8), ptr(otf), ptr(out), ptr(signs), ptr(partial), ptr(ws),
                                  B, C, P, N, stream_ptr()), "ppv_fftconv_ic_fwd_p")
-    fftconv_ic_fwd.last_workspace = ws          # its first B*C*P*(N/2) float2 = the row transform of the image (backward can reuse it)
-    return out, signs, partial
+    return (out, signs, partial, ws) if return_workspace else (out, signs, partial)
 
 
 def group_max(partial, groups):

@@ -26,17 +26,6 @@ BF16, F32 = torch.bfloat16, torch.float32
 _UNSUPPORTED = object()                    # marks a geometry in Encoder._plans that TrunkPlan refused
 
 
-class _DictRef:
-    """A dict cannot be weakly referenced; the plan only needs to ask its table "am I still current?" and must not keep it alive."""
-    __slots__ = ("_d",)
-
-    def __init__(self, d):
-        self._d = d
-
-    def __call__(self):
-        return self._d
-
-
 _NF = len(_lib.TRUNK_CONV_FIELDS)          # pointers per convolution record
 _WT, _WD, _GAMMA, _BETA, _RM, _RV, _DW, _DG, _DB = range(_NF)
 
@@ -69,8 +58,9 @@ class _LeaseHolder:
             except Exception:                         # interpreter shutdown
                 lease.free_event = None
             plan = lease.plan
-            if plan.owner is not None and plan.owner().get(plan.key) is not plan:
-                return                    # the plan has been replaced (other requires_grad pattern / parameter list): its arena is not pooled
+            enc = plan.owner() if plan.owner is not None else None      # weak: the plan must not keep its encoder (or its plan table) alive
+            if plan.owner is not None and (enc is None or enc.__dict__.get("_plans", {}).get(plan.key) is not plan):
+                return                    # the plan has been replaced (other requires_grad pattern / parameter list) or its encoder is gone: the arena is not pooled
             plan.free.append(lease)
 
     def retake(self):
@@ -253,7 +243,7 @@ def get_plan(enc, B, H, W, plist):
             plans[key] = _UNSUPPORTED
             return None
         plan.plist = plist                # the list object itself (Encoder._param_list rebuilds it when Parameter objects are replaced)
-        plan.key, plan.owner = key, _DictRef(plans)
+        plan.key, plan.owner = key, weakref.ref(enc)
         plans[key] = plan
     return plan
 

@@ -249,9 +249,66 @@ def _load_profile(path):
     return d, False
 
 
+_LIVE = {}          # "pmc": dict, "mfma": dict -- counter profiles collected in THIS run by live_counter_passes()
+
+
+def live_counter_passes(budget_s=240):
+    """The PMC counters of the roofline object measured in the driver's own run (they used to be read from committed
+    JSON only).  Counters cannot be read inside this process, so rank 0 starts child runs of this script under rocprofv3 -- the program
+    itself behind `--`, one counter group per pass as MI355X_MICROARCH.md prescribes, every launch serialised (PPV_WGRAD_SIDE=0): a
+    kernel-trace pass for the durations, FETCH_SIZE, WRITE_SIZE and the MFMA-busy pass -- and folds their CSVs with tools/collect_pmc.py /
+    collect_mfma.py.  Any failure (no rocprofv3, a pass over its time budget) leaves _LIVE empty: the line then falls back to the
+    committed profiles and says so ("pmc_source")."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return
+    t_start = time.perf_counter()
+    tools = os.path.join(ROOT, "tools")
+    td = tempfile.mkdtemp(prefix="ppv_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PPV_WGRAD_SIDE="0")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-dense", "--no-roofline",
+             "--no-configs", "--no-live-pmc"]
+    passes = {"stats": ["--kernel-trace", "--stats"], "fetch": ["--pmc", "FETCH_SIZE"], "write": ["--pmc", "WRITE_SIZE"],
+              "mfma": ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"]}
+    found = {}
+    try:
+        for name, flags in passes.items():
+            left = budget_s - (time.perf_counter() - t_start)
+            if left < 20:
+                return
+            out = os.path.join(td, name)
+            r = subprocess.run(["rocprofv3"] + flags + ["--output-format", "csv", "-d", out, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=left)
+            pat = "*kernel_stats.csv" if name == "stats" else "*counter_collection.csv"
+            hits = glob.glob(os.path.join(out, "**", pat), recursive=True)
+            if r.returncode != 0 or not hits:
+                print(f"[bench] live counter pass '{name}' failed (rc {r.returncode}): falling back to the committed profiles", file=sys.stderr, flush=True)
+                return
+            found[name] = hits[0]
+        pj, mj = os.path.join(td, "pmc.json"), os.path.join(td, "mfma.json")
+        a = subprocess.run([sys.executable, os.path.join(tools, "collect_pmc.py"), found["fetch"], found["write"], pj], capture_output=True, text=True)
+        b = subprocess.run([sys.executable, os.path.join(tools, "collect_mfma.py"), found["mfma"], found["stats"], mj], capture_output=True, text=True)
+        if a.returncode == 0 and b.returncode == 0:
+            _LIVE["pmc"], _LIVE["mfma"] = json.load(open(pj)), json.load(open(mj))
+            _LIVE["seconds"] = round(time.perf_counter() - t_start, 1)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] live counter passes: {e!r}: falling back to the committed profiles", file=sys.stderr, flush=True)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def _step_hbm(sec_per_step):
-    """Whole-step HBM view: bytes per step from the committed PMC passes (same workload, same kernel sources) over the measured
-    step time."""
+    """Whole-step HBM view: bytes per step from the PMC passes (this run's live passes when they ran, else the committed ones of the
+    same workload and kernel sources) over the measured step time."""
+    if "pmc" in _LIVE:
+        d = _LIVE["pmc"]
+        gb = d["total_fetch_GB_per_step"] + d["total_write_GB_per_step"]
+        tbs = gb / 1e3 / sec_per_step
+        return {"GB_per_step_pmc": round(gb, 1), "pmc_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run", "TB_per_s": round(tbs, 2),
+                "frac_of_8TBps_peak": round(tbs / 8.0, 3), "frac_of_6.3TBps_measured_copy_rate": round(tbs / 6.3, 3)}
     pmc = _latest_profile("_pmc_traffic.json")
     d, stale = _load_profile(pmc)
     if d is None:
@@ -320,9 +377,13 @@ def roofline_of_dominant_kernel(step):
     match = _class_kernels(dom)
     traffic = mfma_busy = None
     pmc_file, mu_file = _latest_profile("_pmc_traffic.json"), _latest_profile("_mfma_util.json")
-    pmc_d, stale_a = _load_profile(pmc_file)
-    mu_d, stale_b = _load_profile(mu_file)
-    stale = stale_a or stale_b
+    if "pmc" in _LIVE:                                          # this run's own counter passes
+        pmc_d, mu_d, stale = _LIVE["pmc"], _LIVE["mfma"], False
+        pmc_file = mu_file = None
+    else:
+        pmc_d, stale_a = _load_profile(pmc_file)
+        mu_d, stale_b = _load_profile(mu_file)
+        stale = stale_a or stale_b
     try:
         pk = pmc_d["per_kernel"]
         tot_b = tot_n = 0.0
@@ -347,6 +408,7 @@ def roofline_of_dominant_kernel(step):
         mfma_busy = None
     return {"bound": "mfma", "kernel": dom, "chosen_by": "largest share of device time among the MFMA launch classes",
             "mfma_busy_frac_pmc": mfma_busy, "pmc_files": [os.path.basename(f) for f in (pmc_file, mu_file) if f],
+            "pmc_source": (f"live: four rocprofv3 child passes of this run ({_LIVE.get('seconds')} s)" if "pmc" in _LIVE else "committed profiles/ (hash-guarded)"),
             "stale": stale,   # true: the committed counter profiles were taken on other kernel sources -> traffic / mfma_busy are null
             "measured_in": "one extra step with every launch serialised on one stream (kernel alone on the device)", "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "launches_per_step": n,
@@ -487,6 +549,8 @@ def main():
                     help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
                          "default is the headline Camera+ResNet-101 metric")
     ap.add_argument("--ssim", action="store_true", help="camera_loss = 'SSIM' (fused SSIM kernels) instead of the default MSE")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not start the rocprofv3 child passes that measure roofline.traffic / "
+                    "mfma_busy / step_hbm in this run (the committed profiles are used instead)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side legs of the default run (BASELINE.json configs 2, 3, 4 under "
                     "the line's \"configs\" key)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4],
@@ -599,6 +663,10 @@ def main():
             encoder.lazy_output = lazy0
             os.environ.pop("PPV_BENCH_DENSE_HEAD", None)
 
+    if (rank == 0 and world == 1 and not args.no_live_pmc and not args.no_roofline and not args.no_dense and not args.decoder and not args.ssim
+            and not use_graph and args.batch == 128 and os.environ.get("PPV_BENCH_LIVE_PMC", "1") != "0"):
+        torch.cuda.synchronize()
+        live_counter_passes()
     roof = None if args.no_roofline else roofline_of_dominant_kernel(eager_step)
     side_configs = None
     if world == 1 and not args.decoder and not args.ssim and not use_graph and not args.no_configs and not args.no_dense and args.batch == 128:

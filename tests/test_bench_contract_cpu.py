@@ -58,3 +58,30 @@ def test_hash_changes_with_the_sources(tmp_path):
     h1 = csrc_hash(str(tmp_path))
     (d / "a.hip").write_text("y")
     assert csrc_hash(str(tmp_path)) != h1
+
+
+def test_live_counter_passes_take_precedence_and_fall_back_cleanly(monkeypatch):
+    """bench.py measures roofline.traffic / step_hbm in its own run (rocprofv3 child passes, round 5); where rocprofv3 is missing the
+    call leaves nothing behind and the committed profiles are used; a live result overrides them and is labelled."""
+    b = _bench()
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    b._LIVE.clear()
+    b.live_counter_passes()
+    assert b._LIVE == {}
+    b._LIVE["pmc"] = {"total_fetch_GB_per_step": 60.0, "total_write_GB_per_step": 32.0, "per_kernel": {}}
+    b._LIVE["mfma"] = {"per_kernel": {}}
+    h = b._step_hbm(0.0224)
+    assert h["GB_per_step_pmc"] == 92.0 and h["pmc_source"].startswith("live") and abs(h["TB_per_s"] - 4.11) < 0.01
+    b._LIVE.clear()
+
+
+def test_ic_transform_length_is_the_next_native_length():
+    """Patch sizes off the 128 / 256 grid run on the next 256 / 512 / 1024-point transform (>= 2 P: the linear convolution of two P x P
+    supports fits); above 512 there is no native transform."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import ppv_amd  # noqa: F401
+    import ppv_amd.fftconv as fc
+    assert [fc.ic_transform_length(p) for p in (32, 128, 130, 256, 258, 368, 512)] == [256, 256, 512, 512, 1024, 1024, 1024]
+    with pytest.raises(ValueError):
+        fc.ic_transform_length(514)

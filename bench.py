@@ -183,8 +183,11 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         with torch.cuda.stream(opt_stream) if opt_stream is not None else contextlib.nullcontext():
             grads = [p.grad for p in enc_params]                                  # clip_gradient, train.py:311-316
             if not os.environ.get("PPV_BENCH_NOCLIP"):                            # (diagnostic only: is the optimiser stream on the critical path?)
-                torch._foreach_clamp_min_(grads, -5.0)
-                torch._foreach_clamp_max_(grads, 5.0)
+                if hasattr(encoder, "clip_gradients_") and os.environ.get("PPV_BENCH_FLAT_CLIP", "1") != "0":
+                    encoder.clip_gradients_(5.0)                                  # one pass over the flat gradient buffer (same values)
+                else:
+                    torch._foreach_clamp_min_(grads, -5.0)
+                    torch._foreach_clamp_max_(grads, 5.0)
             opt_enc.step()
             if opt_stream is not None and hasattr(encoder, "prefetch_weight_layouts") and os.environ.get("PPV_WL_PREFETCH", "1") != "0":
                 encoder.prefetch_weight_layouts()      # bf16 GEMM layouts of the updated weights, beside the next camera forward

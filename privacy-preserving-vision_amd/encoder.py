@@ -1139,6 +1139,25 @@ class Encoder(nn.Module):
             y = bn(conv(o, r3), r3.bn, res=idn)
         return F_.adaptive_avg_pool2d(y.permute(0, 3, 1, 2), self.enc_image_size).permute(0, 2, 3, 1).contiguous()
 
+    def clip_gradients_(self, grad_clip):
+        """The reference's ``clip_gradient`` (Image_Caption/utils.py, called at train.py:311-316: ``p.grad.data.clamp_(-c, c)`` for every
+        parameter) on this module's parameters.  The plan executor hands out the gradients as views of ONE flat f32 buffer
+        (trunk_exec): when every gradient is such a view the clamp is ONE element-wise pass over that buffer instead of two
+        multi-tensor passes (clamp_min, clamp_max) over 314 tensors; any other case falls back to those."""
+        grads = [p.grad for p in self.parameters() if p.grad is not None]
+        if not grads:
+            return
+        # (the tensors autograd hands to .grad share the flat buffer's storage but carry no ._base: they are recognised by storage)
+        st = grads[0].untyped_storage()
+        if all(g.dtype == torch.float32 and g.is_contiguous() and g.untyped_storage().data_ptr() == st.data_ptr() for g in grads):
+            lo = min(g.storage_offset() for g in grads)
+            hi = max(g.storage_offset() + g.numel() for g in grads)
+            if sum(g.numel() for g in grads) * 2 > hi - lo:      # dense: the gaps are the few zero padding floats between slices
+                torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,)).clamp_(-grad_clip, grad_clip)
+                return
+        torch._foreach_clamp_min_(grads, -grad_clip)
+        torch._foreach_clamp_max_(grads, grad_clip)
+
     def fine_tune(self, fine_tune=True):
         """models.py:43-54: freeze everything, then un-freeze children [5:] (layer2..4)."""
         for p in self.resnet.parameters():

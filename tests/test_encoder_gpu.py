@@ -569,6 +569,27 @@ def test_replaced_batchnorm_buffer_is_seen_by_the_plan_executor(one_adder_stats)
     assert float(bn.running_mean.abs().max()) > 0, "the new running_mean buffer was not updated"
 
 
+def test_clip_gradients_is_the_reference_clamp_in_one_pass():
+    """Encoder.clip_gradients_ = the reference's clip_gradient (train.py:311-316: p.grad.data.clamp_(-c, c) per parameter); on the plan
+    executor's flat gradient buffer it is one element-wise pass, elsewhere the two multi-tensor passes -- same values either way."""
+    from ppv_amd.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(layers=(1, 1, 1, 1)).cuda().train()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    enc(img)._ppv_cells.float().square().mean().backward()
+    tr = [p for p in enc.parameters() if p.requires_grad]
+    c = float(torch.cat([p.grad.flatten() for p in tr]).abs().quantile(0.7))       # a bound that actually clips ~30 % of the entries
+    want = [p.grad.clone().clamp_(-c, c) for p in tr]
+    assert len({p.grad.untyped_storage().data_ptr() for p in tr}) == 1                               # slices of ONE flat buffer
+    enc.clip_gradients_(c)
+    assert all(torch.equal(p.grad, w) for p, w in zip(tr, want))
+    for p in tr:                                                                    # independent tensors: the fallback path
+        p.grad = p.grad.clone() * 3.0
+    want = [p.grad.clone().clamp_(-c, c) for p in tr]
+    enc.clip_gradients_(c)
+    assert all(torch.equal(p.grad, w) for p, w in zip(tr, want))
+
+
 def test_trunk_plan_gradient_ownership(one_adder_stats):
     """The plan executor hands autograd fresh views of its flat gradient buffer (adopted as ``param.grad`` without a copy when no gradient
     is there, accumulated into when one is: micro-batching), serves a second backward with retain_graph, refuses one whose arena a later

@@ -103,6 +103,9 @@ int ppv_ic_psf_mark_support(const float* Z, void* state, int RR, int P, int K, p
 int ppv_ic_psf_symmetric(const void* state, int RR, int P, int K, ppv_stream_t stream);
 int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0, size_t* off_U, size_t* off_I32,
                              size_t* off_raw);
+/* 1: the Fresnel transforms and the saved fields F0 / U are c64 (default since round 5: the reference feeds its transform c64-valued
+ * fields, Utils.py:80-85, so c64 adds ~5e-7 against the 1e-3 tolerance), 0: c128 (PPV_PSF_F32=0) */
+int ppv_ic_psf_fields_f32(void);
 
 /* ---- Zernike basis (poppy.zernike.zernike_basis, IC Utils.py:75-77 / FD Utils.py:60-63) ---------------------
  * terms: K device records {int n, m, off, cnt; double norm}; coefs: device doubles of the radial polynomials. */

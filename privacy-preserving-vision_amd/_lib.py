@@ -44,6 +44,7 @@ PROTOTYPES = {
     "ppv_ic_psf_mark_support": (_I, [_P, _P, _I, _I, _I, _P]),
     "ppv_ic_psf_symmetric": (_I, [_P, _I, _I, _I, _P]),
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "ppv_ic_psf_fields_f32": (_I, []),
     "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
     "ppv_zernike_max_order": (_I, []),
     "ppv_fftconv_fd_bwd_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -25,58 +25,72 @@ struct FftPlan {
     int radix[MAXST];
 };
 
-__device__ __forceinline__ double2 dmul(double2 a, double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ double2 dadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 dsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 dmi(double2 a) { return make_double2(a.y, -a.x); }   // * (-i)
+// The Fresnel transforms exist for two element types (round 5): C2 = double2 (c128, as the reference's fields are typed after the f64
+// aperture mask, Utils.py:88-97) and C2 = float2 (c64: the VALUES the reference feeds the transform are c64 products -- the plate
+// and the spherical wavefront are cast to c64 before they are multiplied, Utils.py:80-85 -- and its transfer function is c64, so a
+// c64 transform adds 4-5e-7 to PSF, sensor image and lens gradient (tools/micro/fresnel_c64_vs_c128.py on the CPU oracle) against
+// the 1e-3 tolerance; half the bytes and half the LDS per workgroup).  PPV_PSF_F32 selects (default 1).
+template <typename C2> struct CT;
+template <> struct CT<double2> {
+    typedef double R;
+    static __device__ __forceinline__ double2 mk(double x, double y) { return make_double2(x, y); }
+};
+template <> struct CT<float2> {
+    typedef float R;
+    static __device__ __forceinline__ float2 mk(float x, float y) { return make_float2(x, y); }
+};
+template <typename C2> __device__ __forceinline__ C2 dmul(C2 a, C2 b) { return CT<C2>::mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename C2> __device__ __forceinline__ C2 dadd(C2 a, C2 b) { return CT<C2>::mk(a.x + b.x, a.y + b.y); }
+template <typename C2> __device__ __forceinline__ C2 dsub(C2 a, C2 b) { return CT<C2>::mk(a.x - b.x, a.y - b.y); }
+template <typename C2> __device__ __forceinline__ C2 dmi(C2 a) { return CT<C2>::mk(a.y, -a.x); }   // * (-i)
 
-__device__ __forceinline__ void dbfly(double2 (&u)[2]) {
-    const double2 a = u[0], b = u[1];
+template <typename C2> __device__ __forceinline__ void dbfly(C2 (&u)[2]) {
+    const C2 a = u[0], b = u[1];
     u[0] = dadd(a, b); u[1] = dsub(a, b);
 }
-__device__ __forceinline__ void dbfly(double2 (&u)[4]) {
-    const double2 s02 = dadd(u[0], u[2]), d02 = dsub(u[0], u[2]), s13 = dadd(u[1], u[3]), d13 = dmi(dsub(u[1], u[3]));
+template <typename C2> __device__ __forceinline__ void dbfly(C2 (&u)[4]) {
+    const C2 s02 = dadd(u[0], u[2]), d02 = dsub(u[0], u[2]), s13 = dadd(u[1], u[3]), d13 = dmi(dsub(u[1], u[3]));
     u[0] = dadd(s02, s13); u[2] = dsub(s02, s13); u[1] = dadd(d02, d13); u[3] = dsub(d02, d13);
 }
-__device__ __forceinline__ void dbfly(double2 (&u)[3]) {
-    const double h = 0.86602540378443864676;
-    const double2 t1 = dadd(u[1], u[2]);
-    const double2 t2 = make_double2(u[0].x - 0.5 * t1.x, u[0].y - 0.5 * t1.y);
-    const double2 d = dsub(u[1], u[2]);
-    const double2 t3 = make_double2(h * d.y, -h * d.x);       // -i h (u1 - u2)
+template <typename C2> __device__ __forceinline__ void dbfly(C2 (&u)[3]) {
+    typedef typename CT<C2>::R R_;
+    const R_ h = (R_)0.86602540378443864676, half = (R_)0.5;
+    const C2 t1 = dadd(u[1], u[2]);
+    const C2 t2 = CT<C2>::mk(u[0].x - half * t1.x, u[0].y - half * t1.y);
+    const C2 d = dsub(u[1], u[2]);
+    const C2 t3 = CT<C2>::mk(h * d.y, -h * d.x);       // -i h (u1 - u2)
     u[0] = dadd(u[0], t1); u[1] = dadd(t2, t3); u[2] = dsub(t2, t3);
 }
-__device__ __forceinline__ void dbfly(double2 (&u)[7]) {
-    const double c1 = 0.62348980185873353053, c2 = -0.22252093395631440429, c3 = -0.90096886790241912624;
-    const double s1 = 0.78183148246802980871, s2 = 0.97492791218182360702, s3 = 0.43388373911755812048;
-    const double2 a1 = dadd(u[1], u[6]), a2 = dadd(u[2], u[5]), a3 = dadd(u[3], u[4]);
-    const double2 b1 = dsub(u[1], u[6]), b2 = dsub(u[2], u[5]), b3 = dsub(u[3], u[4]);
-    const double2 u0 = u[0];
+template <typename C2> __device__ __forceinline__ void dbfly(C2 (&u)[7]) {
+    typedef typename CT<C2>::R R_;
+    const R_ c1 = (R_)0.62348980185873353053, c2 = (R_)-0.22252093395631440429, c3 = (R_)-0.90096886790241912624;
+    const R_ s1 = (R_)0.78183148246802980871, s2 = (R_)0.97492791218182360702, s3 = (R_)0.43388373911755812048;
+    const C2 a1 = dadd(u[1], u[6]), a2 = dadd(u[2], u[5]), a3 = dadd(u[3], u[4]);
+    const C2 b1 = dsub(u[1], u[6]), b2 = dsub(u[2], u[5]), b3 = dsub(u[3], u[4]);
+    const C2 u0 = u[0];
     // q = 1: cos(1,2,3)  sin(1,2,3);  q = 2: cos(2,4->3,6->1) sin(2, 4->-3, 6->-1);  q = 3: cos(3,6->1,9->2) sin(3, 6->-1, 9->2)
-    const double2 p1 = make_double2(u0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, u0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
-    const double2 p2 = make_double2(u0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, u0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
-    const double2 p3 = make_double2(u0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, u0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
-    const double2 q1 = make_double2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
-    const double2 q2 = make_double2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
-    const double2 q3 = make_double2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
+    const C2 p1 = CT<C2>::mk(u0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, u0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+    const C2 p2 = CT<C2>::mk(u0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, u0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+    const C2 p3 = CT<C2>::mk(u0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, u0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+    const C2 q1 = CT<C2>::mk(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
+    const C2 q2 = CT<C2>::mk(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
+    const C2 q3 = CT<C2>::mk(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
     u[0] = dadd(dadd(u0, a1), dadd(a2, a3));
     // X[q] = p - i q ; X[7-q] = p + i q
-    u[1] = make_double2(p1.x + q1.y, p1.y - q1.x); u[6] = make_double2(p1.x - q1.y, p1.y + q1.x);
-    u[2] = make_double2(p2.x + q2.y, p2.y - q2.x); u[5] = make_double2(p2.x - q2.y, p2.y + q2.x);
-    u[3] = make_double2(p3.x + q3.y, p3.y - q3.x); u[4] = make_double2(p3.x - q3.y, p3.y + q3.x);
+    u[1] = CT<C2>::mk(p1.x + q1.y, p1.y - q1.x); u[6] = CT<C2>::mk(p1.x - q1.y, p1.y + q1.x);
+    u[2] = CT<C2>::mk(p2.x + q2.y, p2.y - q2.x); u[5] = CT<C2>::mk(p2.x - q2.y, p2.y + q2.x);
+    u[3] = CT<C2>::mk(p3.x + q3.y, p3.y - q3.x); u[4] = CT<C2>::mk(p3.x - q3.y, p3.y + q3.x);
 }
 
 // one Stockham stage over a length-M sequence in LDS (threads tid0, tid0+nthr, ... cooperate)
-template <int R>
-__device__ __forceinline__ void dstage(const double2* __restrict__ in, double2* __restrict__ out,
-                                       const double2* __restrict__ tw, int M, int p, int tid, int nthr) {
+template <int R, typename C2>
+__device__ __forceinline__ void dstage(const C2* __restrict__ in, C2* __restrict__ out,
+                                       const C2* __restrict__ tw, int M, int p, int tid, int nthr) {
     const int T = M / R;
     const int step = M / (p * R);
     for (int i = tid; i < T; i += nthr) {
         const int k = i % p;
-        double2 u[R];
+        C2 u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             u[r] = in[i + r * T];
@@ -92,7 +106,8 @@ __device__ __forceinline__ void dstage(const double2* __restrict__ in, double2* 
 // Stockham stage of ANY radix by direct summation (R^2 twiddled adds per butterfly): the odd primes the hand-written butterflies
 // above do not cover (5, 11, 13, 23: e.g. 1104 = 1.5 x 736 = 2^4 * 3 * 23, the transform of the reference constructor's default
 // wave_resolution, Lens.py:21).  W_R^j = tw[(j mod R) * M / R].
-__device__ __forceinline__ void dstage_any(const double2* __restrict__ in, double2* __restrict__ out, const double2* __restrict__ tw,
+template <typename C2>
+__device__ __forceinline__ void dstage_any(const C2* __restrict__ in, C2* __restrict__ out, const C2* __restrict__ tw,
                                            int M, int R, int p, int tid, int nthr) {
     const int T = M / R;
     const int step = M / (p * R), wr = M / R;
@@ -100,12 +115,12 @@ __device__ __forceinline__ void dstage_any(const double2* __restrict__ in, doubl
         const int k = i % p;
         const int j = (i - k) * R + k;
         for (int q = 0; q < R; ++q) {
-            double2 acc = in[i];
+            C2 acc = in[i];
             int e = 0;                                         // (q * r) mod R
             for (int r = 1; r < R; ++r) {
                 e += q;
                 if (e >= R) e -= R;
-                double2 v = in[i + r * T];
+                C2 v = in[i + r * T];
                 if (p > 1) v = dmul(v, tw[r * k * step]);
                 acc = dadd(acc, dmul(v, tw[e * wr]));
             }
@@ -125,18 +140,19 @@ __device__ __forceinline__ long tix(int l, int y, int kx, int RR, int M, int CB)
 // forward FFT of the sequence in buf a (scratch b); returns the buffer that holds the result.
 // Callers must __syncthreads()-separate groups: `sync` = workgroup barrier functor is implicit (all threads of the
 // workgroup call this together, possibly on different sequences).
-__device__ __forceinline__ double2* dfft(double2* a, double2* b, const double2* tw, const FftPlan& pl, int tid,
+template <typename C2>
+__device__ __forceinline__ C2* dfft(C2* a, C2* b, const C2* tw, const FftPlan& pl, int tid,
                                          int nthr) {
     int p = 1;
     for (int s = 0; s < pl.nst; ++s) {
         const int R = pl.radix[s];
-        if (R == 4) dstage<4>(a, b, tw, pl.M, p, tid, nthr);
-        else if (R == 2) dstage<2>(a, b, tw, pl.M, p, tid, nthr);
-        else if (R == 3) dstage<3>(a, b, tw, pl.M, p, tid, nthr);
-        else if (R == 7) dstage<7>(a, b, tw, pl.M, p, tid, nthr);
+        if (R == 4) dstage<4, C2>(a, b, tw, pl.M, p, tid, nthr);
+        else if (R == 2) dstage<2, C2>(a, b, tw, pl.M, p, tid, nthr);
+        else if (R == 3) dstage<3, C2>(a, b, tw, pl.M, p, tid, nthr);
+        else if (R == 7) dstage<7, C2>(a, b, tw, pl.M, p, tid, nthr);
         else dstage_any(a, b, tw, pl.M, R, p, tid, nthr);
         __syncthreads();
-        double2* t = a; a = b; b = t;
+        C2* t = a; a = b; b = t;
         p *= R;
     }
     return a;
@@ -144,15 +160,15 @@ __device__ __forceinline__ double2* dfft(double2* a, double2* b, const double2* 
 
 // The same transform with the plan of M = 1344 = 4 * 4 * 4 * 3 * 7 (RR = 896, the benchmark geometry) known at compile time: stage
 // radix, stride and twiddle step are constants (no integer division by a run-time p, no radix dispatch per stage), 256 threads, and
-// a thread's twiddles -- the same for every transform it takes part in -- are loaded ONCE into registers (Tw1344: 22 double2): with
+// a thread's twiddles -- the same for every transform it takes part in -- are loaded ONCE into registers (Tw1344: 22 C2): with
 // the table in global memory every butterfly waited ~0.7 us for an L2 hit inside each of the ten barrier-separated stages of the
 // column pass, with the table in LDS the workgroup is 64.5 KB and only two fit a CU.
 template <int R, int P, int M> struct StageGeom { static constexpr int T = M / R, STEP = M / (P * R), ITERS = (T + 255) / 256; };
-struct Tw1344 {
-    double2 s2[2][3], s3[2][3], s4[2][2], s5[1][6];
+template <typename C2> struct Tw1344 {
+    C2 s2[2][3], s3[2][3], s4[2][2], s5[1][6];
 };
-template <int R, int P, int M, int NI>
-__device__ __forceinline__ void tw_load(double2 (&w)[NI][R - 1], const double2* __restrict__ tw, int tid) {
+template <int R, int P, int M, int NI, typename C2>
+__device__ __forceinline__ void tw_load(C2 (&w)[NI][R - 1], const C2* __restrict__ tw, int tid) {
     using G = StageGeom<R, P, M>;
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
@@ -162,14 +178,15 @@ __device__ __forceinline__ void tw_load(double2 (&w)[NI][R - 1], const double2* 
         for (int r = 1; r < R; ++r) w[it][r - 1] = tw[r * k * G::STEP];
     }
 }
-__device__ __forceinline__ void tw1344_load(Tw1344& w, const double2* __restrict__ tw, int tid) {
+template <typename C2>
+__device__ __forceinline__ void tw1344_load(Tw1344<C2>& w, const C2* __restrict__ tw, int tid) {
     tw_load<4, 4, 1344, 2>(w.s2, tw, tid);
     tw_load<4, 16, 1344, 2>(w.s3, tw, tid);
     tw_load<3, 64, 1344, 2>(w.s4, tw, tid);
     tw_load<7, 192, 1344, 1>(w.s5, tw, tid);
 }
-template <int R, int P, int M, int NI>
-__device__ __forceinline__ void dstage_c(const double2* __restrict__ in, double2* __restrict__ out, const double2 (*w)[R - 1], int tid) {
+template <int R, int P, int M, int NI, typename C2>
+__device__ __forceinline__ void dstage_c(const C2* __restrict__ in, C2* __restrict__ out, const C2 (*w)[R - 1], int tid) {
     using G = StageGeom<R, P, M>;
     static_assert(NI == G::ITERS, "twiddle rows per thread");
 #pragma unroll
@@ -177,7 +194,7 @@ __device__ __forceinline__ void dstage_c(const double2* __restrict__ in, double2
         const int i = it * 256 + tid;
         if (G::T % 256 != 0 && i >= G::T) break;
         const int k = i % P;
-        double2 u[R];
+        C2 u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             u[r] = in[i + r * G::T];
@@ -189,7 +206,8 @@ __device__ __forceinline__ void dstage_c(const double2* __restrict__ in, double2
         for (int q = 0; q < R; ++q) out[j + q * P] = u[q];
     }
 }
-__device__ __forceinline__ double2* dfft_1344(double2* a, double2* b, const Tw1344& w, int tid) {
+template <typename C2>
+__device__ __forceinline__ C2* dfft_1344(C2* a, C2* b, const Tw1344<C2>& w, int tid) {
     dstage_c<4, 1, 1344, 2>(a, b, w.s2, tid); __syncthreads();          // P = 1: no twiddles read
     dstage_c<4, 4, 1344, 2>(b, a, w.s2, tid); __syncthreads();
     dstage_c<4, 16, 1344, 2>(a, b, w.s3, tid); __syncthreads();
@@ -199,7 +217,8 @@ __device__ __forceinline__ double2* dfft_1344(double2* a, double2* b, const Tw13
 }
 // plan-aware entry: the compile-time form when it applies (256 threads, the make_plan() radix order 4,4,4,3,7; w loaded by
 // tw1344_load when pl.M == 1344, untouched otherwise)
-__device__ __forceinline__ double2* dfft256(double2* a, double2* b, const double2* tw, const Tw1344& w, const FftPlan& pl, int tid) {
+template <typename C2>
+__device__ __forceinline__ C2* dfft256(C2* a, C2* b, const C2* tw, const Tw1344<C2>& w, const FftPlan& pl, int tid) {
     if (pl.M == 1344) return dfft_1344(a, b, w, tid);
     FftPlan q = pl;
     if (q.M < 0) q.M = -q.M;
@@ -512,10 +531,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 // ----------------------------------------------------------------------------- field at the phase plate
 // F0[l][y][x] = aperture * sph[y][x][l] * c64(exp(i * kdn[l] * (h + noise)))      (c64 product, promoted to c128)
+template <typename C2>
 __global__ __launch_bounds__(256) void ic_field_kernel(const float* __restrict__ h, const float* __restrict__ noise,
-                                                       const float2* __restrict__ sph, double2* __restrict__ F0,
+                                                       const float2* __restrict__ sph, C2* __restrict__ F0,
                                                        int RR, double kdn0, double kdn1, double kdn2, float tol,
                                                        int use_tol) {
+    typedef typename CT<C2>::R R_;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long npx = (long)RR * RR;
     if (idx >= npx) return;
@@ -528,21 +549,22 @@ __global__ __launch_bounds__(256) void ic_field_kernel(const float* __restrict__
     const double kd[3] = {kdn0, kdn1, kdn2};
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
-        double2 f = make_double2(0.0, 0.0);
+        C2 f = CT<C2>::mk((R_)0, (R_)0);
         if (open) {
             double s, c;
-            sincos(kd[l] * (double)hh, &s, &c);
+            sincos(kd[l] * (double)hh, &s, &c);                  // the phase (up to ~4e3 rad) and its sine / cosine stay f64 in both forms
             const float2 pl = make_float2((float)c, (float)s);
             const float2 sp = sph[idx * 3 + l];
-            f = make_double2((double)__fsub_rn(__fmul_rn(sp.x, pl.x), __fmul_rn(sp.y, pl.y)),
-                             (double)__fadd_rn(__fmul_rn(sp.x, pl.y), __fmul_rn(sp.y, pl.x)));
+            f = CT<C2>::mk((R_)__fsub_rn(__fmul_rn(sp.x, pl.x), __fmul_rn(sp.y, pl.y)),
+                           (R_)__fadd_rn(__fmul_rn(sp.x, pl.y), __fmul_rn(sp.y, pl.x)));
         }
         F0[(long)l * npx + idx] = f;
     }
 }
 
 // gh[px] = sum_l kdn[l] * Im(GF * conj(F0))
-__global__ __launch_bounds__(256) void ic_field_bwd_kernel(const double2* __restrict__ GF, const double2* __restrict__ F0,
+template <typename C2>
+__global__ __launch_bounds__(256) void ic_field_bwd_kernel(const C2* __restrict__ GF, const C2* __restrict__ F0,
                                                            float* __restrict__ gh, long npx, double kdn0, double kdn1,
                                                            double kdn2) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -551,31 +573,31 @@ __global__ __launch_bounds__(256) void ic_field_bwd_kernel(const double2* __rest
     double a = 0;
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
-        const double2 g = GF[(long)l * npx + idx], f = F0[(long)l * npx + idx];
-        a += kd[l] * (g.y * f.x - g.x * f.y);
+        const C2 g = GF[(long)l * npx + idx], f = F0[(long)l * npx + idx];
+        a += kd[l] * ((double)g.y * (double)f.x - (double)g.x * (double)f.y);
     }
     gh[idx] = (float)a;
 }
 
 // ----------------------------------------------------------------------------- Fresnel FFT passes
 // rows: in [L][RR][RR] placed at column offset pad inside a zero row of length M -> out [L][RR][M]
-template <bool C1344>       // C1344: M = 1344, twiddles in registers (no LDS copy of the table: 43 KB per workgroup, three per CU)
-__global__ __launch_bounds__(256) void dfft_rows_kernel(const double2* __restrict__ in, double2* __restrict__ out,
-                                                        const double2* __restrict__ twg, FftPlan pl, int RR, int pad) {
-    __shared__ double2 s_tw[C1344 ? 1 : MAXM];
-    __shared__ double2 s_a[MAXM];
-    __shared__ double2 s_b[MAXM];
+template <bool C1344, typename C2>       // C1344: M = 1344, twiddles in registers (no LDS copy of the table: 43 KB per workgroup, three per CU)
+__global__ __launch_bounds__(256) void dfft_rows_kernel(const C2* __restrict__ in, C2* __restrict__ out,
+                                                        const C2* __restrict__ twg, FftPlan pl, int RR, int pad) {
+    __shared__ C2 s_tw[C1344 ? 1 : MAXM];
+    __shared__ C2 s_a[MAXM];
+    __shared__ C2 s_b[MAXM];
     const int tid = threadIdx.x, M = pl.M;
     const long row = blockIdx.x;          // l * RR + y
-    Tw1344 w;
+    Tw1344<C2> w;
     if (C1344) tw1344_load(w, twg, tid);
     for (int i = tid; i < M; i += 256) {
         if (!C1344) s_tw[i] = twg[i];
         const int x = i - pad;
-        s_a[i] = (x >= 0 && x < RR) ? in[row * RR + x] : make_double2(0.0, 0.0);
+        s_a[i] = (x >= 0 && x < RR) ? in[row * RR + x] : CT<C2>::mk(0, 0);
     }
     __syncthreads();
-    const double2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, s_tw, pl, tid, 256);
+    const C2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, (const C2*)s_tw, pl, tid, 256);
     const int l = (int)(row / RR), y = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
     for (int i = tid; i < M; i += 256) out[tix(l, y, i, RR, M, CB)] = r[i];
 }
@@ -637,13 +659,15 @@ __global__ __launch_bounds__(512) void dfft_cols_kernel(const double2* __restric
 // 1 TB/s).  Here a workgroup owns ONE column (256 threads, 43 KB: ping-pong buffers only) and reads the twiddles from the 21.5-KB
 // global table (L1 / L2 resident), so three workgroups share a CU and cover each other's barriers and load latencies; the eight
 // workgroups of an 8-column block (one 128-byte line per row) run on one XCD.
-template <bool TW_LDS>
-__global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restrict__ T1, double2* __restrict__ T2,
-                                                         const float2* __restrict__ Ht, const double2* __restrict__ twg, FftPlan pl,
-                                                         int RR, int pad, int conj_h, double scale, int static_plan) {
-    __shared__ double2 s_tw[TW_LDS ? MAXM : 1];
-    __shared__ double2 s_a[MAXM];
-    __shared__ double2 s_b[MAXM];
+template <bool TW_LDS, typename C2>
+__global__ __launch_bounds__(256) void dfft_cols1_kernel(const C2* __restrict__ T1, C2* __restrict__ T2,
+                                                         const float2* __restrict__ Ht, const C2* __restrict__ twg, FftPlan pl,
+                                                         int RR, int pad, int conj_h, double scale_, int static_plan) {
+    typedef typename CT<C2>::R R_;
+    const R_ scale = (R_)scale_;
+    __shared__ C2 s_tw[TW_LDS ? MAXM : 1];
+    __shared__ C2 s_a[MAXM];
+    __shared__ C2 s_b[MAXM];
     const int tid = threadIdx.x, M = pl.M;
     int pb = blockIdx.x;
     if (gridDim.x % 64 == 0) {                       // blocks b, b + 8, ... share an XCD: give it the 8 columns of one 128-byte block
@@ -656,54 +680,54 @@ __global__ __launch_bounds__(256) void dfft_cols1_kernel(const double2* __restri
         for (int i = tid; i < M; i += 256) s_tw[i] = twg[i];
     for (int i = tid; i < M; i += 256) {
         const int y = i - pad;
-        s_a[i] = (y >= 0 && y < RR) ? T1[tix(l, y, kx, RR, M, CB)] : make_double2(0.0, 0.0);
+        s_a[i] = (y >= 0 && y < RR) ? T1[tix(l, y, kx, RR, M, CB)] : CT<C2>::mk(0, 0);
     }
     __syncthreads();
-    const double2* tw = TW_LDS ? s_tw : twg;
-    Tw1344 w;
+    const C2* tw = TW_LDS ? (const C2*)s_tw : twg;
+    Tw1344<C2> w;
     const bool c1344 = !TW_LDS && static_plan && M == 1344;          // compile-time plan + twiddles in registers (uniform branch)
     if (c1344) tw1344_load(w, twg, tid);
     FftPlan pl2 = pl;
     if (!c1344 && M == 1344) pl2.M = -1344;            // dfft256 keys on M == 1344: hide it when the static form is off
-    double2* r = dfft256(s_a, s_b, tw, w, pl2, tid);
-    double2* o = (r == s_a) ? s_b : s_a;
+    C2* r = dfft256(s_a, s_b, tw, w, pl2, tid);
+    C2* o = (r == s_a) ? s_b : s_a;
     const float2* hcol = Ht + ((long)l * M + kx) * M;
     for (int i = tid; i < M; i += 256) {
         const float2 hf = hcol[i];
-        const double2 hv = make_double2((double)hf.x, conj_h ? -(double)hf.y : (double)hf.y);
-        const double2 v = dmul(r[i], hv);
-        r[i] = make_double2(v.x, -v.y);                  // conj for the inverse transform
+        const C2 hv = CT<C2>::mk((R_)hf.x, conj_h ? -(R_)hf.y : (R_)hf.y);
+        const C2 v = dmul(r[i], hv);
+        r[i] = CT<C2>::mk(v.x, -v.y);                  // conj for the inverse transform
     }
     __syncthreads();
-    const double2* z = dfft256(r, o, tw, w, pl2, tid);
+    const C2* z = dfft256(r, o, tw, w, pl2, tid);
     for (int i = tid; i < RR; i += 256) {
-        const double2 a = z[i + pad];
-        T2[tix(l, i, kx, RR, M, CB)] = make_double2(a.x * scale, -a.y * scale);
+        const C2 a = z[i + pad];
+        T2[tix(l, i, kx, RR, M, CB)] = CT<C2>::mk(a.x * scale, -a.y * scale);
     }
 }
 
 // inverse rows: T2 [L][RR][M] -> crop columns pad..pad+RR-1 -> U [L][RR][RR] (c128), optional intensity f32
-template <bool C1344>
-__global__ __launch_bounds__(256) void difft_rows_kernel(const double2* __restrict__ T2, double2* __restrict__ U,
-                                                         float* __restrict__ I32, const double2* __restrict__ twg,
+template <bool C1344, typename C2>
+__global__ __launch_bounds__(256) void difft_rows_kernel(const C2* __restrict__ T2, C2* __restrict__ U,
+                                                         float* __restrict__ I32, const C2* __restrict__ twg,
                                                          FftPlan pl, int RR, int pad) {
-    __shared__ double2 s_tw[C1344 ? 1 : MAXM];
-    __shared__ double2 s_a[MAXM];
-    __shared__ double2 s_b[MAXM];
+    __shared__ C2 s_tw[C1344 ? 1 : MAXM];
+    __shared__ C2 s_a[MAXM];
+    __shared__ C2 s_b[MAXM];
     const int tid = threadIdx.x, M = pl.M;
     const long row = blockIdx.x;
     const int l_ = (int)(row / RR), y_ = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
-    Tw1344 w;
+    Tw1344<C2> w;
     if (C1344) tw1344_load(w, twg, tid);
     for (int i = tid; i < M; i += 256) {
         if (!C1344) s_tw[i] = twg[i];
-        const double2 v = T2[tix(l_, y_, i, RR, M, CB)];
-        s_a[i] = make_double2(v.x, -v.y);
+        const C2 v = T2[tix(l_, y_, i, RR, M, CB)];
+        s_a[i] = CT<C2>::mk(v.x, -v.y);
     }
     __syncthreads();
-    const double2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, s_tw, pl, tid, 256);
+    const C2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, (const C2*)s_tw, pl, tid, 256);
     for (int i = tid; i < RR; i += 256) {
-        const double2 v = make_double2(r[i + pad].x, -r[i + pad].y);
+        const C2 v = CT<C2>::mk(r[i + pad].x, -r[i + pad].y);
         U[row * RR + i] = v;
         if (I32) I32[row * RR + i] = (float)(v.x * v.x + v.y * v.y);      // Utils.py:208-209, cast Utils.py:218
     }
@@ -819,10 +843,12 @@ __global__ __launch_bounds__(256) void psf_finalize_bwd1_kernel(const float* __r
 
 // g_raw = (g_n - dot_l) / sum_l ; then adjoint of area_down fused with the intensity adjoint:
 // GU[l][r][c] = 2 * U[l][r][c] * (1/up^2) * sum_{U0: src(U0)=r} sum_{V0: src(V0)=c} g_raw[U0/up][V0/up][l]
+template <typename C2>
 __global__ __launch_bounds__(256) void area_down_bwd_kernel(const double* __restrict__ g_n, const double* __restrict__ dots,
                                                             const double* __restrict__ sums,
-                                                            const double2* __restrict__ U, double2* __restrict__ GU,
+                                                            const C2* __restrict__ U, C2* __restrict__ GU,
                                                             int RR, int P, int up, float scale) {
+    typedef typename CT<C2>::R R_;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)RR * RR) return;
     const int r = (int)(idx / RR), c = (int)(idx % RR);
@@ -841,9 +867,9 @@ __global__ __launch_bounds__(256) void area_down_bwd_kernel(const double* __rest
     const double inv = 1.0 / (double)(up * up);
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
-        const double2 u = U[(long)l * RR * RR + idx];
+        const C2 u = U[(long)l * RR * RR + idx];
         const double w = 2.0 * g[l] * inv;
-        GU[(long)l * RR * RR + idx] = make_double2(w * u.x, w * u.y);
+        GU[(long)l * RR * RR + idx] = CT<C2>::mk((R_)(w * (double)u.x), (R_)(w * (double)u.y));
     }
 }
 
@@ -954,13 +980,103 @@ size_t ppv_ic_psf_state_bytes(int RR, int P, int K) {
 
 // column pass of the Fresnel transform: PPV_DFFT_COLS = 0 two columns per workgroup (rounds 1-2), 1 one column + twiddles in LDS (two
 // workgroups per CU), 2 one column, twiddles from L2 (three per CU)
+static int dfft_cols_mode() {
+    static const int mode = getenv("PPV_DFFT_COLS") ? atoi(getenv("PPV_DFFT_COLS")) : 2;
+    return mode;
+}
 static void launch_dfft_cols(const double2* T1, double2* T2, const float2* Ht, const double2* tw, const FftPlan& pl, int RR, int pad, int M,
                              int conj_h, double scale, hipStream_t stream) {
-    static const int mode = getenv("PPV_DFFT_COLS") ? atoi(getenv("PPV_DFFT_COLS")) : 2;
-    if (mode == 1) dfft_cols1_kernel<true><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, 0);
-    else if (mode == 2) dfft_cols1_kernel<false><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, dfft_static(M) ? 1 : 0);
+    const int mode = dfft_cols_mode();
+    if (mode == 1) dfft_cols1_kernel<true, double2><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, 0);
+    else if (mode == 2) dfft_cols1_kernel<false, double2><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, dfft_static(M) ? 1 : 0);
     else dfft_cols_kernel<<<dim3(M / 2, 3), 512, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale);
 }
+static void launch_dfft_cols(const float2* T1, float2* T2, const float2* Ht, const float2* tw, const FftPlan& pl, int RR, int pad, int M,
+                             int conj_h, double scale, hipStream_t stream) {
+    // c64: one column per workgroup, 21.5 KB of LDS (seven workgroups per CU); twiddles in LDS only on request (PPV_DFFT_COLS=1)
+    if (dfft_cols_mode() == 1) dfft_cols1_kernel<true, float2><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, 0);
+    else dfft_cols1_kernel<false, float2><<<dim3(M, 3), 256, 0, stream>>>(T1, T2, Ht, tw, pl, RR, pad, conj_h, scale, dfft_static(M) ? 1 : 0);
+}
+
+// element type of the Fresnel transforms and of the fields kept for backward (F0, U): c64 unless PPV_PSF_F32=0 (c128, rounds 1-4)
+static bool psf_f32() {
+    static const bool on = !(getenv("PPV_PSF_F32") && atoi(getenv("PPV_PSF_F32")) == 0);
+    return on;
+}
+}  // extern "C" (templates need C++ linkage)
+
+namespace {
+template <typename C2> const C2* fresnel_twiddles(int M);
+template <> const double2* fresnel_twiddles<double2>(int M) { return (const double2*)ppv_twiddles_f64(M); }
+template <> const float2* fresnel_twiddles<float2>(int M) { return (const float2*)ppv_twiddles_f32(M); }
+
+template <typename C2>
+int psf_fwd_t(const float* Z, const float* coeffs, const float* noise, const void* sph, const void* Ht, const double* kdn, float tol,
+              const double* m1, const double* m2, float* psf_n, double* psf_m, double* loss_acc, void* state, int RR, int P, int K, int up,
+              float up_scale, hipStream_t stream) {
+    const int pad = RR / 4, M = RR + 2 * pad;
+    FftPlan pl;
+    if (int e = make_plan(M, &pl)) return e;
+    const C2* tw = fresnel_twiddles<C2>(M);
+    if (!tw) return PPV_ERR_INIT;
+    IcWs w;
+    carve(&w, (char*)state, RR, P, K);
+    C2 *F0 = (C2*)w.F0, *U = (C2*)w.U, *T1 = (C2*)w.T1, *T2 = (C2*)w.T2;      // (the c64 form uses the first half of each c128-sized region)
+    const long npx = (long)RR * RR;
+    (void)hipMemsetAsync(w.sums, 0, 64, stream);
+    if (loss_acc) (void)hipMemsetAsync(loss_acc, 0, 8, stream);
+    launch_contract(Z, coeffs, w, K, RR, stream);
+    ic_field_kernel<C2><<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.h, noise, (const float2*)sph, F0, RR, kdn[0],
+                                                                         kdn[1], kdn[2], tol, (tol >= 0.f && noise) ? 1 : 0);
+    if (dfft_static(M)) dfft_rows_kernel<true, C2><<<3 * RR, 256, 0, stream>>>(F0, T1, tw, pl, RR, pad);
+    else dfft_rows_kernel<false, C2><<<3 * RR, 256, 0, stream>>>(F0, T1, tw, pl, RR, pad);
+    launch_dfft_cols(T1, T2, (const float2*)Ht, tw, pl, RR, pad, M, 0, 1.0 / ((double)M * (double)M), stream);
+    if (dfft_static(M)) difft_rows_kernel<true, C2><<<3 * RR, 256, 0, stream>>>(T2, U, w.I32, tw, pl, RR, pad);
+    else difft_rows_kernel<false, C2><<<3 * RR, 256, 0, stream>>>(T2, U, w.I32, tw, pl, RR, pad);
+    area_down_kernel<<<(unsigned)(((long)P * P + 255) / 256), 256, 0, stream>>>(w.I32, w.raw, w.sums, RR, P, up, up_scale);
+    const long n = (long)P * P * 3;
+    psf_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(w.raw, w.sums, m1, m2, psf_n, psf_m,
+                                                                       m1 ? loss_acc : nullptr, n);
+    return ppv_last_error();
+}
+
+template <typename C2>
+int psf_bwd_t(const float* Z, const void* Ht, const double* kdn, const double* m1, const double* m2, const float* psf_n,
+              const double* g_psf_m, const float* g_psf_n, const double* g_loss, const double* loss, float* g_coeffs, void* state, int RR,
+              int P, int K, int up, float up_scale, hipStream_t stream) {
+    const int pad = RR / 4, M = RR + 2 * pad;
+    FftPlan pl;
+    if (int e = make_plan(M, &pl)) return e;
+    const C2* tw = fresnel_twiddles<C2>(M);
+    if (!tw) return PPV_ERR_INIT;
+    IcWs w;
+    carve(&w, (char*)state, RR, P, K);
+    C2 *F0 = (C2*)w.F0, *U = (C2*)w.U, *T1 = (C2*)w.T1, *T2 = (C2*)w.T2;
+    const long npx = (long)RR * RR, n = (long)P * P * 3;
+    double* dots = w.sums + 3;
+    (void)hipMemsetAsync(dots, 0, 24, stream);
+    psf_finalize_bwd1_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(psf_n, m1, m2, g_psf_m, g_psf_n, g_loss, loss,
+                                                                            w.g_n, dots, n);
+    C2* GU = T2;      // T2 is dead after forward and holds 3*RR*M >= 3*RR*RR elements; U and F0 stay intact
+    area_down_bwd_kernel<C2><<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.g_n, dots, w.sums, U, GU, RR, P, up, up_scale);
+    if (dfft_static(M)) dfft_rows_kernel<true, C2><<<3 * RR, 256, 0, stream>>>(GU, T1, tw, pl, RR, pad);
+    else dfft_rows_kernel<false, C2><<<3 * RR, 256, 0, stream>>>(GU, T1, tw, pl, RR, pad);
+    // cols: T1 -> T2 would overwrite GU while reading T1 only: fine (GU no longer needed)
+    launch_dfft_cols(T1, T2, (const float2*)Ht, tw, pl, RR, pad, M, 1, 1.0 / ((double)M * (double)M), stream);
+    C2* GF = T1;                                            // T1 dead again
+    if (dfft_static(M)) difft_rows_kernel<true, C2><<<3 * RR, 256, 0, stream>>>(T2, GF, nullptr, tw, pl, RR, pad);
+    else difft_rows_kernel<false, C2><<<3 * RR, 256, 0, stream>>>(T2, GF, nullptr, tw, pl, RR, pad);
+    ic_field_bwd_kernel<C2><<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
+    launch_grad(Z, g_coeffs, w, K, RR, stream);
+    return ppv_last_error();
+}
+}  // namespace
+
+extern "C" {
+
+// 1: the Fresnel transforms and the saved fields F0 / U (ppv_ic_psf_state_offsets) are c64, 0: c128 (PPV_PSF_F32=0)
+int ppv_ic_psf_fields_f32(void) { return psf_f32() ? 1 : 0; }
+
 
 // Optional, once per (state, Z): mark where the basis Z [K][RR][RR] is non-zero, so that ppv_ic_psf_fwd / _bwd skip the pixel groups
 // outside its support (the aperture disk of poppy's zernike_basis(outside = 0): 21.5 % of the 1.12 GB read per direction).  Exact:
@@ -1016,29 +1132,9 @@ int ppv_ic_psf_fwd(const float* Z, const float* coeffs, const float* noise, cons
                    double* loss_acc, void* state, int RR, int P, int K, int up, float up_scale, hipStream_t stream) {
     if (!Z || !coeffs || !sph || !Ht || !kdn || !psf_n || !state) return PPV_ERR_NULL;
     if (RR % 4 || (RR * (long)RR) % 4) return PPV_ERR_BAD_SIZE;
-    const int pad = RR / 4, M = RR + 2 * pad;
-    FftPlan pl;
-    if (int e = make_plan(M, &pl)) return e;
-    const double2* tw = (const double2*)ppv_twiddles_f64(M);
-    if (!tw) return PPV_ERR_INIT;
-    IcWs w;
-    carve(&w, (char*)state, RR, P, K);
-    const long npx = (long)RR * RR, npx4 = npx / 4;
-    (void)hipMemsetAsync(w.sums, 0, 64, stream);
-    if (loss_acc) (void)hipMemsetAsync(loss_acc, 0, 8, stream);
-    launch_contract(Z, coeffs, w, K, RR, stream);
-    ic_field_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.h, noise, (const float2*)sph, w.F0, RR, kdn[0],
-                                                                     kdn[1], kdn[2], tol, (tol >= 0.f && noise) ? 1 : 0);
-    if (dfft_static(M)) dfft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
-    else dfft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(w.F0, w.T1, tw, pl, RR, pad);
-    launch_dfft_cols(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, M, 0, 1.0 / ((double)M * (double)M), stream);
-    if (dfft_static(M)) difft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
-    else difft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(w.T2, w.U, w.I32, tw, pl, RR, pad);
-    area_down_kernel<<<(unsigned)(((long)P * P + 255) / 256), 256, 0, stream>>>(w.I32, w.raw, w.sums, RR, P, up, up_scale);
-    const long n = (long)P * P * 3;
-    psf_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(w.raw, w.sums, m1, m2, psf_n, psf_m,
-                                                                       m1 ? loss_acc : nullptr, n);
-    return ppv_last_error();
+    if (psf_f32())
+        return psf_fwd_t<float2>(Z, coeffs, noise, sph, Ht, kdn, tol, m1, m2, psf_n, psf_m, loss_acc, state, RR, P, K, up, up_scale, stream);
+    return psf_fwd_t<double2>(Z, coeffs, noise, sph, Ht, kdn, tol, m1, m2, psf_n, psf_m, loss_acc, state, RR, P, K, up, up_scale, stream);
 }
 
 // Backward: given g_psf_m (f64, grad of the masked psf; null if unused), g_psf_n (f32, grad of the un-masked
@@ -1049,30 +1145,9 @@ int ppv_ic_psf_bwd(const float* Z, const void* Ht, const double* kdn, const doub
                    const double* loss, float* g_coeffs, void* state, int RR, int P, int K, int up, float up_scale,
                    hipStream_t stream) {
     if (!Z || !Ht || !kdn || !psf_n || !g_coeffs || !state) return PPV_ERR_NULL;
-    const int pad = RR / 4, M = RR + 2 * pad;
-    FftPlan pl;
-    if (int e = make_plan(M, &pl)) return e;
-    const double2* tw = (const double2*)ppv_twiddles_f64(M);
-    if (!tw) return PPV_ERR_INIT;
-    IcWs w;
-    carve(&w, (char*)state, RR, P, K);
-    const long npx = (long)RR * RR, npx4 = npx / 4, n = (long)P * P * 3;
-    double* dots = w.sums + 3;
-    (void)hipMemsetAsync(dots, 0, 24, stream);
-    psf_finalize_bwd1_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(psf_n, m1, m2, g_psf_m, g_psf_n, g_loss, loss,
-                                                                            w.g_n, dots, n);
-    double2* GU = w.T2;      // T2 is dead after forward and holds 3*RR*M >= 3*RR*RR elements; U and F0 stay intact
-    area_down_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(w.g_n, dots, w.sums, w.U, GU, RR, P, up, up_scale);
-    if (dfft_static(M)) dfft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
-    else dfft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(GU, w.T1, tw, pl, RR, pad);
-    // cols: T1 -> T2 would overwrite GU while reading T1 only: fine (GU no longer needed)
-    launch_dfft_cols(w.T1, w.T2, (const float2*)Ht, tw, pl, RR, pad, M, 1, 1.0 / ((double)M * (double)M), stream);
-    double2* GF = w.T1;                                            // T1 dead again
-    if (dfft_static(M)) difft_rows_kernel<true><<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
-    else difft_rows_kernel<false><<<3 * RR, 256, 0, stream>>>(w.T2, GF, nullptr, tw, pl, RR, pad);
-    ic_field_bwd_kernel<<<(unsigned)((npx + 255) / 256), 256, 0, stream>>>(GF, w.F0, w.gh, npx, kdn[0], kdn[1], kdn[2]);
-    launch_grad(Z, g_coeffs, w, K, RR, stream);
-    return ppv_last_error();
+    if (psf_f32())
+        return psf_bwd_t<float2>(Z, Ht, kdn, m1, m2, psf_n, g_psf_m, g_psf_n, g_loss, loss, g_coeffs, state, RR, P, K, up, up_scale, stream);
+    return psf_bwd_t<double2>(Z, Ht, kdn, m1, m2, psf_n, g_psf_m, g_psf_n, g_loss, loss, g_coeffs, state, RR, P, K, up, up_scale, stream);
 }
 
 // h[px] = sum_k c[k] Z[k][px]  (IC Lens.py:176 / FD Optics.py:79-83); npx % 4 == 0

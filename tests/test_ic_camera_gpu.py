@@ -19,13 +19,14 @@ def _taps(cam):
     _lib.lib().ppv_ic_psf_state_offsets(RR, P, K, *[ctypes.byref(o) for o in offs])
     st = cam._state
     npx = RR * RR
+    cdt = torch.complex64 if _lib.lib().ppv_ic_psf_fields_f32() else torch.complex128      # element type of the Fresnel fields (PPV_PSF_F32)
 
     def view(off, dtype, n):
         return st[off.value: off.value + n * torch.empty(0, dtype=dtype).element_size()].view(dtype)
 
     return dict(h=view(offs[0], torch.float32, npx).reshape(RR, RR),
-                F0=view(offs[1], torch.complex128, 3 * npx).reshape(3, RR, RR),
-                U=view(offs[2], torch.complex128, 3 * npx).reshape(3, RR, RR),
+                F0=view(offs[1], cdt, 3 * npx).reshape(3, RR, RR),
+                U=view(offs[2], cdt, 3 * npx).reshape(3, RR, RR),
                 I32=view(offs[3], torch.float32, 3 * npx).reshape(3, RR, RR))
 
 

@@ -162,6 +162,11 @@ int ppv_gemm_f32_ws(const float* x, long ldx, const float* W, long ldw, const fl
 /* ppv_gemm_f32_tn's product a^T b (same contract) on the BF16 matrix pipe: the f32 operands are split in the kernel into bf16 hi + lo and
  * a product is hi*hi + hi*lo + lo*hi with f32 accumulation (~1e-5 of sum |a b|; 5.3x the matrix rate of the exact-f32 form).  The
  * default of the decoder's five batched weight gradients (replaces the autograd GEMMs of Image_Caption/models.py:199-214). */
+/* the row-major sibling: out = x W^T + bias (ppv_gemm_f32's contract) as three bf16 products of in-kernel splits -- the decoder's two large
+ * non-recurrent products (vocabulary layer over all time steps, models.py:211, and its transposed data gradient); K % 4 == 0 */
+int ppv_gemm_bf16x3_nt_plan(int M, int N, int K, size_t* bytes);
+int ppv_gemm_bf16x3_nt(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
+                       int ksplit, void* workspace, ppv_stream_t stream);
 int ppv_gemm_bf16x3_tn_plan(int M, int N, int K, size_t* bytes);
 int ppv_gemm_bf16x3_tn(const float* a, long lda, const float* b, long ldb, float* out, long ldo, int M, int N, int K, int ksplit,
                        void* workspace, ppv_stream_t stream);

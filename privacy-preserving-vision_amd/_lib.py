@@ -101,6 +101,8 @@ PROTOTYPES = {
     "ppv_gemm_f32_ws_plan": (_I, [_I, _I, _I, _P]),
     "ppv_gemm_f32_tn_plan": (_I, [_I, _I, _I, _P]),
     "ppv_gemm_f32_tn": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P]),
+    "ppv_gemm_bf16x3_nt_plan": (_I, [_I, _I, _I, _P]),
+    "ppv_gemm_bf16x3_nt": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "ppv_gemm_bf16x3_tn_plan": (_I, [_I, _I, _I, _P]),
     "ppv_gemm_bf16x3_tn": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P]),
     "ppv_gemm_f32_ws": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P, _P]),

@@ -457,6 +457,125 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_tn_kernel(const float* __r
     }
 }
 
+
+// The same three-product form for ROW-major operands: out[m][n] = sum_k x[m][k] W[n][k] (+ bias[n]) -- ppv_gemm_f32's contract -- for the
+// two large NON-recurrent dense products of the decoder: the vocabulary layer over all time steps (models.py:211 batched, [T B, 512] x
+// [9490, 512]^T) and its transposed data gradient ([T B, 9504] x [512, 9504]^T); the per-step layers that feed the LSTM state back stay
+// exact f32.  Staging: a thread loads float4s along k (8 lanes = one 128-byte line of a row), splits them and writes 8 bytes of hi and
+// of lo into [row][32 k] bf16 images (64-byte rows, 16-byte chunk index XOR 3 * ((row >> 3) & 1): the conflict-free ds_read_b128 pattern
+// of conv_gemm_pipe_kernel's BK = 32 tiles); fragments are plain ds_read_b128 (8 consecutive k of a row).  Same tile (128 x 128, four
+// waves of 64 x 64), pipeline and slab split-K as gemm_bf16x3_tn_kernel.  K % 4 == 0, rows 16-byte aligned.
+constexpr int X3N_IMG = 128 * 64;                                  // one [128 rows][32 k] bf16 image
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_nt_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, long ldw,
+                                                                const float* __restrict__ bias, float* __restrict__ out, long ldo, int M,
+                                                                int N, int K, int ksplit, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) char x3n_smem[];     // [2 buffers][x hi | x lo | W hi | W lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * X3_BN, m0 = blockIdx.z * X3_BM, kslice = blockIdx.y;
+    const int chunks = (K + X3_BK - 1) / X3_BK;
+    const int cps = (chunks + ksplit - 1) / ksplit;
+    const int c_begin = kslice * cps, c_end = min(chunks, c_begin + cps);
+    // staging role: float4 kq (4 k) of rows r0 + 32 i
+    const int kq = tid & 7, r0 = tid >> 3;
+    const float* xs[4];
+    const float* ws[4];
+    bool xok[4], wok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
+        xok[i] = m < M; wok[i] = n < N;
+        xs[i] = x + (long)(xok[i] ? m : 0) * ldx + 4 * kq;
+        ws[i] = W + (long)(wok[i] ? n : 0) * ldw + 4 * kq;
+    }
+    float4 rx[4], rw[4];
+    auto fetch = [&](int c) {
+        const bool kok = c * X3_BK + 4 * kq < K;                       // K % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rx[i] = (xok[i] && kok) ? *reinterpret_cast<const float4*>(xs[i] + (long)c * X3_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = (wok[i] && kok) ? *reinterpret_cast<const float4*>(ws[i] + (long)c * X3_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto park = [&](int buf) {
+        char* base = x3n_smem + buf * 4 * X3N_IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 32 * i;
+            const int off = row * 64 + (((kq >> 1) ^ (((row >> 3) & 1) * 3)) * 16) + (kq & 1) * 8;
+            uint2 hi, lo;
+            x3_split4(rx[i], hi, lo);
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            *reinterpret_cast<uint2*>(base + X3N_IMG + off) = lo;
+            x3_split4(rw[i], hi, lo);
+            *reinterpret_cast<uint2*>(base + 2 * X3N_IMG + off) = hi;
+            *reinterpret_cast<uint2*>(base + 3 * X3N_IMG + off) = lo;
+        }
+    };
+    gf32x4 acc[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    auto frag = [&](const char* img, int rb) {
+        const int row = rb * 16 + fr;
+        return *reinterpret_cast<const x3_bf16x8*>(img + row * 64 + ((fq ^ (((row >> 3) & 1) * 3)) * 16));
+    };
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        park(0);
+        __syncthreads();
+        int buf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            if (c + 1 < c_end) fetch(c + 1);
+            const char* base = x3n_smem + buf * 4 * X3N_IMG;
+            x3_bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = frag(base, wm * 4 + i);
+                bh[i] = frag(base + 2 * X3N_IMG, wn * 4 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                al[i] = frag(base + X3N_IMG, wm * 4 + i);
+                bl[i] = frag(base + 3 * X3N_IMG, wn * 4 + i);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+            if (c + 1 < c_end) park(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // C/D layout: acc[mb][nb][j] = out[m0 + wm * 64 + mb * 16 + fq * 4 + j][n0 + wn * 64 + nb * 16 + fr]
+    float* dst = slab ? slab + (long)kslice * M * N : out;
+    const long ldd = slab ? N : ldo;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int n = n0 + wn * 64 + nb * 16 + fr;
+        if (n >= N) continue;
+        const float b = (bias && !slab) ? bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + wm * 64 + mb * 16 + fq * 4 + j;
+                if (m < M) dst[(long)m * ldd + n] = acc[mb][nb][j] + b;
+            }
+    }
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -633,6 +752,43 @@ int ppv_gemm_bf16x3_tn(const float* a, long lda, const float* b, long ldb, float
     gemm_bf16x3_tn_kernel<<<grid, 256, lds, stream>>>(a, lda, b, ldb, nullptr, 0, M, N, K, ksplit, (float*)workspace);
     const long n4 = (long)M * (N / 4);
     gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, nullptr, out, ldo, M, N, ksplit);
+    return ppv_last_error();
+}
+
+// out = x W^T + bias (ppv_gemm_f32's contract: x [M][K], W [N][K] f32 row-major with row strides, bias [N] or null) as three bf16 products
+// of in-kernel hi / lo splits (gemm_bf16x3_nt_kernel): for the decoder's two large non-recurrent products (vocabulary layer over all
+// steps and its transposed data gradient).  K % 4 == 0, rows 16-byte aligned; ppv_gemm_bf16x3_nt_plan: split and workspace bytes.
+int ppv_gemm_bf16x3_nt_plan(int M, int N, int K, size_t* bytes) {
+    const long tiles = (long)((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
+    static const int target = getenv("PPV_GEMM_X3_WGS") ? atoi(getenv("PPV_GEMM_X3_WGS")) : 512;
+    const int chunks = (K + X3_BK - 1) / X3_BK;
+    int ks = 1;
+    if (N % 4 == 0)
+        while (ks < 16 && tiles * ks < target && chunks / (ks * 2) >= 3) ks *= 2;
+    if (bytes) *bytes = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    return ks;
+}
+
+int ppv_gemm_bf16x3_nt(const float* x, long ldx, const float* W, long ldw, const float* bias, float* out, long ldo, int M, int N, int K,
+                       int ksplit, void* workspace, hipStream_t stream) {
+    if (!x || !W || !out) return PPV_ERR_NULL;
+    if (M < 1 || N < 1 || K < 4 || K % 4 || ldx % 4 || ldw % 4 || ((size_t)x % 16) || ((size_t)W % 16) || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
+    constexpr int lds = 2 * 4 * X3N_IMG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((N + X3_BN - 1) / X3_BN), (unsigned)ksplit, (unsigned)((M + X3_BM - 1) / X3_BM));
+    if (ksplit == 1) {
+        gemm_bf16x3_nt_kernel<<<grid, 256, lds, stream>>>(x, ldx, W, ldw, bias, out, ldo, M, N, K, 1, nullptr);
+        return ppv_last_error();
+    }
+    if (!workspace) return PPV_ERR_NULL;
+    if (N % 4 || ldo % 4 || ((size_t)out % 16) || (bias && ((size_t)bias % 16))) return PPV_ERR_BAD_SIZE;
+    gemm_bf16x3_nt_kernel<<<grid, 256, lds, stream>>>(x, ldx, W, ldw, nullptr, nullptr, 0, M, N, K, ksplit, (float*)workspace);
+    const long n4 = (long)M * (N / 4);
+    gemm_f32_slab_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float*)workspace, bias, out, ldo, M, N, ksplit);
     return ppv_last_error();
 }
 

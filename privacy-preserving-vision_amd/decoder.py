@@ -150,6 +150,18 @@ def _linear(x, w, bias, out, hip):
     return torch.addmm(bias, x, w.t(), out=out) if out is not None else torch.addmm(bias, x, w.t())
 
 
+def _linear_big(x, w, bias, hip):
+    """x @ w^T (+ bias) for the two large products OUTSIDE the recurrence (the vocabulary layer over all time steps, models.py:211, and
+    its transposed data gradient): three bf16 MFMA products of in-kernel hi / lo splits (convops.linear_x3, ~1e-5) by default;
+    PPV_DEC_FC=f32 keeps the exact-f32 MFMA kernel of the per-step layers."""
+    import os
+    K = x.shape[1]
+    if (hip and os.environ.get("PPV_DEC_FC", "x3") == "x3" and K % 4 == 0 and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
+        return co.linear_x3(x, w, bias)
+    return _linear(x, w, bias, None, hip)
+
+
 def _tn(g, h, hip):
     """g [m, N], h [m, K] -> g^T h [N, K]: the batched weight gradients of the dense layers (models.py:199-214 under autograd:
     d W = sum over time steps and captions of (d out)^T in).  Exact f32 on the matrix pipe: both operands are copied transposed with
@@ -270,7 +282,7 @@ class _DecoderFn(torch.autograd.Function):
             HD = HS * dmask
         else:
             dmask, HD = None, HS
-        preds = _linear(HD.view(T * B, D), w_fc.detach().contiguous(), b_fc.detach(), None, hip_gemm).view(T, B, V)
+        preds = _linear_big(HD.view(T * B, D), w_fc.detach().contiguous(), b_fc.detach(), hip_gemm).view(T, B, V)
         preds.mul_(valid)                                        # positions past a caption's end stay exactly 0 (models.py:194)
 
         ctx.mod, ctx.dims = mod, (B, P, R, E, A, D, M, V, T, X)
@@ -311,7 +323,7 @@ class _DecoderFn(torch.autograd.Function):
             w_fcT[:, :V].copy_(w_fc.t())
         else:
             w_fcT = w_fc.t().contiguous()
-        dHS = _linear(gp2p, w_fcT, None, None, hip_gemm).view(T, B, D)
+        dHS = _linear_big(gp2p, w_fcT, None, hip_gemm).view(T, B, D)
         if dmask is not None:
             dHS = dHS * dmask
         ga = None if g_alphas is None else (g_alphas.transpose(0, 1).float() * valid).contiguous()

@@ -335,6 +335,27 @@ def test_gemm_bf16x3_tn_equals_the_matrix_product(K, M, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,bias", [(2176, 9490, 512, True), (2176, 512, 9504, False), (130, 200, 36, True), (64, 128, 4096, False)])
+def test_linear_x3_equals_the_matrix_product(M, N, K, bias):
+    """ppv_gemm_bf16x3_nt: x W^T + bias with row-major f32 operands as three bf16 products of in-kernel hi / lo splits (the decoder's
+    vocabulary layer over all time steps and its transposed data gradient), with and without the slab split, ragged tiles, a row
+    stride that is not the width."""
+    import ppv_amd.convops as co
+    g0 = torch.Generator().manual_seed(M + N + K)
+    xw = torch.randn(M, K + 8, generator=g0).cuda()
+    x = xw[:, :K]                                                    # strided rows
+    w = torch.randn(N, K, generator=g0).cuda()
+    b = torch.randn(N, generator=g0).cuda() if bias else None
+    got = co.linear_x3(x, w, b)
+    want = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    assert got.shape == (M, N)
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-5
+    xi = torch.randint(-8, 9, (M, K), generator=g0).float().cuda()
+    wi = torch.randint(-8, 9, (N, K), generator=g0).float().cuda()
+    assert torch.equal(co.linear_x3(xi, wi), (xi.double() @ wi.double().t()).float())       # exact on small integers: fragment maps
+
+
+@pytest.mark.gpu
 def test_staged_caption_lengths_give_the_same_forward():
     """DecoderWithAttention.stage_lengths (optional): the sorted lengths travel to the host early; forward() must return exactly what
     the reference-style call returns (same order, same decode lengths, same scores), fall back when the staged tensor is not the

@@ -17,6 +17,7 @@
 //   re-layout and the final scatter to NCHW f32.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <utility>
 #include "ppv_common.h"
 #include "ppv_hip.h"
 
@@ -825,6 +826,247 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const bf16_t* __r
                 }
 }
 
+// ----------------------------------------------------------------------------- 3x3 / stride 1 / pad 1 wgrad, ALL NINE taps per workgroup (round 5)
+// conv_wgrad3x3_kernel stages 40 KB per 64-row stage for 3 x 128 x 128 outputs: a G row is fetched by 3 kernel rows x Cs / 128 tiles, an X
+// row by 3 x N / 128 (each time with its halo).  The launch is bound by the bytes a CU can pull through its L2 -> LDS path (24 GB/s per
+// CU measured: 1.7 MB per workgroup in 72 us at the layer-3 shape), not by the matrix pipe (21 % busy).  Here a workgroup owns
+// 128 (n) x 64 (c) x NINE taps: ONE halo tile of the stage's image rows -1 .. rows_ps (each with W + 2 columns, [pixel][64 c] = 128-byte
+// rows) serves every tap, the G stage is fetched once per c-tile instead of once per (kernel row, c-tile): 16 + ~14 KB per stage for
+// 1.5 x the MFMA work (184 MAC per staged byte against 92), 8 tiles instead of 12 for layer 3.  Wave (wn, wc) owns 64 n x 16 c of every
+// tap: acc[9][4] (144 VGPRs); the four G fragments of a k-half are reused by nine taps (26 transposed reads per 36 MFMAs).
+// Halo rows are 128 bytes = 32 banks wide: the 32-byte block of a pixel row is XOR-swizzled with key2(h) = bit 1 | bit 3 << 1 of the halo
+// pixel index, which together with the row's parity (the half of the 64 banks it starts in) separates the eight pixel rows a
+// ds_read_b64_tr_b16 pass touches.  W in {8, 16, 32} (W = 64 keeps the three-tap kernel: its 198-pixel halo), H * W % 64 == 0.
+__device__ __forceinline__ int trkey2(int h) { return ((h >> 1) & 1) | (((h >> 3) & 1) << 1); }
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int OFF> __device__ __forceinline__ void tr_read_off(s16x4& v, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
+template <int NSTAGE, int LOG2W>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_t9_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                                  float* __restrict__ dW, const bf16_t* __restrict__ zero_page,
+                                                                  WgradGeom g) {
+    constexpr int log2W = LOG2W, XI = LOG2W == 5 ? 3 : 2;
+    constexpr int NW = 8, GI = 16 / NW, L = GI + XI;
+    constexpr int XBYTES = XI * NW * 1024, STAGE = 64 * 256 + XBYTES;        // G tile [64 m][128 n] + halo tile [<= XI * 64 pixels][64 c]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int W = 1 << log2W, WP = W + 2, rows_ps = 64 >> log2W;         // image rows per 64-pixel stage
+    constexpr int npix = (rows_ps + 2) * WP, nslots = (npix + 7) >> 3;
+    const int ctiles = g.Cs / 64, ntiles = g.N / 128;
+    const int tiles = ntiles * ctiles;
+    int zslice, tl;
+    if (g.xcd_group) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        zslice = (idx / tiles) * 8 + xcd;
+        tl = idx % tiles;
+    } else {
+        zslice = blockIdx.x / tiles;
+        tl = blockIdx.x % tiles;
+    }
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % ntiles) * 128, c0 = (tl / ntiles) * 64;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    const int nst = (int)((m_end - m_begin + 63) / 64);
+    if (nst <= 0) return;
+    const int HoWo = g.Ho * g.Wo;
+    const long zdX = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+    const float rcp_wp = 1.0f / (float)WP;
+
+    int st_next = 0;
+    auto stage = [&](int buf) {
+        char* sb = smem + buf * STAGE;
+        const long mb = m_begin + (long)st_next * 64;
+        ++st_next;
+        {
+            const int rli = lane >> 4, lch = lane & 15;
+#pragma unroll
+            for (int i = 0; i < GI; ++i) {
+                const int q = i * NW + wave, row = q * 4 + rli;
+                const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+                GLDS16W(reinterpret_cast<const char*>(G) + ((mb + row) * g.N + n0 + gch * 8) * 2, sb + q * 1024);
+            }
+        }
+        const int b = (int)(mb / HoWo), row0 = (int)(mb % HoWo) >> log2W;
+        const int pli = lane >> 3, lch = lane & 7;                            // 8 pixels x 8 chunks per wave-instruction
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            int q = i * NW + wave;
+            if (q >= nslots) q -= nslots;                                     // spare slots repeat a valid one (same bytes, same place)
+            if (q >= nslots) q -= nslots;
+            const int pp = q * 8 + pli;
+            int pr, pc;
+            fast_divmod(pp, WP, rcp_wp, pr, pc);
+            const int ho = row0 + pr - 1, wo = pc - 1;
+            const int gch = (((lch >> 1) ^ trkey2(pp)) << 1) | (lch & 1);
+            const bool ok = (pp < npix) & ((unsigned)ho < (unsigned)g.Hs) & ((unsigned)wo < (unsigned)W);
+            const long off = ok ? ((((long)b * g.Hs + ho) * W + wo) * g.Cs + c0 + gch * 8) * 2 : zdX;
+            GLDS16W(reinterpret_cast<const char*>(X) + off, sb + 64 * 256 + q * 1024);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave >> 2, wc = wave & 3;
+
+    // Fragment addresses.  The loop issues 52 transposed reads per wave and stage beside 72 MFMAs: with the addresses computed per read
+    // (~9 integer instructions each) the loop was bound by vector-instruction ISSUE (340 VALU x 4 cycles per wave against 72 x 16 of MFMA:
+    // tools/micro/tr_mfma_loop.hip, 2.17 us per stage against 1.08 us of MFMAs alone).  Everything that does not depend on the lane is an
+    // immediate offset of the DS instruction now (W is a template parameter): a G fragment = one of four per-lane bases + {0, 1 KB} +
+    // k-half x 8 KB (trkey is the same for rows r, r + 4, r + 32); an X fragment = per-lane base of the k-half + (r WP + s) x 128 (+ 512),
+    // plus the 32-byte block of the swizzle, which depends on bits 1 and 3 of the lane's halo pixel: nine 2-bit entries per k-half and
+    // row group packed in one register, one v_bfe + one v_lshl_add per read.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+    const int p8 = (lane & 3) * 8;
+    unsigned abase[4];
+    {
+        const int r0 = 8 * (lane >> 4) + ((lane >> 2) & 3);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) abase[mi] = lds0 + r0 * 256 + (((wn * 4 + mi) ^ trkey(r0)) * 32) + p8;
+    }
+    unsigned bbase[2], swz[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int k = kk * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
+        const int hb = (k >> log2W) * WP + (k & (W - 1));
+        bbase[kk] = lds0 + 64 * 256 + hb * 128 + p8;
+        swz[kk][0] = swz[kk][1] = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int h0 = hb + (t / 3) * WP + (t % 3);
+            swz[kk][0] |= (unsigned)(wc ^ trkey2(h0)) << (2 * t);
+            swz[kk][1] |= (unsigned)(wc ^ trkey2(h0 + 4)) << (2 * t);                // k % 8 < 4: k + 4 stays in the image row
+        }
+    }
+
+    // 18 units per stage (2 k-halves x 9 taps, 4 MFMAs each), software-pipelined ACROSS stages.  With the stage's barrier in front of its
+    // first fragment reads, all eight waves sat out the same LDS round trip in lockstep with the matrix pipe idle (2.2 us per stage in
+    // the kernel against 1.4 us for the same loop without a barrier, tools/micro/tr_mfma_loop.hip).  Here the barrier that publishes
+    // stage t + 1 (and frees the buffer of stage t - 1 for the DMA of stage t + NSTAGE - 1) sits between the two k-halves of stage t, and
+    // the units after it fetch across the boundary: the X fragments run LOOK units ahead in a ring of LOOK + 1 register pairs whatever the
+    // stage (18 % (LOOK + 1) == 0: static registers), the G fragments of the second k-half arrive during units 1-4, those of the NEXT
+    // stage's first k-half during units 10-13 (their registers are dead after unit 8).  Waits are counted (LDS operations return in
+    // order): unit u waits until only the reads issued after its own fragment remain.  The last stage fetches a stale buffer instead of
+    // a next stage (in range, never used): the counts stay static.
+    constexpr int LOOK = 2;
+    static_assert(18 % (LOOK + 1) == 0, "ring slots must be static across stages");
+    s16x4 alo[2][4], ahi[2][4], blo[LOOK + 1], bhi[LOOK + 1];
+    unsigned ab_cur[4], bb_cur[2], ab_nxt[4], bb_nxt, sw[2][2];
+    auto set_bases = [&](int cur, int nxt) {
+        const unsigned oc = (unsigned)(cur * STAGE), on = (unsigned)(nxt * STAGE);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { ab_cur[mi] = abase[mi] + oc; ab_nxt[mi] = abase[mi] + on; }
+        bb_cur[0] = bbase[0] + oc;
+        bb_cur[1] = bbase[1] + oc;
+        bb_nxt = bbase[0] + on;
+        sw[0][0] = swz[0][0]; sw[0][1] = swz[0][1]; sw[1][0] = swz[1][0]; sw[1][1] = swz[1][1];
+        asm volatile("" : "+v"(sw[0][0]), "+v"(sw[0][1]), "+v"(sw[1][0]), "+v"(sw[1][1]));   // the 36 block offsets are extracted per read, not kept in registers
+    };
+    // X fragment of unit v (0 .. 17: this stage; 18 ..: unit v - 18 of the next stage)
+    auto x_issue = [&](auto V_) {
+        constexpr int v = decltype(V_)::value, u = v % 18, kk = u / 9, t = u % 9, slot = v % (LOOK + 1);
+        constexpr int off = ((t / 3) * WP + (t % 3)) * 128;
+        const unsigned base = v < 18 ? bb_cur[kk] : bb_nxt;
+        tr_read_off<off>(blo[slot], base + (__builtin_amdgcn_ubfe(sw[kk][0], 2 * t, 2) << 5));
+        tr_read_off<off + 512>(bhi[slot], base + (__builtin_amdgcn_ubfe(sw[kk][1], 2 * t, 2) << 5));
+    };
+    auto a_issue_cur1 = [&](auto MI_) {                                     // second k-half of this stage
+        constexpr int mi = decltype(MI_)::value;
+        tr_read_off<8192>(alo[1][mi], ab_cur[mi]);
+        tr_read_off<8192 + 1024>(ahi[1][mi], ab_cur[mi]);
+    };
+    auto a_issue_nxt0 = [&](auto MI_, const unsigned (&ab)[4]) {            // first k-half of the next stage (or of stage 0 in the prologue)
+        constexpr int mi = decltype(MI_)::value;
+        tr_read_off<0>(alo[0][mi], ab[mi]);
+        tr_read_off<1024>(ahi[0][mi], ab[mi]);
+    };
+    auto units = [&](auto FIRST_) {                                          // units FIRST .. FIRST + 8
+        static_for([&](auto I_) {
+            constexpr int u = decltype(FIRST_)::value + decltype(I_)::value, kk = u / 9, t = u % 9;
+            // reads issued after the fragment of unit u (issued in unit u - LOOK in front of that unit's G piece): that piece, then the
+            // fragment and the piece of every unit up to u - 1
+            constexpr int after = [] {
+                auto pc = [](int w) { w = ((w % 18) + 18) % 18; return ((w >= 1 && w <= 4) || (w >= 10 && w <= 13)) ? 2 : 0; };
+                int a = pc(u - LOOK);
+                for (int w = u - LOOK + 1; w < u; ++w) a += 2 + pc(w);
+                return a;
+            }();
+            static_assert(after + 4 <= 15, "lgkmcnt is a 4-bit counter");
+            __builtin_amdgcn_sched_barrier(0);                                // the previous unit's MFMAs stay in front of this wait
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            x_issue(std::integral_constant<int, u + LOOK>{});
+            if constexpr (u >= 1 && u <= 4) a_issue_cur1(std::integral_constant<int, u - 1>{});
+            if constexpr (u >= 10 && u <= 13) a_issue_nxt0(std::integral_constant<int, u - 10>{}, ab_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 bf = tr_pack(blo[u % (LOOK + 1)], bhi[u % (LOOK + 1)]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pack(alo[kk][mi], ahi[kk][mi]), bf, acc[t][mi], 0, 0, 0);
+        }, std::make_integer_sequence<int, 9>{});
+    };
+
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nst) stage(s0);
+    {   // stage 0 has landed: its first fragments go out in front of the loop (the one exposed LDS round trip of the workgroup)
+        const int younger = min(nst, NSTAGE - 1) - 1;
+        if (NSTAGE >= 4 && younger >= 2) wg_wait_vmcnt_le<(NSTAGE >= 4 ? 2 * L : 0)>();
+        else if (younger >= 1) wg_wait_vmcnt_le<L>();
+        else wg_wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+        set_bases(0, 0);
+        static_for([&](auto MI_) { a_issue_nxt0(MI_, ab_cur); }, std::make_integer_sequence<int, 4>{});
+        static_for([&](auto V_) { x_issue(V_); }, std::make_integer_sequence<int, LOOK>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int cur = 0;
+    for (int t = 0; t < nst; ++t) {
+        const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+        set_bases(cur, nxt);
+        if (g.pf_dist != 1) units(std::integral_constant<int, 0>{});
+        // stage t + 1 visible to every wave; every wave is past stage t - 1: its buffer takes the DMA of stage t + NSTAGE - 1
+        const int younger = min(nst - 1, t + NSTAGE - 2) - (t + 1);
+        if (younger >= 1) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
+        else wg_wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nst && g.pf_dist != 2) stage((cur + NSTAGE - 1) % NSTAGE);
+        if (g.pf_dist != 1) units(std::integral_constant<int, 9>{});
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the stale look-ahead reads of the last stage
+
+    float* dst = dW + (long)zslice * g.slab_elems;
+    if (g.native_slabs) {                                      // accumulator-order slab: 36 records per lane (wgrad_reduce_native_body MODE 2)
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst) + ((long)(tl * 8 + wave) * 36) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) d4[(t * 4 + mi) * 64] = acc[t][mi];
+        return;
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    const long wrow = 9L * g.Cs;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + mi * 16 + fq * 4 + j;
+                const int c = c0 + wc * 16 + fr;
+                dst[(long)n * wrow + (long)t * g.Cs + c] = acc[t][mi][j];
+            }
+}
+
 // sum of nslab slabs [N][R][S][C] f32 -> torch [N][C][R][S] f32
 __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __restrict__ dW, float* __restrict__ out, int N, int C,
                                                              int R, int S, int nslab) {
@@ -840,7 +1082,7 @@ __global__ __launch_bounds__(256) void wgrad_to_torch_kernel(const float* __rest
 // sum of nslab accumulator-order slabs (native_slabs) -> torch [N][C][R][S] f32.  One thread per 16-byte record (a lane's four rows
 // of one 16 x 16 MFMA tile): nslab coalesced 16-byte loads, eight in flight, then four 4-byte stores (16 lanes = 64 contiguous bytes
 // of one output row for 1x1 weights).  MODE 0: conv_wgrad_pipe_kernel<TN> tiles (NW = TN / 32 waves, 16 records per wave and lane, one
-// tap per tile); MODE 1: conv_wgrad3x3_kernel tiles (8 waves, 24 records: three taps of kernel row r).
+// tap per tile); MODE 1: conv_wgrad3x3_kernel tiles (8 waves, 24 records: three taps of kernel row r); MODE 2: the nine-tap tiles.
 template <int MODE>
 __device__ __forceinline__ void wgrad_reduce_native_body(const float* __restrict__ slabs, float* __restrict__ out, int N, int C,
                                                             int R, int S, int nslab, int TN, long rec) {
@@ -868,6 +1110,14 @@ __device__ __forceinline__ void wgrad_reduce_native_body(const float* __restrict
         tap = by / ctiles;
         n = n0 + wm * 64 + mi * 16 + fq * 4;
         c = (by % ctiles) * 128 + wn * 64 + ni * 16 + fr;
+    } else if (MODE == 2) {                                    // conv_wgrad3x3_t9_kernel: 8 waves x 36 records (nine taps x four n-tiles)
+        const long q = rec >> 6;
+        const int t = (int)(q % 36), wave = (int)((q / 36) & 7), tl = (int)(q / 288);
+        const int mi = t & 3, wn = wave >> 2, wc = wave & 3;
+        const int ntiles = N / 128;
+        tap = t >> 2;
+        n = (tl % ntiles) * 128 + wn * 64 + mi * 16 + fq * 4;
+        c = (tl / ntiles) * 64 + wc * 16 + fr;
     } else {
         const long q = rec >> 6;
         const int t = (int)(q % 24), wave = (int)((q / 24) & 7), tl = (int)(q / 192);
@@ -899,6 +1149,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceMulti m) 
     const PpvWgradReduce& q = m.p[i];
     const long rec = (long)b * 256 + threadIdx.x;
     if (q.mode == 0) wgrad_reduce_native_body<0>((const float*)q.slabs, q.out, q.N, q.C, q.R, q.S, q.nslab, q.TN, rec);
+    else if (q.mode == 2) wgrad_reduce_native_body<2>((const float*)q.slabs, q.out, q.N, q.C, q.R, q.S, q.nslab, q.TN, rec);
     else wgrad_reduce_native_body<1>((const float*)q.slabs, q.out, q.N, q.C, q.R, q.S, q.nslab, q.TN, rec);
 }
 
@@ -1315,6 +1566,23 @@ static void wgrad3_plan(long M, int N, int Cs, long* splits, int* sps) {
     *splits = (stages + *sps - 1) / *sps;
 }
 
+// the nine-tap kernel (conv_wgrad3x3_t9_kernel): (N/128) x (Cs/64) tiles; PPV_WGRAD3_T9=0 keeps the three-tap kernel, PPV_WGRAD3_T9_WGS its
+// workgroup target
+static int wgrad3_t9() {
+    static const int t = getenv("PPV_WGRAD3_T9") ? atoi(getenv("PPV_WGRAD3_T9")) : 1;
+    return t;
+}
+static void wgrad3_t9_plan(long M, int N, int Cs, long* splits, int* sps) {
+    static const int target = getenv("PPV_WGRAD3_T9_WGS") ? atoi(getenv("PPV_WGRAD3_T9_WGS")) : 144;
+    const long stages = M / 64;
+    const int tiles = (N / 128) * (Cs / 64);
+    long sp = ((target < 8 ? 8 : target) + tiles - 1) / tiles;
+    if (sp > stages / 8) sp = stages / 8;
+    if (sp < 1) sp = 1;
+    *sps = (int)((stages + sp - 1) / sp);
+    *splits = (stages + *sps - 1) / *sps;
+}
+
 // m-slices of the streamed kernel (32-row stages)
 static void wgrad_stream_plan(long M, int N, int R, int S, int Cs, int* TN, long* splits, int* sps) {
     const long stages = (M + 31) / 32;
@@ -1349,6 +1617,8 @@ size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs) {
         long sp3;
         int sps3;
         wgrad3_plan(M, N, Cs, &sp3, &sps3);
+        if (sp3 > splits) splits = sp3;
+        wgrad3_t9_plan(M, N, Cs, &sp3, &sps3);
         if (sp3 > splits) splits = sp3;
     }
     {
@@ -1408,6 +1678,38 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
          (g_wgrad_variant & 0xff) == 9)) {
         long sp3;
         int sps3;
+        if (wgrad3_t9() && Wo <= 32 && !(g_wgrad_variant & 0x2000)) {            // all nine taps per workgroup (0x2000: the three-tap kernel, A/B)
+            wgrad3_t9_plan(g.M, N, Cs, &sp3, &sps3);
+            g.stages_per_split = sps3;
+            g.splits = (int)sp3;
+            g.slab_elems = elems;
+            g.native_slabs = wgrad_native_slabs();
+            g.xcd_group = (g_wgrad_variant & 0x200) ? 1 : 0;
+            g.pf_dist = getenv("PPV_WGRAD3_T9_DEBUG") ? atoi(getenv("PPV_WGRAD3_T9_DEBUG")) : 0;   // timing experiments: 1 = loads only, 2 = compute only (wrong results)
+            const long t9 = (long)(N / 128) * (Cs / 64);
+            const unsigned grid9 = (unsigned)(g.xcd_group ? 8 * ((sp3 + 7) / 8) * t9 : sp3 * t9);
+            constexpr int lds2 = 4 * (64 * 256 + 2 * 8192), lds3 = 3 * (64 * 256 + 3 * 8192);   // four 32-KB stages (W <= 16), three 40-KB stages (W = 32)
+            static bool attr9 = false;
+            if (!attr9) {
+                (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                attr9 = true;
+            }
+            if (Wo == 32)
+                conv_wgrad3x3_t9_kernel<3, 5><<<grid9, 512, lds3, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+            else if (Wo == 16)
+                conv_wgrad3x3_t9_kernel<4, 4><<<grid9, 512, lds2, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+            else
+                conv_wgrad3x3_t9_kernel<4, 3><<<grid9, 512, lds2, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+            if (g.native_slabs && deferred) {
+                *deferred = PpvWgradReduce{slabs, dW_out, N, Cs, R, S, (int)sp3, 128, 2, (int)((elems / 4 + 255) / 256)};
+                return ppv_last_error();
+            }
+            if (g.native_slabs) wgrad_reduce_native_kernel<2><<<(unsigned)((elems / 4 + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3, 128);
+            else wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)sp3);
+            return ppv_last_error();
+        }
         wgrad3_plan(g.M, N, Cs, &sp3, &sps3);
         g.stages_per_split = sps3;
         g.splits = (int)sp3;

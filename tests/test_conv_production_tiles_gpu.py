@@ -218,7 +218,10 @@ def test_halo_dgrad(B, H, Cin, Cout, k, stride):
 WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> the benchmark's split counts
     (32, 32, 256, 1024, 1, 1, 0),   # small-ring 128-wide tile, 1x1 (default under the side-stream overlap)
     (32, 32, 1024, 256, 1, 1, 0),
-    (32, 32, 256, 256, 3, 1, 0),    # fused-tap 3x3
+    (32, 32, 256, 256, 3, 1, 0),    # nine-tap 3x3 (round 5), 32-wide maps: three 40-KB stages
+    (64, 16, 256, 256, 3, 1, 0),    # nine-tap 3x3, 16-wide maps (layer 3): four 32-KB stages, halo 6 x 18 pixels
+    (32, 32, 256, 256, 3, 1, 0x2000),   # three-tap 3x3 (one kernel row per workgroup: rounds 2-4, still the 64-wide form)
+    (16, 64, 128, 128, 3, 1, 0),    # 64-wide maps stay on the three-tap kernel
     (32, 32, 256, 1024, 1, 1, 3),   # 256-wide three-stage tile
     (32, 32, 256, 256, 3, 1, 2),    # 3x3 through the one-tap-per-workgroup kernel (128-wide, four stages)
     (16, 64, 128, 128, 3, 2, 0),    # stride-2 3x3 (first block of a layer): M = 16 384 output pixels

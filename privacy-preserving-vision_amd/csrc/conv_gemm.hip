@@ -303,7 +303,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
     int a_inc[ASLOTS];
     auto retap = [&]() {
         if (g.flat) {
-            if (BK == 64 && g.chunked) {      // channel-chunked source [Cs / 64][M][64]: a K-step's 256 rows are ONE contiguous 32-KB block
+            if (BK == 64 && g.chunked == 1) {      // channel-chunked source [Cs / 64][M][64]: a K-step's 256 rows are ONE contiguous 32-KB block
 #pragma unroll
                 for (int i = 0; i < ASLOTS; ++i) {
                     a_off[i] = (a_ok[i] ? (long)a_pix[i] * 128 : zdelta) + cch * 16;
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
 #ifdef PPV_STAMPS
         if (t == 0) PPV_STAMP(2);
 #endif
-        if (t + NSTAGE - 1 < nk) stage(wr);
-        compute(rd);
+        if (t + NSTAGE - 1 < nk && g.chunked != 3) stage(wr);             // chunked 2 / 3: timing experiments (PPV_CONV_DEBUG: loads / compute only)
+        if (g.chunked != 2) compute(rd);
         rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
         wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
     }
@@ -505,6 +505,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.M = (long)B * Ho * Wo;
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     g.chunked = 0;
+    if (getenv("PPV_CONV_DEBUG") && atoi(getenv("PPV_CONV_DEBUG")) > 0) g.chunked = 1 + atoi(getenv("PPV_CONV_DEBUG"));   // 1 = loads only, 2 = compute only (wrong results: timing experiments)
     if (g_conv_variant & 0x1000) {            // layout A/B (tools/bench_layout_ab.py): flat launches on the BK = 64 tiles read a chunked source
         if (!g.flat || g.M * 128 >= (1L << 31)) return PPV_ERR_BAD_SIZE;
         g.chunked = 1;
@@ -562,7 +563,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     const int CUS = 256;
     int v = g_conv_variant & 0xfff;
     if (v >= 7) v = 0;
-    if (g.chunked && v != 2 && v != 3) return PPV_ERR_BAD_SIZE;   // the experiment exists on the two BK = 64 tiles
+    if (g.chunked == 1 && v != 2 && v != 3) return PPV_ERR_BAD_SIZE;   // the experiment exists on the two BK = 64 tiles
     if (N != 16 && N % 128 && (v == 0 || v >= 3) && g.M >= 128 * 1024) {
         PPV_LAUNCH_PIPE_R(128, 64, 3, 32, 4);   // 64-column layers (layer1): HBM-bound, four small-ring workgroups per CU
         return ppv_last_error();

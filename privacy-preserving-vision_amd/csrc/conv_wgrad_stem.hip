@@ -185,6 +185,12 @@ __device__ __forceinline__ bf16x8 tr_pack(const s16x4& lo, const s16x4& hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <class F, int... Is>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int OFF> __device__ __forceinline__ void tr_read_off(s16x4& v, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
 // exact floor(n / d), n - q*d for 0 <= n < 2^24 via a float reciprocal and one correction step
 __device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int& r) {
     q = (int)((float)n * rcp);
@@ -213,6 +219,11 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt_le() { asm volati
 // layer 3 (256 -> 1024 / 1024 -> 256 at 16 x 16) 59.6 / 57.1 us with the prefetch against 60.2 / 57.2 without, layer 2 (128 -> 512 at
 // 32 x 32) 80.3 against 71.5 (the extra 80 line requests per stage compete with the stage's own 256), layer 4 unchanged.  The
 // lockstep hit-under-miss picture is therefore NOT what bounds this kernel; kept opt-in (PPV_WGRAD_PF=<stages ahead>), default off.
+// MEASURED (round 5, PPV_WGRAD_DEBUG=1 / 2 = loads only / K loop only, rocprofv3 kernel times, layer-3 1x1 shapes, 256-wide tile): whole
+// kernel 35.4 us, loads only 24.8, K loop only 31.0 -- of which ~15 us are fixed per workgroup (first DMA round trip, the 128-KB slab
+// store, launch), not the loop: the same tile rebuilt on 32-row stages in a ring of six buffers with the fragment reads software-
+// pipelined across the stage barrier (the form that took the nine-tap 3x3 kernel from 97 to 76 us) measured 35.4 / 24.6 / 31.6 us: no
+// change, removed again.  What is left to take is the per-workgroup fixed cost (16 stages per workgroup), i.e. the split count.
 template <int TN, int NSTAGE, bool PF = false>
 __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X, float* __restrict__ dst,
                                                 const bf16_t* __restrict__ zero_page, const WgradGeom& g, long m_begin, long m_end,
@@ -340,8 +351,8 @@ __device__ __forceinline__ void wgrad_pipe_body(const bf16_t* __restrict__ G, co
         else if (NSTAGE >= 4 && younger == NSTAGE - 3) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0) + PFO>();
         else wg_wait_vmcnt_le<PFO>();
         __builtin_amdgcn_s_barrier();
-        if (t + NSTAGE - 1 < nst) stage(wr);
-        compute(rd);
+        if (t + NSTAGE - 1 < nst && !(!PF && g.pf_dist == 102)) stage(wr);
+        if (!(!PF && g.pf_dist == 101)) compute(rd);
         rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
         wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
     }
@@ -838,12 +849,6 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const bf16_t* __r
 // pixel index, which together with the row's parity (the half of the 64 banks it starts in) separates the eight pixel rows a
 // ds_read_b64_tr_b16 pass touches.  W in {8, 16, 32} (W = 64 keeps the three-tap kernel: its 198-pixel halo), H * W % 64 == 0.
 __device__ __forceinline__ int trkey2(int h) { return ((h >> 1) & 1) | (((h >> 3) & 1) << 1); }
-
-template <class F, int... Is>
-__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int OFF> __device__ __forceinline__ void tr_read_off(s16x4& v, unsigned addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-}
 
 template <int NSTAGE, int LOG2W>
 __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_t9_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
@@ -1797,6 +1802,7 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
         (void)hipMemsetAsync(slabs, 0, 8 * elems * sizeof(float), stream);
     }
     const unsigned grid = g.xcd_group ? (unsigned)(8 * ((splits + 7) / 8) * tiles) : (unsigned)(splits * tiles);
+    if (getenv("PPV_WGRAD_DEBUG")) g.pf_dist = 100 + atoi(getenv("PPV_WGRAD_DEBUG"));   // timing experiments: 1 = loads only, 2 = compute only (wrong results)
     if (TN == 256 && wide_stages == 2) {
         constexpr int lds = 2 * 3 * 64 * 256;
         static bool attr = false;

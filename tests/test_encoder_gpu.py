@@ -440,7 +440,10 @@ def test_trunk_plan_equals_the_per_kernel_path(layers, B, H, dense, one_adder_st
     from ppv_amd import trunk_exec
     torch.manual_seed(0)
     enc = Encoder(layers=layers).cuda().train()
-    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    # residual branches damped: a random-init trunk amplifies the last-bit differences of the atomics' order (the only difference between
+    # the runs) by orders of magnitude on the way back to the image -- undamped, the image gradient of two runs of the SAME path differs
+    # by 1.5e-2 .. 2.7e-2 from run to run
+    sd = {k: (v.clone() * 0.2 if k.endswith("bn3.weight") else v.clone()) for k, v in enc.state_dict().items()}
     img = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(5)).cuda()
     assert trunk_exec.usable(enc, True)
     plan = _run_trunk(enc, sd, img, dense)

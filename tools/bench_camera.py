@@ -27,15 +27,20 @@ def ic_step():
     (sensor.mean() + loss).backward()
 
 
-def timeit(fn, n=10, w=3):
+def timeit(fn, n=10, w=3, windows=3):
+    """Median of `windows` timed windows of n calls after w warm-up calls.  (One window right after the warm-up measured 4-10 ms per IC
+    step on some boxes against 0.93 ms in every later window: round 5, tools/cam_step_timing.py.)"""
     for _ in range(w):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    ts = []
+    for _ in range(windows):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / n)
+    return sorted(ts)[len(ts) // 2]
 
 
 t_ic = timeit(ic_step)

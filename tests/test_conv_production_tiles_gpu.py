@@ -258,6 +258,21 @@ def test_benchmark_sized_wgrad(B, H, Cin, Cout, k, stride, variant):
     assert rel_err(got, w.grad) < 1e-3
 
 
+@pytest.mark.parametrize("B,H,C", [(1, 8, 128), (2, 8, 128), (3, 8, 256), (5, 8, 128), (1, 16, 128), (3, 16, 128), (1, 32, 128), (2, 32, 256)])
+def test_nine_tap_wgrad_with_few_stages(B, H, C):
+    """conv_wgrad3x3_t9_kernel on one to a few 64-row stages (fewer than its ring holds: the prologue / last-stage paths of the
+    cross-stage pipeline), 8- / 16- / 32-wide maps, against torch autograd."""
+    import ppv_amd.convops as co
+    x, w = _mk(B, H, C, C, 3)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(11)).bfloat16().float()
+    y.backward(g)
+    co.zero_page(torch.device("cuda", 0))
+    got = co.conv_wgrad(g.permute(0, 2, 3, 1).contiguous().cuda().bfloat16(), x.permute(0, 2, 3, 1).contiguous().cuda().bfloat16(), 3, 3, 1, 1)
+    assert rel_err(got, w.grad) < 1e-3
+
+
 @pytest.mark.parametrize("P,B,H,Cin,Cout", [(3, 8, 16, 256, 128), (9, 32, 16, 1024, 256), (24, 4, 8, 128, 384), (2, 5, 7, 128, 128)])
 def test_grouped_wgrad(P, B, H, Cin, Cout):
     """co.conv_wgrad_group: P same-shape 1x1 weight gradients in one launch, un-split over the rows, against torch autograd per problem

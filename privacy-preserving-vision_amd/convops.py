@@ -404,6 +404,17 @@ def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, wan
     return (y, bits) if want_bits else y
 
 
+# BatchNorm backward in EVAL mode (running statistics are constants): g_x = scale * g (.) mask, d gamma = sum g x_hat, d beta = sum g.
+# The kernels compute train-mode g_x = k0 g + k1 x + k2 with k1, k2 proportional to 1 / count (csrc/trunk_ops.hip): an infinite
+# sample count makes both exactly zero while d gamma / d beta (which do not contain the count) stay right.  Set by the trunk's backward
+# around an eval-mode pass (encoder._TrunkFn.backward).
+EVAL_BN = False
+
+
+def _bn_count(rows):
+    return float("inf") if EVAL_BN else float(rows)
+
+
 def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False, sums2=None, out_affine=None):
     """-> (g_x bf16, g_pre bf16|None, dgamma f32|None, dbeta f32|None).  part: optional PRE-ZEROED f32 [64*C] scratch;
     part_ready: part already holds the sums (conv_dgrad(..., red=(x, part)) produced gy).  sums2 = (x2, part2): also take the
@@ -423,10 +434,10 @@ def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, p
     kc = torch.empty(3 * C, dtype=F32, device=dev)
     if sums2 is not None:               # (x2, part2): the projection shortcut's BN sums ride along (relu 0, no g_pre copy)
         assert not relu and not want_gpre
-        check(L().ppv_bn_bwd_sums2(ptr(gy), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(dg), ptr(db), ptr(part), ptr(kc), rows, C,
+        check(L().ppv_bn_bwd_sums2(ptr(gy), ptr(x), ptr(coef), _bn_count(rows), ptr(gx), ptr(dg), ptr(db), ptr(part), ptr(kc), rows, C,
                                    2 if part_ready else int(prezeroed), ptr(sums2[0]), ptr(sums2[1]), stream_ptr()), "ppv_bn_bwd_sums2")
         return gx, gpre, dg, db
-    check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), float(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
+    check(L().ppv_bn_bwd(ptr(gy), ptr(y), ptr(x), ptr(coef), _bn_count(rows), ptr(gx), ptr(gpre), ptr(dg), ptr(db), ptr(part),
                          ptr(kc), rows, C, int(relu), 2 if part_ready else int(prezeroed), stream_ptr()), "ppv_bn_bwd")
     return gx, gpre, dg, db
 
@@ -457,7 +468,7 @@ def maxpool_bn_bwd(gy, y, arg, x_raw, coef, want_affine=False):
     dg = torch.empty(C, dtype=F32, device=x_raw.device) if want_affine else None
     db = torch.empty(C, dtype=F32, device=x_raw.device) if want_affine else None
     part = torch.empty(16 * C, dtype=F32, device=x_raw.device)
-    check(L().ppv_maxpool_bn_bwd(ptr(gy), ptr(y), ptr(arg), ptr(x_raw), ptr(coef), float(B * H * W), ptr(gx), ptr(dg), ptr(db), ptr(part),
+    check(L().ppv_maxpool_bn_bwd(ptr(gy), ptr(y), ptr(arg), ptr(x_raw), ptr(coef), _bn_count(B * H * W), ptr(gx), ptr(dg), ptr(db), ptr(part),
                                  B, H, W, C, stream_ptr()), "ppv_maxpool_bn_bwd")
     return gx, dg, db
 

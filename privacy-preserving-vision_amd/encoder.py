@@ -345,6 +345,7 @@ class _TrunkFn(torch.autograd.Function):
             blocks = []
             import os as _os
             fused_bn = train and _os.environ.get("PPV_BN_FUSED", "0") == "1"      # 1: bn_finalize + bn_act in one launch (measured slower: DESIGN 4b)
+            want_bits = train or bool(getattr(enc, "_grad_wanted", False))        # eval mode under autograd: backward needs the ReLU masks too
             xin_bits = None        # (block input > 0) bit mask; the first block's input is the max-pool output, masked by its own backward
             for blk in enc._blocks:
                 xin = x
@@ -437,11 +438,11 @@ class _TrunkFn(torch.autograd.Function):
                     p = part_for(Bn * H2 * W2, rd.conv.out_channels)
                     xd = co.conv_fwd(xin, rd.wt(tok), rd.stride, 0, p)
                     cd = _bn_coef(rd, p, Bn * H2 * W2)
-                    yo = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=train)
+                    yo = co.bn_act(x3, c3, res=xd, coef_res=cd, want_bits=want_bits)
                 else:
                     xd = cd = None
-                    yo = co.bn_act(x3, c3, res=xin, want_bits=train)
-                yout, ybits = yo if train else (yo, None)
+                    yo = co.bn_act(x3, c3, res=xin, want_bits=want_bits)
+                yout, ybits = yo if want_bits else (yo, None)
                 blocks.append((xin, x1, c1, y1, x2, c2, y2, x3, c3, xd, cd, yout, xin_bits))
                 x, xin_bits = yout, ybits
         if getattr(enc, "lazy_output", False):
@@ -481,8 +482,20 @@ class _TrunkFn(torch.autograd.Function):
         enc = ctx.enc
         dev0 = (g_out if g_out is not None else g_cells).device
         if not ctx.train:
-            raise NotImplementedError("backward through eval-mode BatchNorm is outside the reference's use (validate() "
-                                      "runs under no_grad, train.py:355-451)")
+            # eval-mode BatchNorm (running statistics are constants; outside the reference's use -- validate() runs under no_grad,
+            # train.py:355-451 -- but a saliency / attack pass through the frozen trunk needs it): the same launches with an infinite
+            # sample count, which removes the batch-mean terms of the train-mode formula (convops.EVAL_BN)
+            co.EVAL_BN = True
+            try:
+                return _TrunkFn._backward(ctx, g_out, g_cells)
+            finally:
+                co.EVAL_BN = False
+        return _TrunkFn._backward(ctx, g_out, g_cells)
+
+    @staticmethod
+    def _backward(ctx, g_out, g_cells=None):
+        enc = ctx.enc
+        dev0 = (g_out if g_out is not None else g_cells).device
         grads = {}
         tok = ctx.tok
         if ctx.holder is not None:
@@ -707,7 +720,8 @@ class _TrunkFn(torch.autograd.Function):
         # crossing (csrc/block_exec.hip ppv_bottleneck_bwd: the calls below, same order, same arguments).  Only in the default
         # configuration: single process, no taps / per-class timing, default weight-gradient schedule.
         fast_bwd = (_os.environ.get("PPV_BLOCK_EXEC", "1") != "0" and (sync is None or (bucketed and side is not None)) and taps is None
-                    and co.PROFILE is None and not group_min and wsched == [0, 2, 4] and red_level == 3)
+                    and co.PROFILE is None and not group_min and wsched == [0, 2, 4] and red_level == 3
+                    and ctx.train)       # (eval-mode BatchNorm backward goes through convops.EVAL_BN: the per-kernel calls)
         if fast_bwd:
             bwa = _lib.BottleneckBwd()
             bwa.zero_page = co.zero_page(dev0).data_ptr()
@@ -899,7 +913,7 @@ class Encoder(nn.Module):
     # weight layouts and the per-conv records are runtime state, rebuilt on load
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_nbt_cache", "_wneed_cache", "_plans", "_bwd_main_stream"):
+        for k in ("_stem", "_blocks", "_wl", "_wl_prefetched", "_wgrad_stream", "grad_sync", "_debug_block_grads", "_plist_cache", "_plist_mid", "_last_fill", "_grad_wanted", "_nbt_cache", "_wneed_cache", "_plans", "_bwd_main_stream"):
             st.pop(k, None)
         return st
 
@@ -1017,6 +1031,7 @@ class Encoder(nn.Module):
     def forward(self, images):
         if not images.is_cuda:
             raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
+        object.__setattr__(self, "_grad_wanted", torch.is_grad_enabled())      # (autograd.Function.forward runs with grad mode off)
         out, cells = _TrunkFn.apply(self, images, *self._param_list())
         if getattr(self, "lazy_output", False):
             fill = self.__dict__.pop("_last_fill", None)

@@ -202,6 +202,37 @@ def test_eval_mode_uses_running_statistics():
         assert rel_err(enc(img.cuda()), ref(img)) < 3e-2
 
 
+def test_eval_mode_backward_against_the_oracle():
+    """Backward through the trunk in EVAL mode (BatchNorm on its running statistics: constants): the image gradient and every trainable
+    parameter gradient against the torch restatement in eval mode.  Outside the reference's use (train.py:355-451 validates under
+    no_grad), but a saliency / attack pass through the frozen encoder needs it; the kernels run their train-mode launches with an
+    infinite sample count (convops.EVAL_BN)."""
+    enc, ref = _pair((1, 2, 1, 1))
+    with torch.no_grad():                                          # running statistics that are not the initial (0, 1)
+        for m in list(enc.resnet.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+    ref.load_state_dict(enc.state_dict())
+    enc.eval(); ref.eval()
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    w = torch.randn(2, 36, 36, 2048, generator=torch.Generator().manual_seed(5))
+    xa = img.clone().cuda().requires_grad_(True)
+    xb = img.clone().requires_grad_(True)
+    (enc(xa) * w.cuda()).sum().backward()
+    (ref(xb) * w).sum().backward()
+    # (the max-norm error of the image gradient of this random-init net is 0.13-0.17 in TRAIN mode too: bf16 activations)
+    assert _cos(xa.grad, xb.grad) > 0.997 and abs(float(xa.grad.norm().cpu() / xb.grad.norm()) - 1) < 3e-2
+    ga = dict((n, p.grad) for n, p in enc.named_parameters() if p.requires_grad)
+    gb = dict((n, p.grad) for n, p in ref.named_parameters() if p.requires_grad)
+    assert set(ga) == set(gb) and len(ga) > 0
+    for n in ga:
+        assert ga[n] is not None and _cos(ga[n], gb[n]) > 0.995, n
+    # and the running statistics did not move
+    for (na, ba), (nb, bb) in zip(enc.named_buffers(), ref.named_buffers()):
+        assert na == nb and torch.equal(ba.cpu(), bb), na
+
+
 def test_state_dict_keys_are_torchvision_compatible():
     from ppv_amd.encoder import Encoder
     enc = Encoder()

@@ -521,10 +521,11 @@ def test_trunk_plan_at_the_benchmark_geometry_equals_the_per_kernel_path(monkeyp
     monkeypatch.setenv("PPV_BLOCK_EXEC", "0")
     per_kernel = _run_trunk(enc, sd, img, True)
     a, b = plan[0].float(), per_kernel[0].float()
-    assert rel_err(a, b) < 3e-2 and _l2(a, b) < 3e-2         # (measured 1.4e-2 / 1.3e-2; bit-equal on ~30 % of the elements: bf16 ulps through 33 damped blocks)
-    assert rel_err(a[4:8], a[:4]) < 2e-2                          # the copies went through other tiles of the same launches
+    # tolerances = 4-5x the largest value seen over repeated runs (the differences are the atomics' order, i.e. vary from run to run)
+    assert rel_err(a, b) < 6e-2 and _l2(a, b) < 6e-2         # (measured 1.4e-2 / 1.3e-2; bit-equal on ~30 % of the elements: bf16 ulps through 33 damped blocks)
+    assert rel_err(a[4:8], a[:4]) < 6e-2                          # the copies went through other tiles of the same launches
     for x, y in zip(plan[3], per_kernel[3]):
-        assert rel_err(x, y) < 2e-3                               # running statistics of activations that differ by bf16 ulps (measured 1.4e-4)
+        assert rel_err(x, y) < 1e-2                               # running statistics of activations that differ by bf16 ulps (measured 1.4e-4 .. 2.1e-3)
     # backward amplifies the bf16-ulp differences of the activations once more (33 blocks + stem): measured cos 0.992 on the image
     # gradient; a wrong arena offset, split count or tile would give ~0
     cos_img = _cos(plan[1], per_kernel[1])

@@ -505,7 +505,8 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.M = (long)B * Ho * Wo;
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     g.chunked = 0;
-    if (getenv("PPV_CONV_DEBUG") && atoi(getenv("PPV_CONV_DEBUG")) > 0) g.chunked = 1 + atoi(getenv("PPV_CONV_DEBUG"));   // 1 = loads only, 2 = compute only (wrong results: timing experiments)
+    static const int conv_debug = getenv("PPV_CONV_DEBUG") ? atoi(getenv("PPV_CONV_DEBUG")) : 0;   // 1 = loads only, 2 = compute only (wrong results: timing experiments)
+    if (conv_debug > 0) g.chunked = 1 + conv_debug;
     if (g_conv_variant & 0x1000) {            // layout A/B (tools/bench_layout_ab.py): flat launches on the BK = 64 tiles read a chunked source
         if (!g.flat || g.M * 128 >= (1L << 31)) return PPV_ERR_BAD_SIZE;
         g.chunked = 1;

@@ -1690,7 +1690,8 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
             g.slab_elems = elems;
             g.native_slabs = wgrad_native_slabs();
             g.xcd_group = (g_wgrad_variant & 0x200) ? 1 : 0;
-            g.pf_dist = getenv("PPV_WGRAD3_T9_DEBUG") ? atoi(getenv("PPV_WGRAD3_T9_DEBUG")) : 0;   // timing experiments: 1 = loads only, 2 = compute only (wrong results)
+            static const int t9_debug = getenv("PPV_WGRAD3_T9_DEBUG") ? atoi(getenv("PPV_WGRAD3_T9_DEBUG")) : 0;   // timing experiments: 1 = loads only, 2 = compute only (wrong results)
+            g.pf_dist = t9_debug;
             const long t9 = (long)(N / 128) * (Cs / 64);
             const unsigned grid9 = (unsigned)(g.xcd_group ? 8 * ((sp3 + 7) / 8) * t9 : sp3 * t9);
             constexpr int lds2 = 4 * (64 * 256 + 2 * 8192), lds3 = 3 * (64 * 256 + 3 * 8192);   // four 32-KB stages (W <= 16), three 40-KB stages (W = 32)
@@ -1802,7 +1803,8 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
         (void)hipMemsetAsync(slabs, 0, 8 * elems * sizeof(float), stream);
     }
     const unsigned grid = g.xcd_group ? (unsigned)(8 * ((splits + 7) / 8) * tiles) : (unsigned)(splits * tiles);
-    if (getenv("PPV_WGRAD_DEBUG")) g.pf_dist = 100 + atoi(getenv("PPV_WGRAD_DEBUG"));   // timing experiments: 1 = loads only, 2 = compute only (wrong results)
+    static const int wgrad_debug = getenv("PPV_WGRAD_DEBUG") ? atoi(getenv("PPV_WGRAD_DEBUG")) : 0;   // timing experiments: 1 = loads only, 2 = compute only (wrong results)
+    if (wgrad_debug > 0) g.pf_dist = 100 + wgrad_debug;
     if (TN == 256 && wide_stages == 2) {
         constexpr int lds = 2 * 3 * 64 * 256;
         static bool attr = false;

@@ -450,18 +450,22 @@ __global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __res
     float* sW = sA2 + A;
     float* sE = sW + A;
     float* sBeta = sE + Q;
+    float* sWq = sBeta + C;                                               // [Q]   class tables staged once (dependent walks: see the
+    int* sCells = reinterpret_cast<int*>(sWq + Q);                        // [Q][4]  backward kernel)
     __shared__ float s8[8];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
     for (int i = tid; i < C * A / 8; i += 512) reinterpret_cast<uint4*>(sT)[i] = src[i];
     for (int a = tid; a < A; a += 512) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
     for (int c = tid; c < C; c += 512) sBeta[c] = 0.f;
+    for (int q = tid; q < Q; q += 512) sWq[q] = tb.w[q];
+    for (int i = tid; i < 4 * Q; i += 512) sCells[i] = tb.cells[i];
     __syncthreads();
     for (int q = wave; q < Q; q += 8) {
-        const float wq = tb.w[q];
+        const float wq = sWq[q];
         int cell[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cell[k] = tb.cells[q * 4 + k];
+        for (int k = 0; k < 4; ++k) cell[k] = sCells[q * 4 + k];
         float acc = 0.f;
         for (int a0 = lane * 8; a0 < A; a0 += 512) {
             float pre[8];
@@ -503,10 +507,10 @@ __global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __res
         const float al = sE[q] * inv;                               // alpha of EVERY pixel of class q
         sE[q] = al;
         alq_out[(long)b * Q + q] = al;
-        const float bw = al * tb.mult[q] * tb.w[q];
+        const float bw = al * tb.mult[q] * sWq[q];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = tb.cells[q * 4 + k];
+            const int c = sCells[q * 4 + k];
             if (c >= 0) atomicAdd(&sBeta[c], bw);
         }
     }
@@ -515,65 +519,79 @@ __global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __res
     for (int c = tid; c < C; c += 512) beta_out[(long)b * C + c] = sBeta[c];
 }
 
-// grid (bt, ceil(C / 16)), 256 threads: workgroup y owns 16 cells of image b.  dfb [bt][C] = d awe . feat[b,c,:] (from
+// grid (bt), 1024 threads: ONE workgroup per image, wave w owns cells w, w + 16, ...  dfb [bt][C] = d awe . feat[b,c,:] (from
 // dec_ctx_bwd_kernel run on the cells), galpha [bt][P] or null = the caller's gradient on the returned per-pixel alphas.
-// Class-total softmax backward (every workgroup of the image redoes the 225-term prelude), then GATHER form of the relu /
-// encoder_att backward: a cell sums w_q d pre_q over the <= 12 classes it belongs to (cell_cls [C][12], -1 padded) -- no
-// atomics on the big accumulator, one read-modify-write of the cell's d att1c row; d att2 / d w_full are taken once per class
-// (by the workgroup that owns the class's first cell) with f32 atomics.
-__global__ __launch_bounds__(256) void decc_score_bwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
-                                                             int ldh, const float* __restrict__ wfull, ClassTables tb,
-                                                             const int* __restrict__ cell_cls, const float* __restrict__ alq,
-                                                             const float* __restrict__ dfb, const float* __restrict__ galpha,
-                                                             float* __restrict__ datt1c, float* __restrict__ dhproj,
-                                                             float* __restrict__ dwfull, int P, int Q, int C, int A) {
+// Class-total softmax backward, then GATHER form of the relu / encoder_att backward: a cell sums w_q d pre_q over the <= 12 classes it
+// belongs to (cell_cls [C][12], -1 padded) -- no atomics on the big accumulator, one read-modify-write of the cell's d att1c row; d att2 /
+// d w_full are taken once per class (by the wave that owns the class's first cell), folded across the waves in LDS and stored once.
+// (Round 5: was four 256-thread workgroups per image, each re-loading the image's 64-KB att1c table and redoing the 225-term prelude,
+// with 2 x 512 f32 GLOBAL atomics per wave on rows shared by 16 adders: 68 us per step; the atomics were the cost.)
+__global__ __launch_bounds__(1024) void decc_score_bwd_kernel(const bf16_t* __restrict__ att1c, const float* __restrict__ hproj,
+                                                              int ldh, const float* __restrict__ wfull, ClassTables tb,
+                                                              const int* __restrict__ cell_cls, const float* __restrict__ alq,
+                                                              const float* __restrict__ dfb, const float* __restrict__ galpha,
+                                                              float* __restrict__ datt1c, float* __restrict__ dhproj,
+                                                              float* __restrict__ dwfull, int P, int Q, int C, int A) {
     extern __shared__ __attribute__((aligned(16))) char smc[];
     bf16_t* sT = reinterpret_cast<bf16_t*>(smc);                          // [C][A] bf16
     float* sA2 = reinterpret_cast<float*>(smc + (size_t)C * A * 2);       // [A]
     float* sW = sA2 + A;                                                  // [A]
-    float* sDe = sW + A;                                                  // [Q] class-total d e
+    float* sDa2 = sW + A;                                                 // [A] d att2 of this image
+    float* sDw = sDa2 + A;                                                // [A] d w_full of this image
+    float* sDe = sDw + A;                                                 // [Q] class-total d e
     float* sGa = sDe + Q;                                                 // [Q]
-    __shared__ float s4[4];
+    // the class tables, staged once: the loops below walk them with DEPENDENT indices (cell -> classes -> member cells), which from
+    // global memory is one L2 round trip per step of the walk (~50 per wave: most of the kernel's 50 us)
+    float* sWq = sGa + Q;                                                 // [Q]
+    int* sCells = reinterpret_cast<int*>(sWq + Q);                        // [Q][4]
+    int* sCls = sCells + 4 * Q;                                           // [C][12]
+    __shared__ float s16[16];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
-    for (int i = tid; i < C * A / 8; i += 256) reinterpret_cast<uint4*>(sT)[i] = src[i];
-    for (int a = tid; a < A; a += 256) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
-    for (int q = tid; q < Q; q += 256) sGa[q] = 0.f;
+    for (int i = tid; i < C * A / 8; i += 1024) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    for (int a = tid; a < A; a += 1024) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; sDa2[a] = 0.f; sDw[a] = 0.f; }
+    for (int q = tid; q < Q; q += 1024) { sGa[q] = 0.f; sWq[q] = tb.w[q]; }
+    for (int i = tid; i < 4 * Q; i += 1024) sCells[i] = tb.cells[i];
+    for (int i = tid; i < 12 * C; i += 1024) sCls[i] = cell_cls[i];
     __syncthreads();
     if (galpha)
-        for (int p = tid; p < P; p += 256) atomicAdd(&sGa[tb.pix_class[p]], galpha[(long)b * P + p]);
+        for (int p = tid; p < P; p += 1024) atomicAdd(&sGa[tb.pix_class[p]], galpha[(long)b * P + p]);
     __syncthreads();
     float part = 0.f;
-    for (int q = tid; q < Q; q += 256) {
+    for (int q = tid; q < Q; q += 1024) {
         float d = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = tb.cells[q * 4 + k];
+            const int c = sCells[q * 4 + k];
             if (c >= 0) d += dfb[(long)b * C + c];
         }
-        const float Dq = tb.mult[q] * tb.w[q] * d + sGa[q];
+        const float Dq = tb.mult[q] * sWq[q] * d + sGa[q];
         sGa[q] = Dq;
         part += alq[(long)b * Q + q] * Dq;
     }
-    const float S = block_sum(part, s4);
-    for (int q = tid; q < Q; q += 256) sDe[q] = alq[(long)b * Q + q] * (sGa[q] - tb.mult[q] * S);
+    part = wave_sum(part);
+    if (lane == 0) s16[wave] = part;
     __syncthreads();
-    const int c_lo = blockIdx.y * 16, c_hi = min(c_lo + 16, C);
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) S += s16[w];
+    for (int q = tid; q < Q; q += 1024) sDe[q] = alq[(long)b * Q + q] * (sGa[q] - tb.mult[q] * S);
+    __syncthreads();
     for (int a0 = lane * 8; a0 < A; a0 += 512) {
         float a2[8], wv[8], da2[8], dw[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { a2[k] = sA2[a0 + k]; wv[k] = sW[a0 + k]; da2[k] = dw[k] = 0.f; }
-        for (int c = c_lo + wave; c < c_hi; c += 4) {
+        for (int c = wave; c < C; c += 16) {
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < 12; ++j) {
-                const int q = cell_cls[c * 12 + j];
+                const int q = sCls[c * 12 + j];
                 if (q < 0) break;                                          // wave-uniform
-                const float wq = tb.w[q], de = sDe[q];
-                const bool first = tb.cells[q * 4] == c;                   // this workgroup accounts the class for d att2 / d w
+                const float wq = sWq[q], de = sDe[q];
+                const bool first = sCells[q * 4] == c;                     // this wave accounts the class for d att2 / d w
                 float pre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int cc = tb.cells[q * 4 + k];
+                    const int cc = sCells[q * 4 + k];
                     if (cc < 0) continue;
                     const uint4 v = *reinterpret_cast<const uint4*>(sT + (long)cc * A + a0);
                     pre[0] += bflo(v.x); pre[1] += bfhi(v.x); pre[2] += bflo(v.y); pre[3] += bfhi(v.y);
@@ -594,10 +612,15 @@ __global__ __launch_bounds__(256) void decc_score_bwd_kernel(const bf16_t* __res
             g[0] = v0; g[1] = v1;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            atomicAdd(&dhproj[(long)b * ldh + a0 + k], da2[k]);
-            atomicAdd(&dwfull[(long)b * A + a0 + k], dw[k]);   // per-image rows: <= 16 adders per address (one shared row: 2048)
+        for (int k = 0; k < 8; ++k) {                                      // 16 waves per address, LDS atomics
+            atomicAdd(&sDa2[a0 + k], da2[k]);
+            atomicAdd(&sDw[a0 + k], dw[k]);
         }
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 1024) {                                  // the only workgroup of this image: plain read-modify-write
+        dhproj[(long)b * ldh + a] += sDa2[a];
+        dwfull[(long)b * A + a] += sDw[a];
     }
 }
 
@@ -731,7 +754,7 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
     if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !alpha_out || !alq_out ||
         !beta_out || !awe_save || !xh)
         return PPV_ERR_NULL;
-    const size_t lds = (size_t)C * A * 2 + (size_t)(2 * A + Q + C) * 4;
+    const size_t lds = (size_t)C * A * 2 + (size_t)(2 * A + 6 * Q + C) * 4;
     if (bt < 1 || A % 8 || E % 8 || A > 2048 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
@@ -743,7 +766,7 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
 }
 
 // Adjoint of ppv_decc_attend_fwd.  cell_cls [C][12] (classes a cell belongs to, -1 padded); dfb [bt][C] scratch; datt1c
-// [B][C][A] f32 ACCUMULATED; dhproj first A columns PRE-ZEROED; dwfull [B][A] PER-IMAGE rows ACCUMULATED (sum over b afterwards);
+// [B][C][A] f32 ACCUMULATED; dhproj first A columns ACCUMULATED (dec_ctx_bwd writes the rest); dwfull [B][A] PER-IMAGE rows ACCUMULATED (sum over b afterwards);
 // dawe_out [bt][E] (kept for the batched
 // beta^T . d awe GEMM); galpha [bt][P] or null.  C*A*2 + (2A+2Q)*4 <= 150 KB.
 int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj, int ldh, const float* wfull, const int* cls_cells,
@@ -754,7 +777,7 @@ int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj,
     if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !cell_cls || !alq || !awe_save ||
         !dxh || !dhproj || !dawe_out || !dfb || !datt1c || !dwfull)
         return PPV_ERR_NULL;
-    const size_t lds = (size_t)C * A * 2 + (size_t)(2 * A + 2 * Q) * 4;
+    const size_t lds = (size_t)C * A * 2 + (size_t)(4 * A + 7 * Q + 12 * C) * 4;
     if (bt < 1 || A % 8 || E % 8 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
@@ -762,7 +785,7 @@ int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj,
     dec_ctx_bwd_kernel<<<dim3(bt, (C + PS - 1) / PS), 256, E * sizeof(float), stream>>>(
         (const bf16_t*)feat, dxh, ldx, x_off, hproj, ldh, A, awe_save, nullptr, dhproj, dawe_out, dfb, C, E, PS);
     ClassTables tb{cls_cells, cls_w, cls_mult, pix_class};
-    decc_score_bwd_kernel<<<dim3(bt, (C + 15) / 16), 256, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, cell_cls, alq, dfb,
+    decc_score_bwd_kernel<<<bt, 1024, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, cell_cls, alq, dfb,
                                                                        galpha, datt1c, dhproj, dwfull, P, Q, C, A);
     return ppv_last_error();
 }

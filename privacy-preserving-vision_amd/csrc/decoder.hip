@@ -29,15 +29,27 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+// Wave-wide reductions on the DPP path: quad_perm xor 1 / xor 2, row_half_mirror, row_mirror leave every lane of a 16-lane row with
+// the row's total, four v_readlane fold the rows.  (Written with __shfl_xor the six steps compile to ds_bpermute_b32: six DEPENDENT
+// LDS round trips, ~0.7 us per reduction -- the compact score kernel does one per class, 28 per wave: 22 of its 29 us, round 5.)
+#define PPV_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += PPV_DPP(v, 0xB1);                                     // quad_perm [1,0,3,2]
+    v += PPV_DPP(v, 0x4E);                                     // quad_perm [2,3,0,1]
+    v += PPV_DPP(v, 0x141);                                    // row_half_mirror
+    v += PPV_DPP(v, 0x140);                                    // row_mirror
+    const int i = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, PPV_DPP(v, 0xB1));
+    v = fmaxf(v, PPV_DPP(v, 0x4E));
+    v = fmaxf(v, PPV_DPP(v, 0x141));
+    v = fmaxf(v, PPV_DPP(v, 0x140));
+    const int i = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48))));
 }
 // block-wide (256 threads) reductions through 4 LDS words
 __device__ __forceinline__ float block_sum(float v, float* s4) {
@@ -248,17 +260,29 @@ __global__ __launch_bounds__(256) void dec_ctx_bwd_kernel(const bf16_t* __restri
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int p = p0 + wave; p < p1; p += 4) {
-        const bf16_t* row = encs + ((long)b * P + p) * E;
-        float acc = 0.f;
+    // four rows per wave at a time: their loads are in flight together (one row after the other was one L2 round trip per row and
+    // 512-column piece: 33 us for the 64 cells of the compact path)
+    for (int pb = p0 + wave; pb < p1; pb += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int e0 = lane * 8; e0 < E; e0 += 512) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row + e0);
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = min(pb + 4 * i, p1 - 1);                         // (a clamped row is computed and dropped)
+                v[i] = *reinterpret_cast<const uint4*>(encs + ((long)b * P + p) * E + e0);
+            }
             const float* d = sD + e0;
-            acc += bflo(v.x) * d[0] + bfhi(v.x) * d[1] + bflo(v.y) * d[2] + bfhi(v.y) * d[3] + bflo(v.z) * d[4] +
-                   bfhi(v.z) * d[5] + bflo(v.w) * d[6] + bfhi(v.w) * d[7];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] += bflo(v[i].x) * d[0] + bfhi(v[i].x) * d[1] + bflo(v[i].y) * d[2] + bfhi(v[i].y) * d[3] + bflo(v[i].z) * d[4] +
+                          bfhi(v[i].z) * d[5] + bflo(v[i].w) * d[6] + bfhi(v[i].w) * d[7];
         }
-        acc = wave_sum(acc);
-        if (lane == 0) dalpha[(long)b * P + p] = acc + (dalpha_in ? dalpha_in[(long)b * P + p] : 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pb + 4 * i;
+            const float a = wave_sum(acc[i]);
+            if (lane == 0 && p < p1) dalpha[(long)b * P + p] = a + (dalpha_in ? dalpha_in[(long)b * P + p] : 0.f);
+        }
     }
 }
 
@@ -445,8 +469,8 @@ __global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __res
                                                              float* __restrict__ alpha_out, float* __restrict__ alq_out,
                                                              float* __restrict__ beta_out, int P, int Q, int C, int A) {
     extern __shared__ __attribute__((aligned(16))) char smc[];
-    bf16_t* sT = reinterpret_cast<bf16_t*>(smc);
-    float* sA2 = reinterpret_cast<float*>(smc + (size_t)C * A * 2);
+    bf16_t* sT = reinterpret_cast<bf16_t*>(smc);                          // [C + 1][A]: row C is zero (the "no cell" slot of a class)
+    float* sA2 = reinterpret_cast<float*>(smc + (size_t)(C + 1) * A * 2);
     float* sW = sA2 + A;
     float* sE = sW + A;
     float* sBeta = sE + Q;
@@ -455,34 +479,67 @@ __global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __res
     __shared__ float s8[8];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
-    for (int i = tid; i < C * A / 8; i += 512) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    // eight 16-byte loads in flight per thread (written as `sT[i] = src[i]` the loop compiled to load / wait / store per iteration: eight
+    // serial L2 round trips for the 64-KB table, a third of the kernel)
+    for (int i0 = tid; i0 < C * A / 8; i0 += 8 * 512) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[min(i0 + k * 512, C * A / 8 - 1)];
+        __builtin_amdgcn_sched_barrier(0);                                 // (a clamped index re-writes the last chunk with its own value:
+#pragma unroll                                                             //  no branch for the compiler to sink the loads into)
+        for (int k = 0; k < 8; ++k) reinterpret_cast<uint4*>(sT)[min(i0 + k * 512, C * A / 8 - 1)] = v[k];
+    }
     for (int a = tid; a < A; a += 512) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; }
     for (int c = tid; c < C; c += 512) sBeta[c] = 0.f;
     for (int q = tid; q < Q; q += 512) sWq[q] = tb.w[q];
-    for (int i = tid; i < 4 * Q; i += 512) sCells[i] = tb.cells[i];
+    for (int i = tid; i < 4 * Q; i += 512) { const int c = tb.cells[i]; sCells[i] = c < 0 ? C : c; }
+    for (int a = tid; a < A / 2; a += 512) reinterpret_cast<unsigned*>(sT + (size_t)C * A)[a] = 0u;
     __syncthreads();
-    for (int q = wave; q < Q; q += 8) {
-        const float wq = sWq[q];
-        int cell[4];
+    // (the four member rows of a class are read UNCONDITIONALLY -- unused slots point at the zero row: behind a branch per slot each
+    // read waited for the one before it, four LDS round trips per class and wave)
+    // per 512-channel piece: this lane's att2 / w_full values stay in registers, a class = FOUR row reads issued together (as
+    // written before -- read, wait, unpack per row, then eight dependent reads of att2 / w_full -- a class cost 12 serial LDS round
+    // trips: 0.7 us, 20 of the kernel's 29 us), two classes per iteration
+    for (int piece = 0; piece * 512 < A; ++piece) {                        // wave-uniform: the reductions below need every lane
+        const bool live = piece * 512 + lane * 8 < A;                     // (A < 512: the lanes past the end carry zero weights)
+        const int a0 = live ? piece * 512 + lane * 8 : 0;
+        float a2[8], wv[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cell[k] = sCells[q * 4 + k];
-        float acc = 0.f;
-        for (int a0 = lane * 8; a0 < A; a0 += 512) {
-            float pre[8];
+        for (int k = 0; k < 8; ++k) { a2[k] = sA2[a0 + k]; wv[k] = live ? sW[a0 + k] : 0.f; }
+        for (int q0 = wave; q0 < Q; q0 += 16) {
+            float acc[2];
+            uint4 v[2][4];
+            float wq[2];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) pre[k] = 0.f;
+            for (int u = 0; u < 2; ++u) {
+                const int q = min(q0 + 8 * u, Q - 1);
+                wq[u] = sWq[q];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (cell[k] < 0) continue;
-                const uint4 v = *reinterpret_cast<const uint4*>(sT + (long)cell[k] * A + a0);
-                pre[0] += bflo(v.x); pre[1] += bfhi(v.x); pre[2] += bflo(v.y); pre[3] += bfhi(v.y);
-                pre[4] += bflo(v.z); pre[5] += bfhi(v.z); pre[6] += bflo(v.w); pre[7] += bfhi(v.w);
+                for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const uint4*>(sT + (long)sCells[q * 4 + k] * A + a0);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += fmaxf(pre[k] * wq + sA2[a0 + k], 0.f) * sW[a0 + k];
+            for (int u = 0; u < 2; ++u) {
+                float pre[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 w = v[u][k];
+                    pre[0] += bflo(w.x); pre[1] += bfhi(w.x); pre[2] += bflo(w.y); pre[3] += bfhi(w.y);
+                    pre[4] += bflo(w.z); pre[5] += bfhi(w.z); pre[6] += bflo(w.w); pre[7] += bfhi(w.w);
+                }
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += fmaxf(pre[k] * wq[u] + a2[k], 0.f) * wv[k];
+                acc[u] = a;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + 8 * u;
+                const float t = wave_sum(acc[u]);
+                if (lane == 0 && q < Q) sE[q] = piece ? sE[q] + t : t;
+            }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) sE[q] = acc;
     }
     __syncthreads();
     float m = -3.4e38f;
@@ -511,7 +568,7 @@ __global__ __launch_bounds__(512) void decc_score_fwd_kernel(const bf16_t* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = sCells[q * 4 + k];
-            if (c >= 0) atomicAdd(&sBeta[c], bw);
+            if (c < C) atomicAdd(&sBeta[c], bw);
         }
     }
     __syncthreads();
@@ -533,8 +590,8 @@ __global__ __launch_bounds__(1024) void decc_score_bwd_kernel(const bf16_t* __re
                                                               float* __restrict__ datt1c, float* __restrict__ dhproj,
                                                               float* __restrict__ dwfull, int P, int Q, int C, int A) {
     extern __shared__ __attribute__((aligned(16))) char smc[];
-    bf16_t* sT = reinterpret_cast<bf16_t*>(smc);                          // [C][A] bf16
-    float* sA2 = reinterpret_cast<float*>(smc + (size_t)C * A * 2);       // [A]
+    bf16_t* sT = reinterpret_cast<bf16_t*>(smc);                          // [C + 1][A] bf16: row C is zero (the "no cell" slot of a class)
+    float* sA2 = reinterpret_cast<float*>(smc + (size_t)(C + 1) * A * 2); // [A]
     float* sW = sA2 + A;                                                  // [A]
     float* sDa2 = sW + A;                                                 // [A] d att2 of this image
     float* sDw = sDa2 + A;                                                // [A] d w_full of this image
@@ -548,11 +605,19 @@ __global__ __launch_bounds__(1024) void decc_score_bwd_kernel(const bf16_t* __re
     __shared__ float s16[16];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint4* src = reinterpret_cast<const uint4*>(att1c + (long)b * C * A);
-    for (int i = tid; i < C * A / 8; i += 1024) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    for (int i0 = tid; i0 < C * A / 8; i0 += 4 * 1024) {                   // four loads in flight per thread (see the forward kernel)
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + k * 1024, C * A / 8 - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<uint4*>(sT)[min(i0 + k * 1024, C * A / 8 - 1)] = v[k];
+    }
     for (int a = tid; a < A; a += 1024) { sA2[a] = hproj[(long)b * ldh + a]; sW[a] = wfull[a]; sDa2[a] = 0.f; sDw[a] = 0.f; }
     for (int q = tid; q < Q; q += 1024) { sGa[q] = 0.f; sWq[q] = tb.w[q]; }
-    for (int i = tid; i < 4 * Q; i += 1024) sCells[i] = tb.cells[i];
+    for (int i = tid; i < 4 * Q; i += 1024) { const int c = tb.cells[i]; sCells[i] = c < 0 ? C : c; }
     for (int i = tid; i < 12 * C; i += 1024) sCls[i] = cell_cls[i];
+    for (int a = tid; a < A / 2; a += 1024) reinterpret_cast<unsigned*>(sT + (size_t)C * A)[a] = 0u;
     __syncthreads();
     if (galpha)
         for (int p = tid; p < P; p += 1024) atomicAdd(&sGa[tb.pix_class[p]], galpha[(long)b * P + p]);
@@ -563,7 +628,7 @@ __global__ __launch_bounds__(1024) void decc_score_bwd_kernel(const bf16_t* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = sCells[q * 4 + k];
-            if (c >= 0) d += dfb[(long)b * C + c];
+            if (c < C) d += dfb[(long)b * C + c];
         }
         const float Dq = tb.mult[q] * sWq[q] * d + sGa[q];
         sGa[q] = Dq;
@@ -583,17 +648,20 @@ __global__ __launch_bounds__(1024) void decc_score_bwd_kernel(const bf16_t* __re
         for (int k = 0; k < 8; ++k) { a2[k] = sA2[a0 + k]; wv[k] = sW[a0 + k]; da2[k] = dw[k] = 0.f; }
         for (int c = wave; c < C; c += 16) {
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float4* g = reinterpret_cast<float4*>(datt1c + ((long)b * C + c) * A + a0);
+            float4 v0 = g[0], v1 = g[1];                                   // the row this cell accumulates into: requested before the class walk
             for (int j = 0; j < 12; ++j) {
                 const int q = sCls[c * 12 + j];
                 if (q < 0) break;                                          // wave-uniform
                 const float wq = sWq[q], de = sDe[q];
                 const bool first = sCells[q * 4] == c;                     // this wave accounts the class for d att2 / d w
                 float pre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                uint4 v4[4];                                                // the four member rows in flight together (unused slots
+#pragma unroll                                                              // read the zero row: no branch, no wait between the reads)
+                for (int k = 0; k < 4; ++k) v4[k] = *reinterpret_cast<const uint4*>(sT + (long)sCells[q * 4 + k] * A + a0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int cc = sCells[q * 4 + k];
-                    if (cc < 0) continue;
-                    const uint4 v = *reinterpret_cast<const uint4*>(sT + (long)cc * A + a0);
+                    const uint4 v = v4[k];
                     pre[0] += bflo(v.x); pre[1] += bfhi(v.x); pre[2] += bflo(v.y); pre[3] += bfhi(v.y);
                     pre[4] += bflo(v.z); pre[5] += bfhi(v.z); pre[6] += bflo(v.w); pre[7] += bfhi(v.w);
                 }
@@ -605,8 +673,6 @@ __global__ __launch_bounds__(1024) void decc_score_bwd_kernel(const bf16_t* __re
                     if (first) { da2[k] += dp; dw[k] += de * fmaxf(pr, 0.f); }
                 }
             }
-            float4* g = reinterpret_cast<float4*>(datt1c + ((long)b * C + c) * A + a0);
-            float4 v0 = g[0], v1 = g[1];
             v0.x += acc[0]; v0.y += acc[1]; v0.z += acc[2]; v0.w += acc[3];
             v1.x += acc[4]; v1.y += acc[5]; v1.z += acc[6]; v1.w += acc[7];
             g[0] = v0; g[1] = v1;
@@ -630,7 +696,7 @@ using namespace ppv;
 
 extern "C" {
 
-static inline int dec_slab(int P) { return 48 < P ? 48 : P; }
+static inline int dec_slab(int P) { return P <= 64 ? 16 : 48; }      // pixels (cells) per workgroup of the context kernels: four rows per wave
 
 // models.py:181-183,151 : gather by the length sort, bf16 copy and per-image mean.  mean [B][E] PRE-ZEROED.  E % 8 == 0.
 int ppv_dec_prepare(const float* enc, const long* order, void* encs, float* mean, int B, int P, int E, hipStream_t stream) {
@@ -754,7 +820,7 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
     if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !alpha_out || !alq_out ||
         !beta_out || !awe_save || !xh)
         return PPV_ERR_NULL;
-    const size_t lds = (size_t)C * A * 2 + (size_t)(2 * A + 6 * Q + C) * 4;
+    const size_t lds = (size_t)(C + 1) * A * 2 + (size_t)(2 * A + 6 * Q + C) * 4;
     if (bt < 1 || A % 8 || E % 8 || A > 2048 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
@@ -777,7 +843,7 @@ int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj,
     if (!att1c || !feat || !hproj || !wfull || !cls_cells || !cls_w || !cls_mult || !pix_class || !cell_cls || !alq || !awe_save ||
         !dxh || !dhproj || !dawe_out || !dfb || !datt1c || !dwfull)
         return PPV_ERR_NULL;
-    const size_t lds = (size_t)C * A * 2 + (size_t)(4 * A + 7 * Q + 12 * C) * 4;
+    const size_t lds = (size_t)(C + 1) * A * 2 + (size_t)(4 * A + 7 * Q + 12 * C) * 4;
     if (bt < 1 || A % 8 || E % 8 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }

@@ -33,6 +33,14 @@ __device__ __forceinline__ void unpack8_(const uint4 u, float (&f)[8]) {
         f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
     }
 }
+__device__ __forceinline__ void unpack8u(const uint4 u, float (&f)[8]) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
 __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
     unsigned w[4];
 #pragma unroll
@@ -576,29 +584,40 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const bf16_t* __re
     if (i >= tot) return;
     const int c0 = (int)(i % c8n) * 8;
     const int wo = (int)((i / c8n) % Wo), ho = (int)((i / ((long)c8n * Wo)) % Ho), b = (int)(i / ((long)c8n * Wo * Ho));
+    // The nine taps are requested TOGETHER from clamped coordinates and masked afterwards: behind a bounds branch per tap (round 1-4
+    // form) every tap was its own load -> wait -> compare round trip, nine serial L2 / HBM latencies per thread (147 us for 335 MB).
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = coef[c0 + k]; sh[k] = coef[C + c0 + k]; }
+    uint4 raw[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int h = 2 * ho - 1 + t / 3, w = 2 * wo - 1 + t % 3;
+        ok[t] = ((unsigned)h < (unsigned)H) & ((unsigned)w < (unsigned)W);
+        const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+        raw[t] = *reinterpret_cast<const uint4*>(x + (((long)b * H + hc) * W + wc) * C + c0);
+    }
     float best[8];
     int bi[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int t = 0; t < 9; ++t) {
+        float xv[8];
+        unpack8u(raw[t], xv);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int h = 2 * ho - 1 + r, w = 2 * wo - 1 + s;
-            if (h < 0 || w < 0 || h >= H || w >= W) continue;
-            float xv[8];
-            load8(x + (((long)b * H + h) * W + w) * C + c0, xv);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // the activation is stored as bf16 downstream: compare the ROUNDED values
-                const float v = bf2f_(f2bf_(fmaxf(xv[k] * coef[c0 + k] + coef[C + c0 + k], 0.f)));
-                if (v > best[k]) { best[k] = v; bi[k] = r * 3 + s; }
-            }
+        for (int k = 0; k < 8; ++k) {
+            // the activation is stored as bf16 downstream: compare the ROUNDED values
+            float v = bf2f_(f2bf_(fmaxf(xv[k] * sc[k] + sh[k], 0.f)));
+            v = ok[t] ? v : -INFINITY;
+            if (v > best[k]) { best[k] = v; bi[k] = t; }
         }
+    }
     store8(y + i * 8, best);
     unsigned long long packed = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) packed |= (unsigned long long)bi[k] << (8 * k);
+    for (int k = 0; k < 8; ++k) packed |= (unsigned long long)(best[k] > 0.f ? bi[k] : 0xff) << (8 * k);   // 0xff: the window's maximum is 0 (no tap takes a gradient)
     *reinterpret_cast<unsigned long long*>(arg + i * 8) = packed;
 }
 
@@ -640,26 +659,41 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const bf16_t* __r
 // (reads it + the raw conv output) and the apply pass (reads both again, writes g_x): 1.8 GB.  The pre-pool gradient is a GATHER of
 // the pooled gradient (<= 4 windows per pixel), so both BatchNorm passes can take it straight from the 67-MB pooled tensors: pass 1
 // = the sums (sum g_pre, sum g_pre * x per channel, 8 partial rows), pass 2 = coefficients in the prologue + g_x.  1.1 GB.
+// The <= 2 x 2 windows a pre-pool pixel can belong to are fetched TOGETHER from clamped indices and masked afterwards (a bounds branch
+// per window made every window its own arg / g / y round trip: four serial latencies per pixel, 219 us for the stem's 700 MB).
 __device__ __forceinline__ void maxpool_gather8(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ y,
                                                 const unsigned char* __restrict__ arg, int b, int h, int w, int c0, int Ho, int Wo, int C,
                                                 float (&acc)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int ho = (h + 1) / 2 - 1; ho <= (h + 1) / 2; ++ho) {
-        const int r = h + 1 - 2 * ho;
-        if (ho < 0 || ho >= Ho || r < 0 || r > 2) continue;
-        for (int wo = (w + 1) / 2 - 1; wo <= (w + 1) / 2; ++wo) {
-            const int s = w + 1 - 2 * wo;
-            if (wo < 0 || wo >= Wo || s < 0 || s > 2) continue;
-            const long o = (((long)b * Ho + ho) * Wo + wo) * C + c0;
-            const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(arg + o);
-            float g[8], yv[8];
-            load8(gy + o, g);
-            load8(y + o, yv);
+    const int ho0 = (h + 1) / 2 - 1, wo0 = (w + 1) / 2 - 1;
+    unsigned long long pk[4];
+    uint4 gv[4];
+    int tap[4];
+    bool ok[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((int)((packed >> (8 * k)) & 0xff) == r * 3 + s && yv[k] > 0.f) acc[k] += g[k];
+    for (int q = 0; q < 4; ++q) {
+        const int ho = ho0 + (q >> 1), wo = wo0 + (q & 1);
+        const int r = h + 1 - 2 * ho, s = w + 1 - 2 * wo;
+        ok[q] = ((unsigned)ho < (unsigned)Ho) & ((unsigned)wo < (unsigned)Wo) & ((unsigned)r <= 2u) & ((unsigned)s <= 2u);
+        tap[q] = r * 3 + s;
+        const int hc = min(max(ho, 0), Ho - 1), wc = min(max(wo, 0), Wo - 1);
+        const long o = (((long)b * Ho + hc) * Wo + wc) * C + c0;
+        // lanes whose candidate is not a window of their pixel (2.25 of the 4 are, on average) do not fetch: the loads are predicated
+        // per lane, the use below is arithmetic (no second branch for the compiler to sink the loads into)
+        pk[q] = 0xffffffffffffffffull;
+        gv[q] = make_uint4(0, 0, 0, 0);
+        if (ok[q]) {                                           // (the pooled activation itself is not needed: a window whose maximum is 0
+            pk[q] = *reinterpret_cast<const unsigned long long*>(arg + o);   //  carries the tap byte 0xff, bn_relu_maxpool_kernel)
+            gv[q] = *reinterpret_cast<const uint4*>(gy + o);
         }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float g[8];
+        unpack8u(gv[q], g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += ((int)((pk[q] >> (8 * k)) & 0xff) == tap[q]) ? g[k] : 0.f;   // (no fetch: tap byte 0xff)
     }
 }
 
@@ -708,8 +742,9 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const bf16_t* __res
             if (pix >= npix) break;
             const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
             float acc[8], xv[8];
+            const uint4 xr = *reinterpret_cast<const uint4*>(x + pix * C + c0);   // in flight with the gather's loads
             maxpool_gather8(gy, y, arg, b, h, w, c0, Ho, Wo, C, acc);
-            load8(x + pix * C + c0, xv);
+            unpack8u(xr, xv);
             if (APPLY) {
                 float o[8];
 #pragma unroll
@@ -763,12 +798,24 @@ __global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const bf16_t* __res
     const long npool = (long)B * Ho * Wo;
     const long p0 = (long)blockIdx.x * rpp * ppw;
     if (tr < rpp) {
-        for (int it = 0; it < ppw; ++it) {
-            const long o = p0 + (long)it * rpp + tr;
-            if (o >= npool) break;
+        for (int it0 = 0; it0 < ppw; it0 += 4) {                   // four pooled pixels in flight per thread
+            uint4 gr[4], yr[4];
+            long oo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long o = p0 + (long)(it0 + u) * rpp + tr;
+                oo[u] = (it0 + u < ppw && o < npool) ? o : -1;
+                const long oc = oo[u] < 0 ? 0 : o;
+                gr[u] = *reinterpret_cast<const uint4*>(gy + oc * C + c0);
+                yr[u] = *reinterpret_cast<const uint4*>(y + oc * C + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+            const long o = oo[u];
+            if (o < 0) continue;
             float g[8], yv[8];
-            load8(gy + o * C + c0, g);
-            load8(y + o * C + c0, yv);
+            unpack8u(gr[u], g);
+            unpack8u(yr[u], yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (!(yv[k] > 0.f)) continue;
@@ -781,6 +828,7 @@ __global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const bf16_t* __res
                 }
                 sa[k] += g[k];
                 sb[k] += g[k] * xv;
+            }
             }
         }
     }

@@ -591,11 +591,19 @@ __global__ __launch_bounds__(256) void dfft_rows_kernel(const C2* __restrict__ i
     const long row = blockIdx.x;          // l * RR + y
     Tw1344<C2> w;
     if (C1344) tw1344_load(w, twg, tid);
-    for (int i = tid; i < M; i += 256) {
-        if (!C1344) s_tw[i] = twg[i];
-        const int x = i - pad;
-        s_a[i] = (x >= 0 && x < RR) ? in[row * RR + x] : CT<C2>::mk(0, 0);
+    {   // the row's <= 6 elements per thread in flight together (see dfft_cols1_kernel)
+        C2 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = in[row * RR + min(max(tid + k * 256 - pad, 0), RR - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + k * 256, x = i - pad;
+            if (i < M) s_a[i] = (x >= 0 && x < RR) ? v[k] : CT<C2>::mk(0, 0);
+        }
     }
+    if (!C1344)
+        for (int i = tid; i < M; i += 256) s_tw[i] = twg[i];
     __syncthreads();
     const C2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, (const C2*)s_tw, pl, tid, 256);
     const int l = (int)(row / RR), y = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
@@ -678,9 +686,20 @@ __global__ __launch_bounds__(256) void dfft_cols1_kernel(const C2* __restrict__ 
     const int CB = (M % 8 == 0) ? 8 : 2;
     if (TW_LDS)
         for (int i = tid; i < M; i += 256) s_tw[i] = twg[i];
-    for (int i = tid; i < M; i += 256) {
-        const int y = i - pad;
-        s_a[i] = (y >= 0 && y < RR) ? T1[tix(l, y, kx, RR, M, CB)] : CT<C2>::mk(0, 0);
+    {   // the <= 6 elements of a thread are requested together (MAXM = 1344 = 5.25 x 256): one round trip instead of one per element
+        static_assert(MAXM <= 6 * 256, "six elements per thread");
+        C2 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int y = min(max(tid + k * 256 - pad, 0), RR - 1);
+            v[k] = T1[tix(l, y, kx, RR, M, CB)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + k * 256, y = i - pad;
+            if (i < M) s_a[i] = (y >= 0 && y < RR) ? v[k] : CT<C2>::mk(0, 0);
+        }
     }
     __syncthreads();
     const C2* tw = TW_LDS ? (const C2*)s_tw : twg;
@@ -692,11 +711,21 @@ __global__ __launch_bounds__(256) void dfft_cols1_kernel(const C2* __restrict__ 
     C2* r = dfft256(s_a, s_b, tw, w, pl2, tid);
     C2* o = (r == s_a) ? s_b : s_a;
     const float2* hcol = Ht + ((long)l * M + kx) * M;
-    for (int i = tid; i < M; i += 256) {
-        const float2 hf = hcol[i];
-        const C2 hv = CT<C2>::mk((R_)hf.x, conj_h ? -(R_)hf.y : (R_)hf.y);
-        const C2 v = dmul(r[i], hv);
-        r[i] = CT<C2>::mk(v.x, -v.y);                  // conj for the inverse transform
+    {
+        float2 hf6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hf6[k] = hcol[min(tid + k * 256, M - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + k * 256;
+            if (i < M) {
+                const float2 hf = hf6[k];
+                const C2 hv = CT<C2>::mk((R_)hf.x, conj_h ? -(R_)hf.y : (R_)hf.y);
+                const C2 v = dmul(r[i], hv);
+                r[i] = CT<C2>::mk(v.x, -v.y);          // conj for the inverse transform
+            }
+        }
     }
     __syncthreads();
     const C2* z = dfft256(r, o, tw, w, pl2, tid);
@@ -719,11 +748,19 @@ __global__ __launch_bounds__(256) void difft_rows_kernel(const C2* __restrict__ 
     const int l_ = (int)(row / RR), y_ = (int)(row % RR), CB = (M % 8 == 0) ? 8 : 2;
     Tw1344<C2> w;
     if (C1344) tw1344_load(w, twg, tid);
-    for (int i = tid; i < M; i += 256) {
-        if (!C1344) s_tw[i] = twg[i];
-        const C2 v = T2[tix(l_, y_, i, RR, M, CB)];
-        s_a[i] = CT<C2>::mk(v.x, -v.y);
+    {
+        C2 v6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v6[k] = T2[tix(l_, y_, min(tid + k * 256, M - 1), RR, M, CB)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + k * 256;
+            if (i < M) s_a[i] = CT<C2>::mk(v6[k].x, -v6[k].y);
+        }
     }
+    if (!C1344)
+        for (int i = tid; i < M; i += 256) s_tw[i] = twg[i];
     __syncthreads();
     const C2* r = C1344 ? dfft_1344(s_a, s_b, w, tid) : dfft(s_a, s_b, (const C2*)s_tw, pl, tid, 256);
     for (int i = tid; i < RR; i += 256) {

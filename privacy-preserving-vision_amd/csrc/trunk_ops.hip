@@ -201,16 +201,31 @@ __global__ __launch_bounds__(256) void bn_act_fold_wg_kernel(const bf16_t* __res
     // statistics of this thread's channels: all loads first (they return right behind the rows), then the arithmetic
     constexpr int TR = 4;                              // partial rows held in registers (more rows: a second, dependent round of loads)
     float ps[CPT][TR], pq[CPT][TR], pg[CPT], pb[CPT];
+    // unconditional loads from clamped indices, a scheduling fence, THEN the masks: written as `cond ? load : 0` every load sat in its own
+    // branch with its own wait -- 2 T serial round trips in front of every workgroup's first store (round 5)
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int c = threadIdx.x + j * 256;
-        const bool ok = c < C;
+        const int cc = min((int)threadIdx.x + j * 256, C - 1);
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            ps[j][t] = (ok && t < T) ? sums[((long)t * 2) * C + c] : 0.f;
-            pq[j][t] = (ok && t < T) ? sums[((long)t * 2 + 1) * C + c] : 0.f;
+            const long o = ((long)min(t, T - 1) * 2) * C + cc;
+            ps[j][t] = sums[o];
+            pq[j][t] = sums[o + C];
         }
-        pg[j] = ok ? gamma[c] : 0.f; pb[j] = ok ? beta[c] : 0.f;
+        pg[j] = gamma[cc];
+        pb[j] = beta[cc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const bool ok = (int)threadIdx.x + j * 256 < C;
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            ps[j][t] = (ok && t < T) ? ps[j][t] : 0.f;
+            pq[j][t] = (ok && t < T) ? pq[j][t] : 0.f;
+        }
+        pg[j] = ok ? pg[j] : 0.f;
+        pb[j] = ok ? pb[j] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {

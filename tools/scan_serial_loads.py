@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "privacy-preserving-vision_amd", "csrc")
-files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+files = [os.path.abspath(f) for f in sys.argv[1:]] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 out = "/tmp/ppv_isa"
 os.makedirs(out, exist_ok=True)
 for f in files:

@@ -42,5 +42,5 @@ for f in files:
         sq = "".join(seq)
         lone = len(re.findall(r"(?<!L)Lw", sq))
         if sq.count("L") >= 3 and lone >= 2:
-            demangled = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()[:70]
+            demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()[:70]
             print(f"  {demangled:70s} loads {sq.count('L'):3d}  lone {lone:3d}  {sq[:70]}")

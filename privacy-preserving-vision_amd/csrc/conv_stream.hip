@@ -219,27 +219,32 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                         }
                     }
                 }
+                // operands of the four chunks this lane stores in this step (rows prow, prow + 8 of both row blocks), ALL requested before
+                // the first store of the step: a wait for loads issued behind a store also waits for that store (one in-order counter)
+                uint4 av_[MI][2], xv_[MI][2];
+                unsigned mb_[MI][2];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    // operands of the two chunks this lane stores for this row block (rows prow, prow + 8), requested before the
-                    // transposition
-                    uint4 av[2], xv[2];
-                    unsigned mb[2];
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const unsigned m = (unsigned)m0 + wave * 32 + mi * 16 + h * 8 + prow;
                         const bool ok = FULL || m < (unsigned)g.M;
                         const unsigned off = (ok ? m : 0u) * (unsigned)g.N + c;  // ragged tile: row 0 stands in, the result is dropped
                         // (32-bit element offsets: SGPR base + VGPR offset addressing, the host checks M * N < 2^31)
-                        av[h] = xv[h] = make_uint4(0, 0, 0, 0);
-                        mb[h] = 0xff;
-                        if constexpr (ADD) av[h] = *reinterpret_cast<const uint4*>(addend + off);
+                        av_[mi][h] = xv_[mi][h] = make_uint4(0, 0, 0, 0);
+                        mb_[mi][h] = 0xff;
+                        if constexpr (ADD) av_[mi][h] = *reinterpret_cast<const uint4*>(addend + off);
                         if constexpr (RED) {
-                            xv[h] = *reinterpret_cast<const uint4*>(red_x + off);
-                            if (!ok) xv[h] = make_uint4(0, 0, 0, 0);
+                            xv_[mi][h] = *reinterpret_cast<const uint4*>(red_x + off);
+                            if (!ok) xv_[mi][h] = make_uint4(0, 0, 0, 0);
                         }
-                        if constexpr (MASK) mb[h] = mask_bits[off >> 3];
+                        if constexpr (MASK) mb_[mi][h] = mask_bits[off >> 3];
                     }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    uint4 (&av)[2] = av_[mi];
+                    uint4 (&xv)[2] = xv_[mi];
+                    unsigned (&mb)[2] = mb_[mi];
                     // ---- transposition of the 16 x 64 block through the wave's private patch
                     if constexpr (!ADD) {
 #pragma unroll

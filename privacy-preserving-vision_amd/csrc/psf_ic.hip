@@ -426,8 +426,25 @@ __global__ __launch_bounds__(256) void zernike_contract_sym_kernel(const float* 
     const long npx2 = (long)R * R / 2;
     const float2* z = reinterpret_cast<const float2*>(Z) + ix.q;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // 32 planes in flight per thread: the quadrant has only 100 k threads (six waves per CU), eight 8-byte loads each did not cover
+    // the memory latency (94 us for 220 MB); the sums keep their k order (bit-identical to the full pass)
+    int k = 0;
+    for (; k + 32 <= K; k += 32) {
+        float2 v32[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v32[j] = z[(long)(k + j) * npx2];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float2 v = v32[j];
+            const float c0 = s_c4[k + j], c1 = s_c4[K + k + j], c2 = s_c4[2 * K + k + j], c3 = s_c4[3 * K + k + j];
+            a[0] += (double)(c0 * v.x); a[1] += (double)(c0 * v.y);
+            a[2] += (double)(c1 * v.x); a[3] += (double)(c1 * v.y);
+            a[4] += (double)(c2 * v.x); a[5] += (double)(c2 * v.y);
+            a[6] += (double)(c3 * v.x); a[7] += (double)(c3 * v.y);
+        }
+    }
 #pragma unroll 8
-    for (int k = 0; k < K; ++k) {
+    for (; k < K; ++k) {
         const float2 v = z[(long)k * npx2];
         const float c0 = s_c4[k], c1 = s_c4[K + k], c2 = s_c4[2 * K + k], c3 = s_c4[3 * K + k];
         a[0] += (double)(c0 * v.x); a[1] += (double)(c0 * v.y);
@@ -446,6 +463,12 @@ __global__ __launch_bounds__(256) void zernike_contract_sym_kernel(const float* 
 // eight per-lane sums are folded over the wave together -- each of the first three exchange steps keeps the half of the values the
 // lane's bit selects, so a round costs 10 f64 exchanges instead of 48.
 __device__ __forceinline__ double shx(double v, int off) { return __shfl_xor(v, off, 64); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {      // the other lane's f64 through two 32-bit DPP moves (full EXEC)
+    const long long i = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)(i & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)((unsigned long long)i >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 __global__ __launch_bounds__(256) void zernike_grad_sym_kernel(const float* __restrict__ Z, const float* __restrict__ gh,
                                                                double* __restrict__ part, int K, int R,
                                                                const unsigned char* __restrict__ support,
@@ -488,26 +511,32 @@ __global__ __launch_bounds__(256) void zernike_grad_sym_kernel(const float* __re
             const double ey = cl == 0 ? dy[0] : cl == 1 ? dy[1] : cl == 2 ? dy[2] : dy[3];
             a[j] = (double)v[j].x * ex + (double)v[j].y * ey;
         }
-        // fold: after the three halving steps lane l holds the sum over its 8-lane-strided group of value ((l>>5)&1)*4 + ((l>>4)&1)*2 + ((l>>3)&1)
-        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        // fold.  The three HALVING steps (4, 2, 1 values exchanged) use the lane bits the DPP path can pair exactly -- xor 1 and xor 2
+        // (quad_perm), xor 8 (row_ror:8) --, the single value left is then summed over bit 2 (row_shl / row_shr by 4) and over bits 4 and
+        // 5 through the LDS crossbar: 4 ds_bpermute per round instead of 20 (each a dependent LDS round trip: they were most of the
+        // kernel's 73 us).  Lane l ends with value (l & 1) * 4 + ((l >> 1) & 1) * 2 + ((l >> 3) & 1) summed over the wave.
+        const bool h0 = lane & 1, h1 = lane & 2, h3 = lane & 8;
         double b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double keep = h5 ? a[4 + j] : a[j], give = h5 ? a[j] : a[4 + j];
-            b[j] = keep + shx(give, 32);
+            const double keep = h0 ? a[4 + j] : a[j], give = h0 ? a[j] : a[4 + j];
+            b[j] = keep + dpp_d<0xB1>(give);                      // quad_perm [1,0,3,2]: lane ^ 1
         }
         double c2[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const double keep = h4 ? b[2 + j] : b[j], give = h4 ? b[j] : b[2 + j];
-            c2[j] = keep + shx(give, 16);
+            const double keep = h1 ? b[2 + j] : b[j], give = h1 ? b[j] : b[2 + j];
+            c2[j] = keep + dpp_d<0x4E>(give);                     // quad_perm [2,3,0,1]: lane ^ 2
         }
-        double d = (h3 ? c2[1] : c2[0]) + shx(h3 ? c2[0] : c2[1], 8);
-        d += shx(d, 4);
-        d += shx(d, 2);
-        d += shx(d, 1);
-        const int which = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-        if ((lane & 7) == 0 && k + which < K) row[k + which] = d;
+        double d = (h3 ? c2[1] : c2[0]) + dpp_d<0x128>(h3 ? c2[0] : c2[1]);   // row_ror:8 = lane ^ 8 inside a 16-lane row
+        {
+            const double up = dpp_d<0x104>(d), dn = dpp_d<0x114>(d);          // row_shl:4 (lane + 4), row_shr:4 (lane - 4)
+            d += (lane & 4) ? dn : up;                                        // lane ^ 4
+        }
+        d += shx(d, 16);
+        d += shx(d, 32);
+        const int which = (lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 3) & 1);
+        if ((lane & 0x34) == 0 && k + which < K) row[k + which] = d;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = vn[j];
     }

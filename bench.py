@@ -620,6 +620,14 @@ def main():
     if use_graph:
         step = graph_step(step, device)
 
+    # The interpreter's cyclic garbage collector is parked for the warm-up + timed steps (everything the steps allocate is freed by
+    # reference counting; a generation-2 sweep over the ~10^5 live objects of the modules takes 10-30 ms, i.e. 1-2 of the K = 20 timed
+    # steps: one driver-style run in round 5 read 23.28 ms per step with a host enqueue time of 17 ms against 21.70 / 11 in the run
+    # before it on the same box).  A training script gets the same with gc.freeze() after its set-up.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -633,6 +641,16 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PPV_BENCH_WINDOWS") and world == 1:   # diagnosis: more windows of K steps after the reported one (stderr only)
+        for wi in range(int(os.environ["PPV_BENCH_WINDOWS"])):
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            print(f"[bench] window {wi + 2}: {(time.perf_counter() - tw) / args.steps * 1e3:.3f} ms per step (reported window: {elapsed / args.steps * 1e3:.3f})",
+                  file=sys.stderr, flush=True)
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1499,6 +1499,84 @@ __global__ __launch_bounds__(512, 1) void stem_dgrad_rows_kernel(const bf16_t* _
     }
 }
 
+// Strip form of the above (round 5).  stem_dgrad_rows_kernel stages the FOUR gradient rows of a tile (70 KB) for 6 KB of output and
+// its tiles are interleaved across XCDs, so every gradient row travels L2 -> LDS four times: the kernel's loads alone take 108 us, its
+// MFMAs + stores alone 106 us, the whole 185 us (cold, PPV phase experiment).  Here a workgroup owns a STRIP of consecutive output rows
+// of one image segment and keeps a ring of SIX row slots (17 KB each): a tile stages only the one row that is new (y + 3, under this
+// tile's multiply), reads rows y - 1 .. y + 2 from their slots, and does not wait for its own stores (the wait at the head of the next
+// tile is counted: the DMA is older than the stores).
+__global__ __launch_bounds__(512, 1) void stem_dgrad_strip_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ wsd,
+                                                                 float* __restrict__ gimg, const bf16_t* __restrict__ zero_page,
+                                                                 int B, int Ho, int Wo, int strip, int strips_per_col) {
+    constexpr int NP = 136, ROWB = NP * 128, NSLOT = 6, NGRP = NP / 8;    // 17 one-KiB wave-instructions per gradient row
+    extern __shared__ __attribute__((aligned(16))) char stem_smem[];
+    float* sOut = reinterpret_cast<float*>(stem_smem + NSLOT * ROWB);     // [6][256] f32
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tpr = Wo / 128, H = 2 * Ho, W = 2 * Wo;
+    bf16x8 wreg[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(wsd + fr * 1024 + ks * 32 + fq * 8);
+    // workgroup -> (image, column segment, strip of rows)
+    const int sidx = blockIdx.x % strips_per_col, col = blockIdx.x / strips_per_col;
+    const int xseg = col % tpr, b = col / tpr;
+    const int y0 = sidx * strip, y1 = min(Ho, y0 + strip);
+    if (b >= B || y0 >= y1) return;
+    const int lp = lane >> 3, lc = lane & 7;
+    auto stage_row = [&](int yy) {                              // gradient row yy -> slot yy mod 6 (rows outside the image: zeros)
+        const int slot = ((yy % NSLOT) + NSLOT) % NSLOT;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int grp = k * 8 + wave;
+            if (grp >= NGRP) break;                             // wave-uniform
+            const int pix = grp * 8 + lp;
+            const int xx = xseg * 128 - 1 + pix;
+            const bf16_t* src = zero_page;
+            if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) src = gx + (((long)b * Ho + yy) * Wo + xx) * 64 + (lc ^ (pix & 7)) * 8;
+            GLDS16W(src, stem_smem + slot * ROWB + grp * 1024);
+        }
+    };
+    for (int yy = y0 - 1; yy <= y0 + 2; ++yy) stage_row(yy);
+    for (int y = y0; y < y1; ++y) {
+        // rows y - 1 .. y + 2 have landed (the last of them was requested before the previous tile's stores: those may still be in flight)
+        if (y == y0 || tid >= 384) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __syncthreads();                                        // ... for every wave; the slot of row y - 2 and sOut are free
+        if (y + 1 < y1) stage_row(y + 3);
+        const char* rowp[4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) rowp[dy] = stem_smem + ((((y - 1 + dy) % NSLOT) + NSLOT) % NSLOT) * ROWB;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            bf16x8 af[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ks = kb * 8 + q;
+                const int tap = ks >> 1, dy = tap >> 2, dx = tap & 3, c8 = (ks & 1) * 4 + fq;
+                const int pix = wave * 16 + fr + dx;
+                af[q] = *reinterpret_cast<const bf16x8*>(rowp[dy] + (pix * 8 + (c8 ^ (pix & 7))) * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q], wreg[kb * 8 + q], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+        if (fr < 12) {
+            const int c = fr % 3, pw = (fr / 3) & 1, ph = fr / 6;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sOut[(c * 2 + ph) * 256 + 2 * (wave * 16 + fq * 4 + j) + pw] = acc[j];
+        }
+        __syncthreads();
+        if (tid < 6 * 64) {
+            const int seg = tid >> 6, q = tid & 63;
+            const int c = seg >> 1, ph = seg & 1;
+            *reinterpret_cast<float4*>(gimg + (((long)b * 3 + c) * H + 2 * y + ph) * W + xseg * 256 + q * 4) =
+                *reinterpret_cast<const float4*>(sOut + seg * 256 + q * 4);
+        }
+    }
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -1946,7 +2024,24 @@ int ppv_stem_dgrad(const void* g_raw, const void* wsd, float* g_img, const void*
     if (Wo % 128) return PPV_ERR_BAD_SIZE;
     constexpr int lds = 2 * 4 * 136 * 128 + 6 * 256 * 4;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)stem_dgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)stem_dgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)stem_dgrad_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 136 * 128 + 6 * 256 * 4);
+        attr = true;
+    }
+    static const int strip_form = getenv("PPV_STEM_DGRAD_STRIP") ? atoi(getenv("PPV_STEM_DGRAD_STRIP")) : 1;
+    if (strip_form && Ho >= 8) {
+        // strips of consecutive rows: ~256 workgroups, at least 8 rows each (the four-row prologue is staged once per strip)
+        const int cols = B * (Wo / 128);
+        int per_col = (256 + cols - 1) / cols;
+        if (per_col > Ho / 8) per_col = Ho / 8;
+        if (per_col < 1) per_col = 1;
+        const int strip = (Ho + per_col - 1) / per_col;
+        per_col = (Ho + strip - 1) / strip;
+        stem_dgrad_strip_kernel<<<cols * per_col, 512, 6 * 136 * 128 + 6 * 256 * 4, stream>>>((const bf16_t*)g_raw, (const bf16_t*)wsd, g_img,
+                                                                                           (const bf16_t*)zero_page, B, Ho, Wo, strip, per_col);
+        return ppv_last_error();
+    }
     const int tiles = B * Ho * (Wo / 128);
     stem_dgrad_rows_kernel<<<tiles < 256 ? (tiles + 7) / 8 * 8 : 256, 512, lds, stream>>>((const bf16_t*)g_raw, (const bf16_t*)wsd, g_img,
                                                                                   (const bf16_t*)zero_page, B, Ho, Wo, tiles);

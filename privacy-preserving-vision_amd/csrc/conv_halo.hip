@@ -19,6 +19,7 @@
 // Bank conflicts: a halo row is 128 B = 8 chunks of 16 B, stored at chunk ^ (halo column & 7): the 16 lanes of an A-fragment read
 // hold 16 consecutive columns of one image row at one logical chunk -> 8 distinct physical chunks twice = conflict-free b128 reads
 // for every tap shift (8-pixel-wide images: two rows per fragment, 2-way).  Weight rows as in conv_gemm_pipe_kernel (chunk ^ row & 7).
+#include <utility>
 #include "conv_common.h"
 #include "conv_tile_epilogue.h"
 
@@ -231,6 +232,159 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
 #else
     tile_epilogue<HL_BM, HL_BN, HL_LDS, 1, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{});
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Layer 1: 64 -> 64 channels on 64-column maps (three convolutions forward, three data gradients per step).  On the 128 x 64 tiled
+// kernel these ran at 84 / 110 us against 30 / 45 us of compulsory bytes (tools/bench_layer1.py): K = 9 x 64 means every 128-pixel tile
+// staged its pixels nine times AND the whole 72-KB filter -- 600 MB through the L2 -> LDS path for a 67-MB input.  Here a workgroup's
+// 256 output pixels are four rows of one image; the 6 x 66-pixel halo tile (396 x 128 B) is staged once, one 8-KB tap slice of the
+// filter per step runs through a three-slot ring (slices t + 1, t + 2 in flight while step t computes), and two workgroups share a CU
+// (74 KB each) so one's prologue / store loop runs under the other's nine steps.  Eight waves x (32 pixels x 64 channels).
+constexpr int H6_PITCH = 66, H6_HPX = 6 * H6_PITCH, H6_HPI = (H6_HPX + 7) / 8, H6_HALO = H6_HPI * 1024, H6_WSLOT = 64 * 128, H6_NWS = 3;
+constexpr int H6_LDS = H6_HALO + H6_NWS * H6_WSLOT;              // 75 776 B
+
+template <class F, int... Is>
+__device__ __forceinline__ void h6_static_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int OFF> __device__ __forceinline__ void h6_read128(bf16x8& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
+template <bool RED>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo64_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+                                                                void* __restrict__ Out, float* __restrict__ stat_part,
+                                                                const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
+                                                                const bf16_t* __restrict__ zero_page, ConvGeom g, int stat_rows,
+                                                                const bf16_t* __restrict__ red_x, const float* __restrict__ red_coef) {
+    constexpr int MI = 2, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid;
+    const long m0 = (long)tile_m * 256;
+    const int HW = g.Ho * 64;
+    const int b0 = (int)(m0 / HW), y0 = (int)(m0 % HW) >> 6;
+    const int rl = lane >> 3, p8 = lane & 7;
+    const long zdelta = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
+    // ---- halo tile: 1-KiB instruction i = halo pixels 8 i .. 8 i + 7, wave w issues i = 8 t + w
+#pragma unroll
+    for (int t = 0; t < (H6_HPI + 7) / 8; ++t) {
+        const int inst = t * 8 + wave;
+        const int hp = inst * 8 + rl;
+        const int hy = hp / H6_PITCH, hx = hp % H6_PITCH;
+        const int y = y0 + hy - 1, x = hx - 1;
+        const bool ok = (hp < H6_HPX) & ((unsigned)y < (unsigned)g.Ho) & ((unsigned)x < 64u);
+        const long off = (ok ? ((long)b0 * HW + (long)y * 64 + x) * 128 : zdelta) + ((p8 ^ (hx & 7)) * 16);
+        if (inst < H6_HPI) GLDS16(reinterpret_cast<const char*>(X) + off, smem + inst * 1024);
+    }
+    // ---- filter slices: rows 0 .. 63 of Wt [64][9][64], one tap per step; wave w carries rows 8 w .. 8 w + 7
+    const bf16_t* wbase;
+    {
+        const int row = wave * 8 + rl;
+        wbase = Wt + (long)row * (9 * 64) + (p8 ^ (row & 7)) * 8;
+    }
+    auto issue_w = [&](int slot, int tap) __attribute__((always_inline)) {
+        GLDS16(wbase + tap * 64, smem + H6_HALO + slot * H6_WSLOT + wave * 1024);
+    };
+    issue_w(0, 0);
+    issue_w(1, 1);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    auto lds_addr = [](const char* p) __attribute__((always_inline)) {
+        return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+    };
+    unsigned abase[MI][3][2], bbase[2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = wave * 32 + mi * 16 + fr;
+        const unsigned hb = lds_addr(smem) + ((p >> 6) * H6_PITCH + (p & 63)) * 128;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) abase[mi][s][kk] = hb + (((kk * 4 + fq) ^ ((fr + s) & 7)) * 16);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) bbase[kk] = lds_addr(smem + H6_HALO) + fr * 128 + (((kk * 4 + fq) ^ (fr & 7)) * 16);
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    h6_static_for([&](auto T_) {
+        constexpr int T = decltype(T_)::value, r = T / 3, s = T % 3, slot = T % 3;
+        // slice T (and, at T = 0, the halo tile: older) has landed for this wave; slice T + 1 may still be in flight
+        if constexpr (T < 8) wait_vmcnt_le<1>(); else wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is past step T - 1 (slot (T + 2) % 3)
+        if constexpr (T + 2 < 9) issue_w((T + 2) % 3, T + 2);
+        if (g.chunked == 2) return;                            // PPV_CONV_DEBUG=1: staging and barriers only (timing experiments)
+        bf16x8 af[2][MI], bfr[2][NI];
+        constexpr int ashift = (r * H6_PITCH + s) * 128, bshift = slot * H6_WSLOT;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h6_read128<ashift>(af[kk][0], abase[0][s][kk]);
+            h6_read128<ashift>(af[kk][1], abase[1][s][kk]);
+            h6_read128<bshift>(bfr[kk][0], bbase[kk]);
+            h6_read128<bshift + 2048>(bfr[kk][1], bbase[kk]);
+            h6_read128<bshift + 4096>(bfr[kk][2], bbase[kk]);
+            h6_read128<bshift + 6144>(bfr[kk][3], bbase[kk]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mi], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mi], bfr[1][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, 9>{});
+    if (g.chunked == 3) {                                      // PPV_CONV_DEBUG=2: no epilogue
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(Out)[tid] = acc[1][3][2];
+        return;
+    }
+    __syncthreads();
+#ifdef PPV_STAMPS
+    unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tile_epilogue<256, 64, H6_LDS, 2, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, 0, CoopBn{}, stamp_);
+#else
+    tile_epilogue<256, 64, H6_LDS, 2, false, RED, MI, NI>(acc, smem, Out, stat_part, addend, mask_bits, g, tile_m, stat_rows, red_x, red_coef, m0, 0, CoopBn{});
+#endif
+}
+
+bool conv3x3_halo64_supported(const ConvGeom& g, int Cs, int div) {
+    return g.R == 3 && g.S == 3 && g.a == 1 && g.off == -1 && g.offw == -1 && div == 1 && g.Hs == g.Ho && g.Ws == g.Wo && g.Wo == 64 &&
+           g.Ho % 4 == 0 && Cs == 64 && g.N == 64 && g.M % 256 == 0;
+}
+
+int conv3x3_halo64_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
+                          const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
+                          const ConvGeom& g, int stat_rows, hipStream_t stream) {
+    if (!conv3x3_halo64_supported(g, g.Cs, 1)) return PPV_ERR_BAD_SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, H6_LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, H6_LDS);
+        attr_set = true;
+    }
+    const int grid = (int)(g.M / 256);
+    if (red_x)
+        conv3x3_halo64_kernel<true><<<grid, 512, H6_LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, stat_rows, red_x, red_coef);
+    else
+        conv3x3_halo64_kernel<false><<<grid, 512, H6_LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, stat_rows, nullptr, nullptr);
+    return ppv_last_error();
 }
 
 static bool halo_geom(const ConvGeom& g, int Cs, int div, HaloGeom* hg) {

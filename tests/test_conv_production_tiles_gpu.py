@@ -149,7 +149,7 @@ AUTO_FWD = [
     (128, 16, 256, 256, 3, 1),    # the layer-3 conv2 shape itself at B = 128 -> conv_halo.hip (one image per tile)
     (64, 32, 128, 512, 1, 1),     # M = 65 536, N = 512: t256 = 1024 -> <256,128,3,32,2>
     (32, 64, 256, 64, 1, 1),      # M = 131 072, N = 64              -> <128,64,3,32,4>
-    (33, 64, 64, 64, 3, 1),       # ragged M, 64 columns, 3x3        -> <128,64,3,32,4>
+    (33, 64, 64, 64, 3, 1),       # 64 columns, 3x3, 528 row tiles   -> conv_halo.hip's 64-channel form; variant 7: <128,64,3,32,4>
     (16, 32, 256, 512, 1, 2),     # projection shortcut, stride 2: M = 4096, t256 = 64 -> <128,128,4,64,1>
     (64, 16, 1024, 256, 1, 1),    # M = 16 384, N = 256: t256 = 128  -> <128,128,4,64,1>
     (128, 16, 256, 1024, 1, 1),   # the layer-3 conv3 shape itself at B = 128 -> conv_stream.hip (K = 256)
@@ -165,6 +165,7 @@ AUTO_DGRAD = [  # (B, H, Cin, Cout, k, stride): GEMM columns = Cin
     (32, 32, 256, 256, 3, 1),     # N = 256, M = 32 768 -> conv_halo.hip; variant 7: <256,128,3,64,1>
     (64, 32, 512, 128, 1, 1),     # N = 512, M = 65 536 -> <256,128,3,32,2> (conv1 data gradient: addend + mask + sums)
     (32, 64, 64, 256, 1, 1),      # N = 64, M = 131 072 -> <128,64,3,32,4>
+    (33, 64, 64, 64, 3, 1),       # layer-1 3x3 data gradient -> conv_halo.hip's 64-channel form; variant 7: <128,64,3,32,4>
     (16, 32, 256, 512, 1, 2),     # stride-2 projection data gradient (zero-page taps), N = 256
     (128, 16, 1024, 256, 1, 1),   # the layer-3 conv1 data gradient at B = 128 -> conv_stream.hip with addend + mask + sums
     (32, 64, 256, 64, 1, 1),      # layer-1 conv1 data gradient (K = 64 -> 256 columns) -> conv_stream.hip
@@ -213,6 +214,15 @@ def test_halo_forward(B, H, Cin, Cout, k, stride):
 def test_halo_dgrad(B, H, Cin, Cout, k, stride):
     with _variant(9):
         _check_dgrad(B, H, Cin, Cout, k, stride)
+
+
+# the 64 -> 64-channel, 64-column form (layer 1: four image rows per tile), forced on few tiles: the top / bottom tiles of an image take
+# their border rows from the zero page, the 50th halo instruction is half outside the tile
+@pytest.mark.parametrize("B", [1, 3])
+def test_halo64_forward_and_dgrad(B):
+    with _variant(9):
+        _check_forward(B, 64, 64, 64, 3, 1)
+        _check_dgrad(B, 64, 64, 64, 3, 1)
 
 
 WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> the benchmark's split counts

@@ -287,6 +287,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo64_kernel(const bf16_t* __
         const int row = wave * 8 + rl;
         wbase = Wt + (long)row * (9 * 64) + (p8 ^ (row & 7)) * 8;
     }
+    const int dbg = g.chunked > 1 ? g.chunked - 1 : 0;        // PPV_CONV_DEBUG bits (timing experiments, wrong results): 1 = no fragment reads /
+                                                              // MFMAs, 2 = no epilogue, 4 = only the first two filter slices are staged
     auto issue_w = [&](int slot, int tap) __attribute__((always_inline)) {
         GLDS16(wbase + tap * 64, smem + H6_HALO + slot * H6_WSLOT + wave * 1024);
     };
@@ -321,8 +323,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo64_kernel(const bf16_t* __
         // slice T (and, at T = 0, the halo tile: older) has landed for this wave; slice T + 1 may still be in flight
         if constexpr (T < 8) wait_vmcnt_le<1>(); else wait_vmcnt_le<0>();
         __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is past step T - 1 (slot (T + 2) % 3)
-        if constexpr (T + 2 < 9) issue_w((T + 2) % 3, T + 2);
-        if (g.chunked == 2) return;                            // PPV_CONV_DEBUG=1: staging and barriers only (timing experiments)
+        if constexpr (T + 2 < 9) {
+            if (!(dbg & 4)) issue_w((T + 2) % 3, T + 2);
+        }
+        if (dbg & 1) return;
         bf16x8 af[2][MI], bfr[2][NI];
         constexpr int ashift = (r * H6_PITCH + s) * 128, bshift = slot * H6_WSLOT;
 #pragma unroll
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo64_kernel(const bf16_t* __
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][mi], bfr[1][ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }, std::make_integer_sequence<int, 9>{});
-    if (g.chunked == 3) {                                      // PPV_CONV_DEBUG=2: no epilogue
+    if (dbg & 2) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(Out)[tid] = acc[1][3][2];
         return;
     }

@@ -526,6 +526,11 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         return conv3x3_halo_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
                                    (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
                                    stat_rows, stream);
+    static const int halo_n64 = getenv("PPV_HALO_N64") ? atoi(getenv("PPV_HALO_N64")) : 1;         // A/B: 0 = 128 x 128 tiled kernel for layer 4's stride-1 3x3
+    if ((g_conv_variant == 9 || (g_conv_variant == 0 && halo_n64 && (g.M / 256) * (N / 64) >= 200)) && !out_f32 && conv3x3_halo_n64_supported(g, Cs, div))
+        return conv3x3_halo_n64_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
+                                       (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
+                                       stat_rows, stream);
     static const int halo64 = getenv("PPV_HALO64") ? atoi(getenv("PPV_HALO64")) : 1;               // A/B: 0 = 128 x 64 tiled kernel for layer 1's 3x3
     if ((g_conv_variant == 9 || (g_conv_variant == 0 && halo64 && g.M / 256 >= 512)) && !out_f32 && conv3x3_halo64_supported(g, Cs, div))
         return conv3x3_halo64_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,

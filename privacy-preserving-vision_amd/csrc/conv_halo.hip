@@ -34,9 +34,17 @@ struct HaloGeom {
     int tiles_n;
 };
 
-constexpr int HL_BM = 256, HL_BN = 128, HL_BK = 64, HL_NT = 512;
-constexpr int HL_HALO_PX = 344, HL_HALO_BYTES = HL_HALO_PX * 128, HL_WSTAGE = HL_BN * HL_BK * 2, HL_NWS = 4;
-constexpr int HL_LDS = 2 * HL_HALO_BYTES + HL_NWS * HL_WSTAGE;               // 153 600 B: one workgroup per CU
+// BN = 128: the form above (layers 2-3).  BN = 64 (round 5, layer 4: 512 -> 512 on 8 x 8 maps, M = 8192 rows): the 128 x 128 tiled kernel
+// staged 2.3 MB per workgroup (79 us at the ~45 GB/s a CU pulls through L2 -> LDS, MFMA 15 us); with 256 workgroups the staged bytes per
+// workgroup are least for 256 pixels x 64 columns (four images, 400 halo pixels per chunk: 0.41 MB of pixels + 0.59 MB of filter), eight
+// waves x (32 pixels x 64 columns).
+constexpr int HL_BM = 256, HL_BK = 64, HL_NT = 512, HL_NWS = 4;
+template <int BN> struct HaloCfg {
+    static constexpr int HALO_PX = BN == 128 ? 344 : 400, HALO_BYTES = HALO_PX * 128, WSTAGE = BN * HL_BK * 2;
+    static constexpr int LDS = 2 * HALO_BYTES + HL_NWS * WSTAGE;             // 153 600 B / 135 168 B: one workgroup per CU
+    static constexpr int WN = BN / 64, MI = BN == 128 ? 4 : 2, NI = 4, WI = WSTAGE / 8192;   // WI: 1-KiB filter instructions per wave and slice
+    static constexpr int MAXS = (HALO_PX + 63) / 64;
+};
 
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform
     if (n >= 3) wait_vmcnt_le<3>();
@@ -45,14 +53,17 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-unifo
     else wait_vmcnt_le<0>();
 }
 
-template <bool RED>
+template <bool RED, int HL_BN>
 __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                 void* __restrict__ Out, float* __restrict__ stat_part,
                                                                 const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                 const bf16_t* __restrict__ zero_page, ConvGeom g, HaloGeom hg,
                                                                 int stat_rows, const bf16_t* __restrict__ red_x,
                                                                 const float* __restrict__ red_coef) {
-    constexpr int MI = 4, NI = 4, WN = 2, WROWS = 64, WCOLS = 64;
+    using Cfg = HaloCfg<HL_BN>;
+    constexpr int MI = Cfg::MI, NI = Cfg::NI, WN = Cfg::WN, WROWS = MI * 16, WCOLS = 64, WI = Cfg::WI;
+    constexpr int HL_HALO_BYTES = Cfg::HALO_BYTES, HL_WSTAGE = Cfg::WSTAGE, HL_LDS = Cfg::LDS;
+    static_assert(NI == 4, "four B fragments per k-half");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const s_halo = smem;
     char* const s_w = smem + 2 * HL_HALO_BYTES;
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     const long zdelta = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
 
     // ---- halo slices of this wave: slice t = 1-KiB instruction t * 8 + wave = halo pixels (t * 8 + wave) * 8 .. + 7
-    constexpr int MAXS = 6;                                 // ceil(344 / 64)
+    constexpr int MAXS = Cfg::MAXS;                         // ceil(halo pixels / 64): 6 / 7
     long h_off[MAXS];
     int h_inc[MAXS];
     const int img_px = (hg.TH + 2) * hg.pitch;
@@ -92,9 +103,9 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     };
     // ---- weight slices: rows n0 .. n0 + 127 of Wt [N][9][Cs], 64 channels of one tap per step
     const long wrow = 9L * g.Cs;
-    const bf16_t* wbase[2];
+    const bf16_t* wbase[WI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WI; ++i) {
         const int row = (i * 8 + wave) * 8 + rl;
         wbase[i] = Wt + (long)(n0 + row) * wrow + (p8 ^ (row & 7)) * 8;
     }
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
         char* sb = s_w + slot * HL_WSTAGE;
         const int koff = tap * g.Cs + c0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) GLDS16(wbase[i] + koff, sb + (i * 8 + wave) * 1024);
+        for (int i = 0; i < WI; ++i) GLDS16(wbase[i] + koff, sb + (i * 8 + wave) * 1024);
     };
 
     // ---- A-fragment addressing
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     issue_w(0, 0, 0);
     issue_w(1, 1, 0);
     issue_w(2, 2, 0);
-    wait_vmcnt_le<4>();                                       // halo 0 and slice 0 are older than slices 1, 2
+    wait_vmcnt_le<2 * WI>();                                  // halo 0 and slice 0 are older than slices 1, 2
     __builtin_amdgcn_s_barrier();
 
     // Register pipeline: a step's first-half fragments (kk = 0) are read during the PREVIOUS step's second-half MFMAs, its
@@ -164,8 +175,8 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bfr[2]) : "v"(b));
         asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(bfr[3]) : "v"(b));
     };
-    auto lgkm_wait8 = []() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    auto lgkm_wait8 = []() __attribute__((always_inline)) {                       // all but the MI + NI reads issued last
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(Cfg::MI + Cfg::NI) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
     load_frags(af0, bf0, s_halo, s_w, 0, 0, 0);
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
         for (int tap = 0; tap < 9; ++tap) {
             const int r = tap / 3, s = tap % 3;
             // slice step + 1 (and, at a chunk's last tap, the next halo tile: older than that slice) has landed for this wave ...
-            wait_vmcnt_dyn((step + 2 < T ? 2 : 0) + (had_prev ? 1 : 0));
+            wait_vmcnt_dyn((step + 2 < T ? WI : 0) + (had_prev ? 1 : 0));
             __builtin_amdgcn_s_barrier();                    // ... and for every wave; every wave is past step - 1
             had_prev = false;
             if (tap < MAXS) {
@@ -223,7 +234,9 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the last step's look-ahead reads: their registers are free only now
 #pragma unroll
-    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af0[i]), "v"(bf0[i]));
+    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af0[i]));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(bf0[i]));
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #ifdef PPV_STAMPS
@@ -391,10 +404,10 @@ int conv3x3_halo64_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* s
     return ppv_last_error();
 }
 
-static bool halo_geom(const ConvGeom& g, int Cs, int div, HaloGeom* hg) {
+static bool halo_geom(const ConvGeom& g, int Cs, int div, HaloGeom* hg, int HL_BN = 128) {
     if (g.R != 3 || g.S != 3 || g.a != 1 || g.off != -1 || g.offw != -1 || div != 1 || g.Hs != g.Ho || g.Ws != g.Wo) return false;
     const int W = g.Wo, H = g.Ho;
-    if (W != 16 && W != 32) return false;           // 8 and 64 columns need 400 halo pixels (and are layer 4 / layer 1: too few tiles / 64 channels)
+    if (HL_BN == 128 ? (W != 16 && W != 32) : W != 8) return false;   // 128 columns: 16- / 32-wide maps; 64 columns: 8-wide maps (400 halo pixels); layer 1: above
     if (Cs % HL_BK || g.N % HL_BN || g.M % HL_BM) return false;
     const int rows = HL_BM / W;                      // image rows per tile
     const int TH = rows < H ? rows : H;
@@ -406,7 +419,7 @@ static bool halo_geom(const ConvGeom& g, int Cs, int div, HaloGeom* hg) {
     hg->hpi = (hg->hpx + 7) / 8;
     hg->hpw = (hg->hpi + 7) / 8;
     hg->tiles_n = g.N / HL_BN;
-    return hg->hpx <= HL_HALO_PX && hg->hpw <= 6;
+    return hg->hpx <= (HL_BN == 128 ? HaloCfg<128>::HALO_PX : HaloCfg<64>::HALO_PX) && hg->hpw <= (HL_BN == 128 ? HaloCfg<128>::MAXS : HaloCfg<64>::MAXS);
 }
 
 bool conv3x3_halo_supported(const ConvGeom& g, int Cs, int div) {
@@ -414,23 +427,42 @@ bool conv3x3_halo_supported(const ConvGeom& g, int Cs, int div) {
     return halo_geom(g, Cs, div, &hg);
 }
 
-int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
-                        const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
-                        const ConvGeom& g, int stat_rows, hipStream_t stream) {
+bool conv3x3_halo_n64_supported(const ConvGeom& g, int Cs, int div) {
     HaloGeom hg;
-    if (!halo_geom(g, g.Cs, 1, &hg)) return PPV_ERR_BAD_SIZE;
+    return halo_geom(g, Cs, div, &hg, 64);
+}
+
+template <int BN>
+static int halo_launch_t(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
+                         const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
+                         const ConvGeom& g, int stat_rows, hipStream_t stream) {
+    HaloGeom hg;
+    if (!halo_geom(g, g.Cs, 1, &hg, BN)) return PPV_ERR_BAD_SIZE;
+    constexpr int LDS = HaloCfg<BN>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     const int grid = (int)(g.M / HL_BM) * hg.tiles_n;
     if (red_x)
-        conv3x3_halo_kernel<true><<<grid, HL_NT, HL_LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, red_x, red_coef);
+        conv3x3_halo_kernel<true, BN><<<grid, HL_NT, LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, red_x, red_coef);
     else
-        conv3x3_halo_kernel<false><<<grid, HL_NT, HL_LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, nullptr, nullptr);
+        conv3x3_halo_kernel<false, BN><<<grid, HL_NT, LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, nullptr, nullptr);
     return ppv_last_error();
+}
+
+int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
+                        const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
+                        const ConvGeom& g, int stat_rows, hipStream_t stream) {
+    return halo_launch_t<128>(X, Wt, out, stat_part, addend, mask_bits, zero_page, red_x, red_coef, g, stat_rows, stream);
+}
+
+int conv3x3_halo_n64_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
+                            const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
+                            const ConvGeom& g, int stat_rows, hipStream_t stream) {
+    return halo_launch_t<64>(X, Wt, out, stat_part, addend, mask_bits, zero_page, red_x, red_coef, g, stat_rows, stream);
 }
 
 }  // namespace ppv

@@ -216,6 +216,16 @@ def test_halo_dgrad(B, H, Cin, Cout, k, stride):
         _check_dgrad(B, H, Cin, Cout, k, stride)
 
 
+# the 64-column tile on 8-wide maps (layer 4: four images per tile, 400 halo pixels, seven halo slices per chunk), forced on few tiles;
+# the benchmark's own launch (128 images, 512 -> 512) is in AUTO_FWD / AUTO_DGRAD above
+@pytest.mark.parametrize("B,C,N", [(4, 64, 64), (8, 128, 64), (12, 192, 128), (4, 512, 192)])
+def test_halo_n64_forward_and_dgrad(B, C, N):
+    with _variant(9):
+        _check_forward(B, 8, C, N, 3, 1)
+        if C % 64 == 0 and N % 64 == 0:
+            _check_dgrad(B, 8, N, C, 3, 1)
+
+
 # the 64 -> 64-channel, 64-column form (layer 1: four image rows per tile), forced on few tiles: the top / bottom tiles of an image take
 # their border rows from the zero page, the 50th halo instruction is half outside the tile
 @pytest.mark.parametrize("B", [1, 3])

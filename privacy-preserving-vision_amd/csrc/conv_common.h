@@ -154,6 +154,10 @@ bool conv3x3_halo_supported(const ConvGeom& g, int Cs, int div);
 int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
                         const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
                         const ConvGeom& g, int stat_rows, hipStream_t stream);
+// conv_dgrad_s2.hip: data gradient of the stride-2 3x3 / 1x1 convolutions as four parity-class problems (bf16, no addend, no bit mask).
+bool conv_dgrad_s2_supported(const ConvGeom& g, int Cs, int div);
+int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* zero_page, const bf16_t* red_x,
+                         const float* red_coef, const ConvGeom& g, int stat_rows, hipStream_t stream);
 // ... its 64-column tile on 8-wide maps (layer 4: four images per tile) ...
 bool conv3x3_halo_n64_supported(const ConvGeom& g, int Cs, int div);
 int conv3x3_halo_n64_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,

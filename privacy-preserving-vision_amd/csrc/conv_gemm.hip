@@ -474,7 +474,8 @@ namespace ppv { __device__ unsigned long long* g_stamps = nullptr; }
 extern "C" {
 
 // tuning / A-B hook: 0 auto, 1 two-stage, 2 = 128x128x4-stage, 3 = 256x128x3-stage, 4 = 256x128 BK32 two per CU, 7 = tiled kernels only
-// (no conv_stream.hip / conv_halo.hip), 8 = conv_stream.hip wherever it can run, 9 = conv_halo.hip wherever it can run
+// (no conv_stream.hip / conv_halo.hip), 8 = conv_stream.hip wherever it can run, 9 = conv_halo.hip wherever it can run,
+// 10 = conv_dgrad_s2.hip wherever it can run
 int ppv_conv_set_variant(int v) { g_conv_variant = v; return PPV_OK; }
 
 #ifdef PPV_STAMPS
@@ -511,6 +512,12 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         if (!g.flat || g.M * 128 >= (1L << 31)) return PPV_ERR_BAD_SIZE;
         g.chunked = 1;
     }
+    // stride-2 data gradients as four parity-class problems (variant 10: wherever it can run; automatic: launches that fill the chip)
+    static const int dgrad_s2 = getenv("PPV_DGRAD_S2") ? atoi(getenv("PPV_DGRAD_S2")) : 1;         // A/B: 0 = the general kernels (zero-page taps)
+    if ((g_conv_variant == 10 || (g_conv_variant == 0 && dgrad_s2 && ((long)B * Hs * Ws / 256) * (N / 128) >= 64)) && !out_f32 && !addend &&
+        !mask_bits && !(red_x_ && N % 128) && !(stat_part && !red_x_) && conv_dgrad_s2_supported(g, Cs, div))
+        return conv_dgrad_s2_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
+                                    stat_rows, stream);
     // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
     // (its f32 instantiation has no epilogue options: variant 8 leaves f32 launches with an addend / sums to the tiled kernels)
     static const int stream_auto = getenv("PPV_STREAM_DGRAD") ? atoi(getenv("PPV_STREAM_DGRAD")) : 1;   // A/B: 0 = tiled kernels for the addend launches too

@@ -9,7 +9,13 @@ namespace ppv {
 // ----------------------------------------------------------------------------- shared epilogue of the 256/128-row tiled kernels
 // acc: the wave's MI x NI accumulator tiles of a BM x BN output tile whose rows are GEMM rows m0 .. m0 + BM - 1 and columns n0 ..;
 // smem: the workgroup's whole dynamic LDS (LDS_TOTAL bytes, free: every wave is past its last read of the K loop's stages).
-template <int BM, int BN, int LDS_TOTAL, int WGPCU, bool OUT_F32, bool RED, int MI, int NI, bool COOP = false>
+// RM: tile row m -> row of the tensors in memory (output, mask, BatchNorm input).  Identity for every convolution but the stride-2 data
+// gradients of conv_dgrad_s2.hip, whose tiles hold the pixels of ONE parity class of the gradient map (single-pass bf16 paths only).
+struct RowIdentity {
+    static constexpr bool identity = true;
+    __device__ __forceinline__ long operator()(long m) const { return m; }
+};
+template <int BM, int BN, int LDS_TOTAL, int WGPCU, bool OUT_F32, bool RED, int MI, int NI, bool COOP = false, class RM = RowIdentity>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, void* __restrict__ Out, float* __restrict__ stat_part,
                                               const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                               const ConvGeom& g, int tile_m, int stat_rows, const bf16_t* __restrict__ red_x,
@@ -17,7 +23,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
 #ifdef PPV_STAMPS
                                               , unsigned long long* stamp_
 #endif
-                                              ) {
+                                              , const RM rm = RM{}) {
+    static_assert(RM::identity || (!OUT_F32 && !COOP), "row maps: bf16 store paths");
     constexpr int NT = BM * 2, NWAVE = NT / 64;
     constexpr int WN = BN / 64 > 0 ? BN / 64 : 1, WM = NWAVE / WN;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
@@ -263,6 +270,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
         const int row0 = tid / CPR, ch = tid % CPR;
         const long e0 = (m0 + row0) * g.N + n0 + ch * 8;
         const long estep = (long)RSTEP * g.N;
+        auto eoff = [&](int k) __attribute__((always_inline)) -> long {
+            if constexpr (RM::identity) return e0 + k * estep;
+            else return rm(m0 + row0 + (long)k * RSTEP) * g.N + n0 + ch * 8;
+        };
         constexpr int GRP = RED ? (WGPCU > 1 ? 2 : 4) : SITERS;            // RED: rounds of a few chunks (register budget)
 #pragma unroll
         for (int i0 = 0; i0 < SITERS; i0 += GRP) {
@@ -270,11 +281,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
             uint4 xv[RED ? GRP : 1];
             if (mask_bits) {
 #pragma unroll
-                for (int it = 0; it < GRP; ++it) mbv[it] = mask_bits[(e0 + (i0 + it) * estep) >> 3];
+                for (int it = 0; it < GRP; ++it) mbv[it] = mask_bits[eoff(i0 + it) >> 3];
             }
             if constexpr (RED) {
 #pragma unroll
-                for (int it = 0; it < GRP; ++it) xv[it] = *reinterpret_cast<const uint4*>(red_x + e0 + (i0 + it) * estep);
+                for (int it = 0; it < GRP; ++it) xv[it] = *reinterpret_cast<const uint4*>(red_x + eoff(i0 + it));
             }
             uint4 v[GRP];
 #pragma unroll
@@ -289,7 +300,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
                     if (red_coef) v[it] = red_mask8(v[it], xv[it], rsc, rsh);
                     red_acc8(v[it], xv[it], ra, rb);
                 }
-                *reinterpret_cast<uint4*>(out + e0 + (i0 + it) * estep) = v[it];
+                *reinterpret_cast<uint4*>(out + eoff(i0 + it)) = v[it];
             }
         }
     } else {
@@ -297,8 +308,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
         for (int it = 0; it < SITERS; ++it) {
             const int idx = it * NT + tid;
             const int row = idx / CPR, ch = idx % CPR;
-            const long m = m0 + row;
-            if (m < g.M) {
+            if (m0 + row < g.M) {
+                const long m = rm(m0 + row);
                 uint4 v = *reinterpret_cast<const uint4*>(sO + row * LDO + ch * 16);
                 if (mask_bits) v = relu_mask8(v, mask_bits[(m * g.N + n0) / 8 + ch]);
                 if constexpr (RED) {

@@ -216,6 +216,66 @@ def test_halo_dgrad(B, H, Cin, Cout, k, stride):
         _check_dgrad(B, H, Cin, Cout, k, stride)
 
 
+def _check_dgrad_s2(B, H, Cin, Cout, k):
+    """stride-2 data gradient in the forms trunk_plan.hip issues: plain bf16 (projection shortcut) and with the BatchNorm-backward sums
+    + the recomputed BN/ReLU mask (conv2 of a stage's first block); oracle = torch CPU autograd of F.conv2d(stride=2)."""
+    import ppv_amd.convops as co
+    x, w = _mk(B, H, Cin, Cout, k)
+    pad = (k - 1) // 2
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=pad)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).bfloat16().float()
+    y.backward(g)
+    want = x.grad.permute(0, 2, 3, 1).contiguous()
+    gd = g.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    wd = co.weight_layout(w.cuda(), 1)
+    got = co.conv_dgrad(gd, wd, 2, pad, (H, H))
+    assert rel_err(got.float(), want) < BF
+    if k == 1:
+        odd = got.view(B, H // 2, 2, H // 2, 2, Cin)
+        assert not odd[:, :, 1].any() and not odd[:, :, :, :, 1].any()      # the three tap-less parity classes are exact zeros
+    rows = want.numel() // Cin
+    if not co.red_supported(rows, Cin):
+        return
+    gen = torch.Generator().manual_seed(9)
+    xraw = torch.randn(want.shape, generator=gen).bfloat16()
+    part = torch.zeros(64 * Cin, device="cuda")
+    fused = co.conv_dgrad(gd, wd, 2, pad, (H, H), red=(xraw.cuda(), part))
+    assert rel_err(fused.float(), want) < BF
+    sums = part[:co.RED_ROWS * 2 * Cin].view(co.RED_ROWS, 2, Cin).sum(0).cpu()
+    rb = want.bfloat16().float().reshape(-1, Cin)
+    xf = xraw.float().reshape(-1, Cin)
+    tol = 4 * 2 ** -9 / rows ** 0.5 + 1e-4
+    assert ((sums[0] - rb.sum(0)).abs() / rb.abs().sum(0)).max().item() < tol
+    assert ((sums[1] - (rb * xf).sum(0)).abs() / (rb * xf).abs().sum(0)).max().item() < tol
+    coef = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3,
+                        torch.randn(Cin, generator=gen) * 0.1, torch.rand(Cin, generator=gen) + 0.5]).contiguous()
+    keep2 = (xraw.double() * coef[0].double() + coef[1].double()) > 0
+    part = torch.zeros(64 * Cin, device="cuda")
+    fused = co.conv_dgrad(gd, wd, 2, pad, (H, H), red=(xraw.cuda(), part, coef.cuda()))
+    assert rel_err(fused.float(), want * keep2) < BF
+    assert not fused[~keep2.cuda()].any()
+    sums = part[:co.RED_ROWS * 2 * Cin].view(co.RED_ROWS, 2, Cin).sum(0).cpu()
+    rb = (want * keep2).bfloat16().float().reshape(-1, Cin)
+    assert ((sums[0] - rb.sum(0)).abs() / rb.abs().sum(0)).max().item() < tol
+
+
+# conv_dgrad_s2.hip (four parity-class problems) forced (variant 10) on small maps -- ragged row tiles, one to four taps per class, several
+# 64-channel chunks -- and left to the automatic rule at the benchmark's own layer-4 / layer-3 shapes
+S2 = [(2, 8, 128, 64, 3), (3, 16, 128, 128, 3), (1, 32, 256, 64, 3), (5, 8, 128, 192, 1), (2, 16, 256, 128, 1), (3, 4, 128, 64, 3)]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k", S2)
+def test_stride2_dgrad_by_parity_class(B, H, Cin, Cout, k):
+    with _variant(10):
+        _check_dgrad_s2(B, H, Cin, Cout, k)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k", [(128, 16, 512, 512, 3), (128, 16, 1024, 2048, 1), (32, 32, 256, 256, 3)])
+def test_stride2_dgrad_benchmark_sized(B, H, Cin, Cout, k):
+    _check_dgrad_s2(B, H, Cin, Cout, k)
+
+
 # the 64-column tile on 8-wide maps (layer 4: four images per tile, 400 halo pixels, seven halo slices per chunk), forced on few tiles;
 # the benchmark's own launch (128 images, 512 -> 512) is in AUTO_FWD / AUTO_DGRAD above
 @pytest.mark.parametrize("B,C,N", [(4, 64, 64), (8, 128, 64), (12, 192, 128), (4, 512, 192)])

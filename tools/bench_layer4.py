@@ -1,4 +1,4 @@
-"""Layer-4 convolutions (B = 128, 8 x 8 maps; conv1 of block 0 on 16 x 16), cold rotating operands: forward with BatchNorm statistics and
+"""Layer-4 (default; argv[1] = 2 / 3: the other layers' block-0 and body shapes) convolutions (B = 128, 8 x 8 maps; conv1 of block 0 on 16 x 16), cold rotating operands: forward with BatchNorm statistics and
 data gradient with the fused BN-backward sums.  Run on the GPU box: python tools/bench_layer4.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,9 +21,12 @@ def timed(fn, n=12):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for cin, cout, k, h, stride in [(512, 512, 3, 8, 1), (512, 512, 3, 16, 2), (2048, 512, 1, 8, 1), (512, 2048, 1, 8, 1), (1024, 512, 1, 16, 1),
-                                (1024, 2048, 1, 16, 2)]:
-    NB = 24
+SHAPES = {"4": [(512, 512, 3, 8, 1), (512, 512, 3, 16, 2), (2048, 512, 1, 8, 1), (512, 2048, 1, 8, 1), (1024, 512, 1, 16, 1),
+                (1024, 2048, 1, 16, 2)],
+          "3": [(256, 256, 3, 32, 2), (512, 256, 1, 32, 1), (512, 1024, 1, 32, 2), (256, 1024, 1, 16, 1), (1024, 256, 1, 16, 1)],
+          "2": [(128, 128, 3, 64, 2), (256, 128, 1, 64, 1), (256, 512, 1, 64, 2), (128, 512, 1, 32, 1), (512, 128, 1, 32, 1)]}
+for cin, cout, k, h, stride in SHAPES[sys.argv[1] if len(sys.argv) > 1 else "4"]:
+    NB = max(3, min(24, int(800e6 // (B * h * h * cin * 2))))
     ho = h // stride
     M = B * ho * ho
     xs = [torch.randn(B, h, h, cin, device="cuda").bfloat16() for _ in range(NB)]

@@ -10,8 +10,11 @@
 // (py + off + r) and (px + off + s) even (3x3: 1 + 2 + 2 + 4 taps; 1x1: one class has the tap, three are zero), its GEMM rows are the
 // B * H/2 * W/2 pixels of that class, tap (r, s) reads g at (iy + (py + off + r) / 2, jx + (px + off + s) / 2), and the store loop of
 // the shared epilogue scatters row (b, iy, jx) to pixel (2 iy + py, 2 jx + px) (RowMap of conv_tile_epilogue.h).  One launch, class-major
-// grid, the four-tap class first.  K loop: the 256 x 128 / BK = 64 / three-stage LDS-DMA pipeline of conv_gemm_pipe_kernel.
+// grid, the four-tap class first (the four classes of a tile back to back on one XCD measured 1.3-2.1x slower).  K loop: the
+// 256 x 128 / three-stage LDS-DMA pipeline of conv_gemm_pipe_kernel.
 // Served: bf16 output, no addend, no ReLU bit mask (what trunk_plan.hip issues); with or without the BatchNorm-backward sums (RED).
+#include <cstdlib>
+#include <type_traits>
 #include "conv_common.h"
 #include "conv_tile_epilogue.h"
 
@@ -33,17 +36,22 @@ struct S2RowMap {
     }
 };
 
-constexpr int S2_BM = 256, S2_BN = 128, S2_BK = 64, S2_NS = 3;
-constexpr int S2_LDS = S2_NS * (S2_BM + S2_BN) * S2_BK * 2;                 // 147 456 B
+constexpr int S2_BM = 256, S2_BN = 128, S2_NS = 3;
+// BK = 32 (default): 76 KB (the epilogue's staging area), two workgroups per CU -- a class runs 2-64 K-steps, a workgroup is mostly
+// prologue and store loop, and a second one beside it hides them (545 against 598 us over the six launches); BK = 64: 144 KB, one per CU
+template <int BK> constexpr int s2_lds() {
+    constexpr int ring = S2_NS * (S2_BM + S2_BN) * BK * 2, epi = S2_BM * (S2_BN * 2 + 32) + 4096;
+    return ring > epi ? ring : epi;
+}
 
-template <bool RED>
-__global__ __launch_bounds__(512, 1) void conv_dgrad_s2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+template <bool RED, int BK>
+__global__ __launch_bounds__(512, BK == 64 ? 1 : 2) void conv_dgrad_s2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                bf16_t* __restrict__ Out, float* __restrict__ stat_part,
                                                                const bf16_t* __restrict__ zero_page, ConvGeom g, S2Tab tab,
                                                                int tiles_per_class, int tiles_n, int stat_rows,
                                                                const bf16_t* __restrict__ red_x, const float* __restrict__ red_coef) {
-    constexpr int BM = S2_BM, BN = S2_BN, BK = S2_BK, NSTAGE = S2_NS;
-    constexpr int NT = 512, NWAVE = 8, ROWB = BK * 2, RPI = 1024 / ROWB, RPR = NWAVE * RPI;
+    constexpr int BM = S2_BM, BN = S2_BN, NSTAGE = S2_NS, S2_LDS = s2_lds<BK>();
+    constexpr int NT = 512, NWAVE = 8, ROWB = BK * 2, CH = BK / 8, RPI = 1024 / ROWB, RPR = NWAVE * RPI;
     constexpr int WN = 2, WROWS = 64, WCOLS = 64, MI = 4, NI = 4;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int ASLOTS = BM / RPR, BSLOTS = BN / RPR, L = ASLOTS + BSLOTS;
@@ -70,8 +78,8 @@ __global__ __launch_bounds__(512, 1) void conv_dgrad_s2_kernel(const bf16_t* __r
         return;
     }
 
-    auto key = [](int row) { return row & 7; };
-    const int rl = lane / 8, p = lane % 8, cch = p ^ key(rl);
+    auto key = [](int row) { return BK == 64 ? (row & 7) : (((row >> 3) & 1) * 3); };      // as conv_gemm_pipe_kernel
+    const int rl = lane / CH, p = lane % CH, cch = p ^ key(rl);
     int a_h0[ASLOTS], a_w0[ASLOTS], a_pix[ASLOTS];
     bool a_ok[ASLOTS];
     const long zdelta = reinterpret_cast<const char*>(zero_page) - reinterpret_cast<const char*>(X);
@@ -166,9 +174,9 @@ __global__ __launch_bounds__(512, 1) void conv_dgrad_s2_kernel(const bf16_t* __r
     __syncthreads();
 #ifdef PPV_STAMPS
     unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    tile_epilogue<BM, BN, S2_LDS, 1, false, RED, MI, NI, false, S2RowMap>(acc, smem, Out, stat_part, nullptr, nullptr, g, ci * 7 + tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{}, stamp_, rm);
+    tile_epilogue<BM, BN, S2_LDS, (BK == 64 ? 1 : 2), false, RED, MI, NI, false, S2RowMap>(acc, smem, Out, stat_part, nullptr, nullptr, g, ci * 7 + tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{}, stamp_, rm);
 #else
-    tile_epilogue<BM, BN, S2_LDS, 1, false, RED, MI, NI, false, S2RowMap>(acc, smem, Out, stat_part, nullptr, nullptr, g, ci * 7 + tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{}, rm);
+    tile_epilogue<BM, BN, S2_LDS, (BK == 64 ? 1 : 2), false, RED, MI, NI, false, S2RowMap>(acc, smem, Out, stat_part, nullptr, nullptr, g, ci * 7 + tile_m, stat_rows, red_x, red_coef, m0, n0, CoopBn{}, rm);
 #endif
 }
 
@@ -183,7 +191,7 @@ bool conv_dgrad_s2_supported(const ConvGeom& g, int Cs, int div) {
     if (div != 2 || g.a != 1 || g.off != g.offw || g.R != g.S) return false;
     if (!((g.R == 3 && g.off == -1) || (g.R == 1 && g.off == 0))) return false;
     if (g.Ho != 2 * g.Hs || g.Wo != 2 * g.Ws || ilog2_exact(g.Hs) < 0 || ilog2_exact(g.Ws) < 0) return false;
-    return Cs % S2_BK == 0 && g.N % S2_BN == 0;
+    return Cs % 64 == 0 && g.N % S2_BN == 0;
 }
 
 int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* zero_page, const bf16_t* red_x,
@@ -218,16 +226,22 @@ int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* st
     ConvGeom gc = g;                                                       // one class: rows = B * Hs * Ws pixels of the g grid
     gc.Ho = g.Hs; gc.Wo = g.Ws; gc.M = (long)g.B * g.Hs * g.Ws; gc.sh = 0; gc.flat = 0; gc.chunked = 0;
     const int tiles_n = g.N / S2_BN, tiles_m = (int)((gc.M + S2_BM - 1) / S2_BM), tpc = tiles_m * tiles_n;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-        attr_set = true;
-    }
-    if (red_x)
-        conv_dgrad_s2_kernel<true><<<4 * tpc, 512, S2_LDS, stream>>>(X, Wt, (bf16_t*)out, stat_part, zero_page, gc, tab, tpc, tiles_n, stat_rows, red_x, red_coef);
-    else
-        conv_dgrad_s2_kernel<false><<<4 * tpc, 512, S2_LDS, stream>>>(X, Wt, (bf16_t*)out, nullptr, zero_page, gc, tab, tpc, tiles_n, stat_rows, nullptr, nullptr);
+    static const int bk = getenv("PPV_S2_BK") ? atoi(getenv("PPV_S2_BK")) : 32;                    // A/B: 64 = one 144-KB workgroup per CU
+    auto go = [&](auto BK_) {
+        constexpr int BK = decltype(BK_)::value, LDS = s2_lds<BK>();
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<false, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<true, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr_set = true;
+        }
+        if (red_x)
+            conv_dgrad_s2_kernel<true, BK><<<4 * tpc, 512, LDS, stream>>>(X, Wt, (bf16_t*)out, stat_part, zero_page, gc, tab, tpc, tiles_n, stat_rows, red_x, red_coef);
+        else
+            conv_dgrad_s2_kernel<false, BK><<<4 * tpc, 512, LDS, stream>>>(X, Wt, (bf16_t*)out, nullptr, zero_page, gc, tab, tpc, tiles_n, stat_rows, nullptr, nullptr);
+    };
+    if (bk == 64) go(std::integral_constant<int, 64>{});
+    else go(std::integral_constant<int, 32>{});
     return ppv_last_error();
 }
 

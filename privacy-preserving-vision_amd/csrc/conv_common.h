@@ -21,6 +21,9 @@ struct ConvGeom {
     int flat;            // 1x1, unit step, no offset, same grid: GEMM row m IS source pixel m (no (b, ho, wo) decomposition)
     long M;              // B * Ho * Wo
     int chunked;         // layout experiment (flat launches, BK = 64): the source is [Cs / 64][M][64] instead of [M][Cs]
+    int add_lw = 0, add_lh = 0;   // != 0: the addend is COMPACT -- [B][Ho / 2][Wo / 2][N], the even-even pixels of the output map (every other
+                                  // pixel adds zero), Wo = 1 << add_lw, Ho = 1 << add_lh: the projection shortcut's stride-2 data gradient
+                                  // as trunk_plan.hip hands it to conv1's data gradient (conv_stream.hip only)
 };
 
 // Cooperative (grid-barrier) BatchNorm of the tile epilogue (conv_tile_epilogue.h, COOP; experiment of round 4): the
@@ -154,6 +157,10 @@ bool conv3x3_halo_supported(const ConvGeom& g, int Cs, int div);
 int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
                         const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
                         const ConvGeom& g, int stat_rows, hipStream_t stream);
+// The next ppv_conv_gemm / ppv_conv_gemm_red call of this thread takes its addend in the compact form of ConvGeom::add_lw (internal: the
+// whole-trunk executor; the launch fails if it does not land on conv_stream.hip -- ask conv_addend_compact_supported first).
+void conv_set_addend_compact(bool on);
+bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N);
 // conv_dgrad_s2.hip: data gradient of the stride-2 3x3 / 1x1 convolutions as four parity-class problems (bf16, no addend, no bit mask).
 bool conv_dgrad_s2_supported(const ConvGeom& g, int Cs, int div);
 int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* zero_page, const bf16_t* red_x,

@@ -466,10 +466,23 @@ __global__ __launch_bounds__(256) void weight_layout_multi_kernel(const WLayoutD
 using namespace ppv;
 
 static int g_conv_variant = 0;
+static thread_local bool g_addend_compact = false;         // conv_set_addend_compact: one-shot, consumed by the next conv_gemm_impl
 static thread_local int g_conv_offw_override = INT_MIN;   // set by ppv_conv_gemm_rect around its call into conv_gemm_impl
 #ifdef PPV_STAMPS
 namespace ppv { __device__ unsigned long long* g_stamps = nullptr; }
 #endif
+
+namespace ppv {
+void conv_set_addend_compact(bool on) { g_addend_compact = on; }
+bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N) {
+    static const int on = getenv("PPV_ADDEND_COMPACT") ? atoi(getenv("PPV_ADDEND_COMPACT")) : 1;   // A/B: 0 = dense shortcut gradient
+    if (!on || g_conv_variant != 0 || H < 2 || W < 2 || (H & (H - 1)) || (W & (W - 1))) return false;
+    ConvGeom g;
+    g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cs; g.Ho = H; g.Wo = W; g.N = N; g.R = 1; g.S = 1; g.a = 1; g.off = 0; g.offw = 0; g.sh = 0;
+    g.M = (long)B * H * W; g.flat = 1; g.chunked = 0;
+    return Cs <= 128 && conv1x1_stream_supported(g, Cs, 1);    // layer 2 (K = 128: 288 -> 211 us for the pair of launches); layer 3's K = 256 stream
+}                                                              // kernel has no registers left for the gather (measured: no gain), layer 4 is tiled
+}  // namespace ppv
 
 extern "C" {
 
@@ -518,10 +531,20 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         !mask_bits && !(red_x_ && N % 128) && !(stat_part && !red_x_) && conv_dgrad_s2_supported(g, Cs, div))
         return conv_dgrad_s2_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
                                     stat_rows, stream);
+    const bool compact = g_addend_compact;
+    g_addend_compact = false;
+    if (compact) {
+        int lw = 0, lh = 0;
+        while ((1 << lw) < Wo) ++lw;
+        while ((1 << lh) < Ho) ++lh;
+        if (!addend || out_f32 || g_conv_variant != 0 || (1 << lw) != Wo || (1 << lh) != Ho || lw < 1 || lh < 1 || Cs > 128 || !conv1x1_stream_supported(g, Cs, div))
+            return PPV_ERR_BAD_SIZE;
+        g.add_lw = lw; g.add_lh = lh;
+    }
     // few input channels, wide output: conv_stream.hip (variant 8: wherever it can run; automatic: launches with a residual addend)
     // (its f32 instantiation has no epilogue options: variant 8 leaves f32 launches with an addend / sums to the tiled kernels)
     static const int stream_auto = getenv("PPV_STREAM_DGRAD") ? atoi(getenv("PPV_STREAM_DGRAD")) : 1;   // A/B: 0 = tiled kernels for the addend launches too
-    if (((g_conv_variant == 0 && addend && !out_f32 && stream_auto) || (g_conv_variant == 8 && (!out_f32 || (!addend && !red_x_ && !stat_part)))) &&
+    if (((g_conv_variant == 0 && addend && !out_f32 && (stream_auto || compact)) || (g_conv_variant == 8 && (!out_f32 || (!addend && !red_x_ && !stat_part)))) &&
         conv1x1_stream_supported(g, Cs, div))
         return conv1x1_stream_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)addend,
                                      (const unsigned char*)mask_bits, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,

@@ -233,7 +233,16 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                         // (32-bit element offsets: SGPR base + VGPR offset addressing, the host checks M * N < 2^31)
                         av_[mi][h] = xv_[mi][h] = make_uint4(0, 0, 0, 0);
                         mb_[mi][h] = 0xff;
-                        if constexpr (ADD) av_[mi][h] = *reinterpret_cast<const uint4*>(addend + off);
+                        if constexpr (ADD) {
+                            if (KC > 128 || g.add_lw == 0) {                 // (KC = 256 sits at its register cap: no compact form there, the host knows)
+                                av_[mi][h] = *reinterpret_cast<const uint4*>(addend + off);
+                            } else {                                         // compact addend: only the even-even pixels of the map have one
+                                const unsigned x = m & ((1u << g.add_lw) - 1u), y = (m >> g.add_lw) & ((1u << g.add_lh) - 1u);
+                                const unsigned b = m >> (g.add_lw + g.add_lh);
+                                const unsigned cm = (((b << (g.add_lh - 1)) + (y >> 1)) << (g.add_lw - 1)) + (x >> 1);
+                                if (ok && ((x | y) & 1u) == 0u) av_[mi][h] = *reinterpret_cast<const uint4*>(addend + (cm * (unsigned)g.N + c));
+                            }
+                        }
                         if constexpr (RED) {
                             xv_[mi][h] = *reinterpret_cast<const uint4*>(red_x + off);
                             if (!ok) xv_[mi][h] = make_uint4(0, 0, 0, 0);

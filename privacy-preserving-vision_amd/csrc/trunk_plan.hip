@@ -20,6 +20,11 @@
 #include "ppv_common.h"
 #include "ppv_hip.h"
 
+namespace ppv {                            // conv_gemm.hip (declared in conv_common.h): compact addend of the next ppv_conv_gemm* call
+void conv_set_addend_compact(bool on);
+bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N);
+}
+
 namespace {
 
 inline size_t a256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -363,7 +368,15 @@ int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, co
             if (side) TRY(fork_between(main, side));
             TRY(ppv_conv_wgrad(A + o.gxd, xin, kd.dw, wscr, zero_page, B, o.Hin, o.Win, o.Cin, o.H2, o.W2, C3, 1, 1, o.st, 0, ws));
         }
-        TRY(ppv_conv_gemm(A + o.gxd, kd.wd, A + o.gind, nullptr, nullptr, nullptr, zero_page, B, o.H2, o.W2, C3, o.Hin, o.Win, o.Cin, 1, 1, 1, 0, o.st, 0, 0, main));
+        // stride-2 shortcut: its data gradient is nonzero on the even-even pixels only.  Where conv1's data gradient runs on conv_stream.hip
+        // the gradient stays COMPACT (a plain 1x1 product on the g grid, a quarter of the bytes) and the addend is gathered from it;
+        // otherwise (layer 1: stride 1; layer 4: tiled kernel) the dense map is written (conv_dgrad_s2.hip) and read back.
+        const bool compact = o.st == 2 && ppv::conv_addend_compact_supported(B, o.Hin, o.Win, P, o.Cin);
+        if (compact)
+            TRY(ppv_conv_gemm(A + o.gxd, kd.wd, A + o.gind, nullptr, nullptr, nullptr, zero_page, B, o.H2, o.W2, C3, o.H2, o.W2, o.Cin, 1, 1, 1, 0, 1, 0, 0, main));
+        else
+            TRY(ppv_conv_gemm(A + o.gxd, kd.wd, A + o.gind, nullptr, nullptr, nullptr, zero_page, B, o.H2, o.W2, C3, o.Hin, o.Win, o.Cin, 1, 1, 1, 0, o.st, 0, 0, main));
+        ppv::conv_set_addend_compact(compact);
         if (feed_prev)
             TRY(ppv_conv_gemm_red(A + o.gx1, k1.wd, A + o.gin, (float*)(A + L.b[i - 1].p3), A + L.b[i - 1].x3, nullptr, A + o.gind, xin_bits, zero_page,
                                   B, o.Hin, o.Win, P, o.Hin, o.Win, o.Cin, 1, 1, 1, 0, 1, 8, main));

@@ -507,6 +507,8 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
                           const void* zero_page, const void* red_x_, const float* red_coef,
                           int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,
                           int out_f32, int stat_rows, hipStream_t stream) {
+    const bool compact = g_addend_compact;                   // one-shot request of conv_set_addend_compact, consumed whatever happens below
+    g_addend_compact = false;
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
@@ -531,8 +533,6 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         !mask_bits && !(red_x_ && N % 128) && !(stat_part && !red_x_) && conv_dgrad_s2_supported(g, Cs, div))
         return conv_dgrad_s2_launch((const bf16_t*)X, (const bf16_t*)Wt, out, stat_part, (const bf16_t*)zero_page, (const bf16_t*)red_x_, red_coef, g,
                                     stat_rows, stream);
-    const bool compact = g_addend_compact;
-    g_addend_compact = false;
     if (compact) {
         int lw = 0, lh = 0;
         while ((1 << lw) < Wo) ++lw;

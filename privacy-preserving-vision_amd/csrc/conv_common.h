@@ -21,6 +21,8 @@ struct ConvGeom {
     int flat;            // 1x1, unit step, no offset, same grid: GEMM row m IS source pixel m (no (b, ho, wo) decomposition)
     long M;              // B * Ho * Wo
     int chunked;         // layout experiment (flat launches, BK = 64): the source is [Cs / 64][M][64] instead of [M][Cs]
+    int nt = 0;          // 1: the bf16 output tile is stored NON-TEMPORALLY (round 5: -0.43 ms per step, tools/ab_env01.sh PPV_NT_STORE; the
+                         // outputs are 17-270 MB each and the consumer's first read comes a whole launch later)
     int add_lw = 0, add_lh = 0;   // != 0: the addend is COMPACT -- [B][Ho / 2][Wo / 2][N], the even-even pixels of the output map (every other
                                   // pixel adds zero), Wo = 1 << add_lw, Ho = 1 << add_lh: the projection shortcut's stride-2 data gradient
                                   // as trunk_plan.hip hands it to conv1's data gradient (conv_stream.hip only)
@@ -51,6 +53,14 @@ __device__ __forceinline__ uint4 relu_mask8(uint4 v, unsigned b) {
     auto keep = [](unsigned two) { return ((two & 1u) ? 0xffffu : 0u) | ((two & 2u) ? 0xffff0000u : 0u); };
     v.x &= keep(b); v.y &= keep(b >> 2); v.z &= keep(b >> 4); v.w &= keep(b >> 6);
     return v;
+}
+
+// 16-byte global store, non-temporal when nt (wave-uniform) is set
+__device__ __forceinline__ void store16_nt(void* p, uint4 v, int nt) {
+    typedef unsigned nt_u32x4_t __attribute__((ext_vector_type(4)));
+    const nt_u32x4_t nv = {v.x, v.y, v.z, v.w};
+    if (nt) __builtin_nontemporal_store(nv, reinterpret_cast<nt_u32x4_t*>(p));
+    else *reinterpret_cast<nt_u32x4_t*>(p) = nv;
 }
 
 #define GLDS16(gptr, lptr)                                                                                   \

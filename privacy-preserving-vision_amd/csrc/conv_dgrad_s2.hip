@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512, BK == 64 ? 1 : 2) void conv_dgrad_s2_kernel(co
         constexpr int CPR = BN / 8, RSTEP = NT / CPR;
         const int row0 = tid / CPR, ch = tid % CPR;
         for (int row = row0; row < BM; row += RSTEP)
-            if (m0 + row < g.M) *reinterpret_cast<uint4*>(Out + rm(m0 + row) * g.N + n0 + ch * 8) = make_uint4(0, 0, 0, 0);
+            if (m0 + row < g.M) store16_nt(Out + rm(m0 + row) * g.N + n0 + ch * 8, make_uint4(0, 0, 0, 0), g.nt & 4);
         return;
     }
 

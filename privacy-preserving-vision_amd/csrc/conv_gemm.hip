@@ -521,6 +521,8 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.M = (long)B * Ho * Wo;
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     g.chunked = 0;
+    static const int nt_store = getenv("PPV_NT_STORE") ? atoi(getenv("PPV_NT_STORE")) : 1;         // A/B: 0 = ordinary output stores
+    g.nt = nt_store;
     static const int conv_debug = getenv("PPV_CONV_DEBUG") ? atoi(getenv("PPV_CONV_DEBUG")) : 0;   // 1 = loads only, 2 = compute only (wrong results: timing experiments)
     if (conv_debug > 0) g.chunked = 1 + conv_debug;
     if (g_conv_variant & 0x1000) {            // layout A/B (tools/bench_layout_ab.py): flat launches on the BK = 64 tiles read a chunked source

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                             }
                             red_acc8(pv, xv[h], ra, rb);
                         }
-                        if (FULL || m < (unsigned)g.M) *reinterpret_cast<uint4*>(out + (m * (unsigned)g.N + c)) = pv;
+                        if (FULL || m < (unsigned)g.M) store16_nt(out + (m * (unsigned)g.N + c), pv, g.nt & 2);
                     }
                 }
                 if constexpr (RED) {                                         // fold the 8 lanes that share a chunk column, then the waves (LDS)

@@ -157,7 +157,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
                         uint4 v = *reinterpret_cast<const uint4*>(sOh + row * LDO + ch * 16);
                         if (mask_bits) v = relu_mask8(v, mb[it]);
                         if constexpr (RED) red_acc8(v, *reinterpret_cast<const uint4*>(red_x + m * g.N + n0 + ch * 8), ra, rb);
-                        *reinterpret_cast<uint4*>(outp + m * g.N + n0 + ch * 8) = v;
+                        store16_nt(outp + m * g.N + n0 + ch * 8, v, g.nt & 1);
                     }
                 }
                 __syncthreads();
@@ -300,7 +300,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
                     if (red_coef) v[it] = red_mask8(v[it], xv[it], rsc, rsh);
                     red_acc8(v[it], xv[it], ra, rb);
                 }
-                *reinterpret_cast<uint4*>(out + eoff(i0 + it)) = v[it];
+                store16_nt(out + eoff(i0 + it), v[it], g.nt & 1);
             }
         }
     } else {
@@ -317,7 +317,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
                     if (red_coef) v = red_mask8(v, xv, rsc, rsh);
                     red_acc8(v, xv, ra, rb);
                 }
-                *reinterpret_cast<uint4*>(out + m * g.N + n0 + ch * 8) = v;
+                store16_nt(out + m * g.N + n0 + ch * 8, v, g.nt & 1);
             }
         }
     }

@@ -41,11 +41,19 @@ __device__ __forceinline__ void unpack8u(const uint4 u, float (&f)[8]) {
         f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
     }
 }
+#ifndef PPV_NT_ELT
+#define PPV_NT_ELT 0       // 1: element-wise outputs (activations, gradients) stored non-temporally (A/B build; measured neutral to -0.1 ms)
+#endif
 __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
-    unsigned w[4];
+    typedef unsigned nt_u32x4_t __attribute__((ext_vector_type(4)));
+    nt_u32x4_t w;
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf_(f[2 * i]) | ((unsigned)f2bf_(f[2 * i + 1]) << 16);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+#if PPV_NT_ELT
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_u32x4_t*>(p));
+#else
+    *reinterpret_cast<nt_u32x4_t*>(p) = w;
+#endif
 }
 
 // ----------------------------------------------------------------------------- BN statistics -> coefficients

@@ -118,7 +118,19 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     self-contained)."""
     enc_params = [p for p in encoder.parameters() if p.requires_grad]
     cam_params = [p for p in camera.parameters() if p.requires_grad]
-    opt_enc = torch.optim.Adam(enc_params, lr=1e-4, fused=True, capturable=graph)
+    # encoder / decoder optimisers (train.py:92-101): torch's fused Adam, as a user of the reference would construct it.  PPV_BENCH_PPV_ADAM=1:
+    # ppv_amd.optim.Adam (same arithmetic and state layout, the whole list in one 10 k-workgroup launch: 193 us against 629 us alone on the
+    # device) -- measured -0.04 ms on the headline and +0.45 ms with the decoder: the update runs BESIDE the next step's camera forward, where
+    # torch's 45-240-workgroup launches leave the CUs to the critical path and a full-width launch does not (DESIGN 4b)
+    if graph or os.environ.get("PPV_BENCH_PPV_ADAM", "0") == "0":
+        def make_adam(ps, lr):
+            return torch.optim.Adam(ps, lr=lr, fused=True, capturable=graph)
+    else:
+        from ppv_amd.optim import Adam as _PpvAdam
+
+        def make_adam(ps, lr):
+            return _PpvAdam(ps, lr=lr)
+    opt_enc = make_adam(enc_params, 1e-4)
     opt_cam = torch.optim.Adam(cam_params, lr=5e-7, fused=os.environ.get("PPV_BENCH_CAM_ADAM_FUSED", "1") != "0", capturable=graph)
     rank = dist.get_rank() if dist.is_initialized() else 0
     imgs = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(device)
@@ -127,7 +139,7 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
     if decoder is not None:                                                       # BASELINE.json config 3 / 5
         from torch.nn.utils.rnn import pack_padded_sequence
         dec_params = [p for p in decoder.parameters() if p.requires_grad]
-        opt_dec = torch.optim.Adam(dec_params, lr=4e-4, fused=True, capturable=graph)   # train.py:33,100-101
+        opt_dec = make_adam(dec_params, 4e-4)                                       # train.py:33,100-101
         gen = torch.Generator().manual_seed(100 + rank)
         caps = torch.randint(0, decoder.vocab_size, (batch, 52), generator=gen).to(device)
         caplens_host = torch.randint(9, 19, (batch, 1), generator=gen)            # COCO-like lengths incl. <start>/<end>: what the loader yields

@@ -191,6 +191,15 @@ int ppv_conv_set_variant(int v);   /* tuning hook: 0 auto, 1 two-stage, 2 128x12
 int ppv_weight_layout_multi(const void* desc, int ndesc, int total_blocks, ppv_stream_t stream);
 int ppv_weight_layout(const float* w, void* out, int Cout, int Cin, int R, int S, int mode, ppv_stream_t stream);
 
+/* ---- optimiser (csrc/optim.hip) ------------------------------------------------------------------
+ * One Adam step (torch.optim.Adam semantics, amsgrad = maximize = False; the encoder / decoder optimisers of
+ * /root/reference/Image_Caption/train.py:92-101, stepped at :318-321) of a whole list of f32 tensors in one launch.
+ * desc: DEVICE array of ndesc 48-byte records {float* p; const float* g; float* m; float* v; long numel; int blk0; int vec}:
+ * blk0 = prefix sum of ceil(numel / 4096) over the records, vec = 1 when the four pointers are 16-byte aligned;
+ * total_blocks = that sum.  bias_correction{1,2} = 1 - beta{1,2}^step (the caller counts steps). */
+int ppv_adam_multi(const void* desc, int ndesc, int total_blocks, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   double bias_correction1, double bias_correction2, ppv_stream_t stream);
+
 /* weight gradient (layer2..4 trainable, models.py:43-54): torch layout [N][Cs][R][S] f32 out; per-slice slabs in scratch */
 size_t ppv_conv_wgrad_scratch_bytes(long M, int N, int R, int S, int Cs);
 int ppv_conv_wgrad(const void* G, const void* X, float* dW_out, void* scratch, const void* zero_page, int B, int Hs,

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -91,6 +91,7 @@ PROTOTYPES = {
     "ppv_conv_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 14 + [_P]),
     "ppv_conv_gemm_red": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P]),
     "ppv_weight_layout_multi": (_I, [_P, _I, _I, _P]),
+    "ppv_adam_multi": (_I, [_P, _I, _I] + [_c.c_double] * 7 + [_P]),
     "ppv_weight_layout": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_conv_stat_tiles": (_I, [_L]),
     "ppv_conv_bn_relu_coop": (_I, [_P] * 10 + [_F, _F, _P, _P] + [_I] * 6 + [_P]),

@@ -1,0 +1,71 @@
+"""ppv_amd.optim.Adam against torch.optim.Adam on the CPU (the oracle here is stock PyTorch's single-tensor f32 implementation of the
+optimiser the reference's harness constructs, Image_Caption/train.py:92-101): same parameters, same gradients, five steps."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(seed, sizes):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(s, generator=g) for s in sizes]
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_adam_equals_torch_cpu(wd):
+    from ppv_amd.optim import Adam
+    sizes = [(64,), (64, 3, 7, 7), (256, 64, 1, 1), (5,), (4099,), (512, 512, 3, 3), (3, 1367)]
+    ref = [torch.nn.Parameter(t.clone()) for t in _make(0, sizes)]
+    flat = torch.zeros(sum(p.numel() for p in ref) + 3, device="cuda")           # gradients as slices of one buffer, some of them unaligned
+    got, off = [], 1
+    for t in _make(0, sizes):
+        got.append(torch.nn.Parameter(t.cuda()))
+    o_ref = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=False)
+    o_got = Adam(got, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    for step in range(5):
+        grads = _make(100 + step, sizes)
+        off = 1
+        for p, q, g in zip(ref, got, grads):
+            p.grad = g.clone()
+            view = flat[off:off + g.numel()].view_as(g)
+            view.copy_(g)
+            q.grad = view
+            off += g.numel()
+        if step == 3:                                                            # a parameter without a gradient in one step keeps its count
+            ref[3].grad = None
+            got[3].grad = None
+        o_ref.step()
+        o_got.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ref, got):
+        assert torch.allclose(q.detach().cpu(), p.detach(), rtol=2e-6, atol=1e-7)
+        assert torch.allclose(o_got.state[q]["exp_avg"].cpu(), o_ref.state[p]["exp_avg"], rtol=2e-6, atol=2e-7)     # one rounding of g - m at O(1)
+        assert torch.allclose(o_got.state[q]["exp_avg_sq"].cpu(), o_ref.state[p]["exp_avg_sq"], rtol=2e-6, atol=1e-8)
+        assert float(o_got.state[q]["step"]) == float(o_ref.state[p]["step"])
+
+
+def test_adam_state_dict_round_trip_with_torch():
+    from ppv_amd.optim import Adam
+    ps = [torch.nn.Parameter(t.cuda()) for t in _make(1, [(300,), (64, 64)])]
+    o = Adam(ps, lr=1e-3)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    o.step()
+    t = torch.optim.Adam(ps, lr=1e-3)
+    t.load_state_dict(o.state_dict())                                            # a checkpoint written with one loads into the other
+    o2 = Adam(ps, lr=1e-3)
+    o2.load_state_dict(t.state_dict())
+    assert float(o2.state[ps[0]]["step"]) == 1.0
+    assert torch.equal(o2.state[ps[1]]["exp_avg"], o.state[ps[1]]["exp_avg"])
+
+
+def test_adam_refuses_what_it_does_not_implement():
+    from ppv_amd.optim import Adam
+    p = [torch.nn.Parameter(torch.zeros(4, device="cuda"))]
+    with pytest.raises(NotImplementedError):
+        Adam(p, amsgrad=True)
+    p64 = [torch.nn.Parameter(torch.zeros(4, device="cuda", dtype=torch.float64))]
+    o = Adam(p64)
+    p64[0].grad = torch.zeros(4, device="cuda", dtype=torch.float64)
+    with pytest.raises(NotImplementedError):
+        o.step()

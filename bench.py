@@ -104,12 +104,82 @@ class _CellsMeanSquare(torch.autograd.Function):
         return t * (g * (2.0 / ctx.n)), None
 
 
+_DENSE_HEAD = [False]     # True: the stand-in head consumes the dense tensor even when the encoder also hands over its cells
+
+
 def head_stand_in(enc_out):
     """Stand-in for the caption head (CE + attention regulariser, train.py:276-282) in the headline metric."""
     cells = getattr(enc_out, "_ppv_cells", None)
-    if cells is None or os.environ.get("PPV_BENCH_DENSE_HEAD"):
+    if cells is None or _DENSE_HEAD[0] or os.environ.get("PPV_BENCH_DENSE_HEAD"):
         return _MeanSquare.apply(enc_out)
     return _CellsMeanSquare.apply(cells, enc_out.shape[1])
+
+
+@contextlib.contextmanager
+def surface_mode(encoder, dense):
+    """dense=True: the module surface of models.py:39-41 -- Encoder.forward materialises its [B,E,E,2048] f32 output, the head reads it and
+    returns a dense gradient that the encoder pools back.  dense=False: ppv_amd's own consumer (the decoder's compact path): the dense
+    tensor is lazy and the head works on the cells behind it."""
+    lazy0 = getattr(encoder, "lazy_output", None)
+    head0 = _DENSE_HEAD[0]
+    if lazy0 is not None:
+        encoder.lazy_output = not dense
+    _DENSE_HEAD[0] = dense
+    try:
+        yield
+    finally:
+        if lazy0 is not None:
+            encoder.lazy_output = lazy0
+        _DENSE_HEAD[0] = head0
+
+
+def timed_windows(step, k, n_windows, world, device, sync=None):
+    """n_windows windows of EXACTLY k steps, each bracketed by a barrier + synchronize on both sides; per window the MAX over ranks.
+    -> (seconds per window, host seconds spent enqueueing each window)."""
+    sync = sync or torch.cuda.synchronize
+    wins, enq = [], []
+    for _ in range(n_windows):
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        e = time.perf_counter() - t0
+        sync()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        wins.append(el)
+        enq.append(e)
+    return wins, enq
+
+
+def surface_fields(world, batch, steps, wins, other_wins, headline_dense, has_decoder):
+    """The timing-protocol keys of the JSON line: `value` is computed from the median of `wins`; this adds the windows, the protocol,
+    and both output surfaces (value_dense_surface == value unless --lazy / --decoder)."""
+    med = lambda w: None if not w else sorted(w)[len(w) // 2]
+    head, other = med(wins), med(other_wins)
+    dense, lazy = (head, other) if headline_dense else (other, head)
+    if has_decoder:
+        dense = lazy = None
+    rate = lambda t: None if t is None else round(world * batch * steps / t, 1)
+    ms = lambda t: None if t is None else round(t / steps * 1e3, 3)
+    return {
+        "windows_ms_per_step": [ms(w) for w in wins],
+        "timing": f"median of {len(wins)} windows of exactly {steps} steps, each bracketed by barrier + synchronize; max over ranks per window",
+        "gc": "cyclic GC frozen + disabled during warm-up and timed windows (gc.freeze(); gc.disable()), re-enabled after",
+        "surface": ("dense: Encoder.forward writes the [B,36,36,2048] f32 tensor of models.py:39-41, the stand-in head reads it and returns a dense "
+                    "gradient" if headline_dense else ("decoder on the encoder's cells (compact path)" if has_decoder else
+                                                       "lazy: dense output not materialised, head on the 8x8 cells (--lazy)")),
+        "value_dense_surface": rate(dense), "ms_per_step_dense_surface": ms(dense),
+        "value_lazy_consumer": rate(lazy), "ms_per_step_lazy_consumer": ms(lazy),
+        "windows_ms_per_step_other_surface": None if not other_wins else [ms(w) for w in other_wins],
+    }
 
 
 def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=False, graph=False):
@@ -283,7 +353,7 @@ def live_counter_passes(budget_s=240):
     t_start = time.perf_counter()
     tools = os.path.join(ROOT, "tools")
     td = tempfile.mkdtemp(prefix="ppv_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", PPV_WGRAD_SIDE="0")
+    env = dict(os.environ, TMPDIR="/tmp", PPV_WGRAD_SIDE="0", PPV_BENCH_ONE_WINDOW="1")
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-dense", "--no-roofline",
              "--no-configs", "--no-live-pmc"]
     passes = {"stats": ["--kernel-trace", "--stats"], "fetch": ["--pmc", "FETCH_SIZE"], "write": ["--pmc", "WRITE_SIZE"],
@@ -562,8 +632,10 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-dense", action="store_true", help="skip the value_dense_surface and empty-queue host-enqueue legs (profiling runs: "
-                    "exactly warmup + steps headline steps, so per-step counter totals divide cleanly)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the secondary legs (the other output surface, the empty-queue host-enqueue "
+                    "measurement): profiling runs execute headline steps only, so per-step counter totals divide cleanly")
+    ap.add_argument("--lazy", action="store_true", help="diagnosis: make the lazy-output step (ppv_amd's own consumer) the headline instead "
+                    "of the dense module surface")
     ap.add_argument("--decoder", action="store_true",
                     help="BASELINE.json config 3/5: add the attention decoder (512/512/512, 9490 words) to the step; the "
                          "default is the headline Camera+ResNet-101 metric")
@@ -634,77 +706,56 @@ def main():
 
     # The interpreter's cyclic garbage collector is parked for the warm-up + timed steps (everything the steps allocate is freed by
     # reference counting; a generation-2 sweep over the ~10^5 live objects of the modules takes 10-30 ms, i.e. 1-2 of the K = 20 timed
-    # steps: one driver-style run in round 5 read 23.28 ms per step with a host enqueue time of 17 ms against 21.70 / 11 in the run
-    # before it on the same box).  A training script gets the same with gc.freeze() after its set-up.
+    # steps).  A training script gets the same with gc.freeze() after its set-up; the line records it ("gc").
+    #
+    # HEADLINE = the dense module surface (models.py:39-41: Encoder.forward writes its [B,E,E,2048] f32 tensor, the head reads it and hands
+    # back a dense gradient); `value_lazy_consumer` = the same step with ppv_amd's own consumer (lazy dense tensor, head on the 8x8 cells).
+    # Each is the MEDIAN of three windows of exactly K steps (`windows_ms_per_step`); --lazy swaps the two roles (diagnosis).
     import gc
+    headline_dense = (not args.lazy) and decoder is None and hasattr(encoder, "lazy_output")
+    n_win = 1 if (use_graph or args.no_dense or os.environ.get("PPV_BENCH_ONE_WINDOW")) else 3     # profiling runs: exactly W + K steps
     gc.collect()
     gc.freeze()
     gc.disable()
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    enqueued = time.perf_counter() - t0          # host time to enqueue the K steps (close to `elapsed` = the host, not the device, sets the pace)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("PPV_BENCH_WINDOWS") and world == 1:   # diagnosis: more windows of K steps after the reported one (stderr only)
-        for wi in range(int(os.environ["PPV_BENCH_WINDOWS"])):
-            torch.cuda.synchronize()
-            tw = time.perf_counter()
-            for _ in range(args.steps):
+    try:
+        with surface_mode(encoder, headline_dense):
+            for _ in range(args.warmup):
                 step()
-            torch.cuda.synchronize()
-            print(f"[bench] window {wi + 2}: {(time.perf_counter() - tw) / args.steps * 1e3:.3f} ms per step (reported window: {elapsed / args.steps * 1e3:.3f})",
-                  file=sys.stderr, flush=True)
-    gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            wins, enqs = timed_windows(step, args.steps, n_win, world, device)
+        mid = sorted(range(n_win), key=lambda i: wins[i])[n_win // 2]
+        elapsed, enqueued = wins[mid], enqs[mid]
 
-    # Host cost of a step WITHOUT back-pressure: over the K timed steps the host runs ahead of the device until the command queue is
-    # full and then enqueues at the device's pace, so `enqueued / K` above converges to ms_per_step whenever the host is the faster
-    # side.  Two steps into an empty queue measure the interpreter + runtime alone.
-    torch.cuda.synchronize()
-    host_free = None
-    if not args.no_dense:
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        host_free = (time.perf_counter() - t1) / 2
+        # Host cost of a step WITHOUT back-pressure: over the K timed steps the host runs ahead of the device until the command queue is
+        # full and then enqueues at the device's pace, so `enqueued / K` converges to ms_per_step whenever the host is the faster
+        # side.  Two steps into an empty queue measure the interpreter + runtime alone.
         torch.cuda.synchronize()
+        host_free = None
+        if not args.no_dense:
+            with surface_mode(encoder, headline_dense):
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                host_free = (time.perf_counter() - t1) / 2
+                torch.cuda.synchronize()
 
-    # The same step with the module's dense [B,36,36,2048] f32 output materialised and consumed (Encoder(lazy_output=False) + a head that
-    # reads it and returns a dense gradient): what a foreign consumer of models.py:39-41's tensor pays.
-    dense = None
-    if world == 1 and not args.decoder and not use_graph and not args.no_dense and not os.environ.get("PPV_BENCH_DENSE_HEAD") and hasattr(encoder, "lazy_output"):
-        lazy0 = encoder.lazy_output
-        encoder.lazy_output = False
-        os.environ["PPV_BENCH_DENSE_HEAD"] = "1"
-        try:
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize()
-            dense = (time.perf_counter() - t1) / 5
-        finally:
-            encoder.lazy_output = lazy0
-            os.environ.pop("PPV_BENCH_DENSE_HEAD", None)
+        # the other surface, same run, same protocol
+        other = other_wins = None
+        if decoder is None and not use_graph and not args.no_dense and hasattr(encoder, "lazy_output"):
+            with surface_mode(encoder, not headline_dense):
+                for _ in range(2):
+                    step()
+                other_wins, _ = timed_windows(step, args.steps, n_win, world, device)
+            other = sorted(other_wins)[n_win // 2]
+    finally:
+        gc.enable()
+        gc.unfreeze()
 
     if (rank == 0 and world == 1 and not args.no_live_pmc and not args.no_roofline and not args.no_dense and not args.decoder and not args.ssim
             and not use_graph and args.batch == 128 and os.environ.get("PPV_BENCH_LIVE_PMC", "1") != "0"):
         torch.cuda.synchronize()
         live_counter_passes()
-    roof = None if args.no_roofline else roofline_of_dominant_kernel(eager_step)
+    with surface_mode(encoder, headline_dense):
+        roof = None if args.no_roofline else roofline_of_dominant_kernel(eager_step)
     side_configs = None
     if world == 1 and not args.decoder and not args.ssim and not use_graph and not args.no_configs and not args.no_dense and args.batch == 128:
         side_configs = side_config_legs(camera, encoder, args.batch, device)
@@ -719,14 +770,14 @@ def main():
                                  "host_enqueue_ms_per_step_timed_region is the same over the K timed steps, where a host that runs ahead "
                                  "is throttled by the full command queue",
             "host_enqueue_ms_per_step_timed_region": round(enqueued / args.steps * 1e3, 3),
-            "value_dense_surface": None if dense is None else round(args.batch / dense, 1),
-            "ms_per_step_dense_surface": None if dense is None else round(dense * 1e3, 3),
+            **surface_fields(world, args.batch, args.steps, wins, other_wins, headline_dense, decoder is not None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "IC OpticsZernike camera (896^2 wave grid, 350 Zernike terms, prueba '3') + ResNet-101 "
                                    "Encoder, fwd+bwd+Adam, 256x256; camera fp32/fp64, trunk bf16 storage + fp32 accumulate; "
-                                   + ("" if args.decoder else "the dense [B,36,36,2048] f32 output of models.py:39-41 is LAZY (written on first access, not "
-                                      "in the timed step) and the stand-in head works on the 8x8 cells behind it -- value_dense_surface is the "
-                                      "same step with that tensor written, read and its dense gradient pooled back (5 steps, same run); ")
+                                   + ("" if args.decoder else ("the dense [B,36,36,2048] f32 output of models.py:39-41 is written, read by the stand-in head and "
+                                      "its dense gradient pooled back INSIDE the timed step (value = value_dense_surface); value_lazy_consumer is the same "
+                                      "step with ppv_amd's own consumer (lazy dense tensor, head on the 8x8 cells behind it), same protocol, same run; "
+                                      if headline_dense else "LAZY dense output (--lazy diagnosis run): the head works on the 8x8 cells; "))
                                    + ("soft-attention LSTM decoder (512-d, 9490 words, captions of 9-18 tokens, CE + attention regulariser)"
                                       if args.decoder else "caption decoder not included (bench.py --decoder adds it)"),
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,

@@ -85,3 +85,30 @@ def test_ic_transform_length_is_the_next_native_length():
     assert [fc.ic_transform_length(p) for p in (32, 128, 130, 256, 258, 368, 512)] == [256, 256, 512, 512, 1024, 1024, 1024]
     with pytest.raises(ValueError):
         fc.ic_transform_length(514)
+
+
+def test_headline_is_the_dense_surface_as_a_median_of_three_windows():
+    """VERDICT r5 task 4: `value` is the dense module surface (models.py:39-41), `value_lazy_consumer` the extra key; both the median of
+    three K-step windows, the windows printed, the GC state recorded."""
+    b = _bench()
+    calls = []
+    wins, enq = b.timed_windows(lambda: calls.append(1), 5, 3, 1, None, sync=lambda: None)
+    assert len(calls) == 15 and len(wins) == 3 and len(enq) == 3 and all(w >= e for w, e in zip(wins, enq))
+    f = b.surface_fields(1, 128, 20, [0.46, 0.44, 0.50], [0.42, 0.43, 0.41], True, False)
+    for key in ("windows_ms_per_step", "timing", "gc", "surface", "value_dense_surface", "ms_per_step_dense_surface", "value_lazy_consumer",
+                "ms_per_step_lazy_consumer", "windows_ms_per_step_other_surface"):
+        assert key in f
+    assert f["windows_ms_per_step"] == [23.0, 22.0, 25.0] and f["ms_per_step_dense_surface"] == 23.0     # the median window
+    assert f["value_dense_surface"] == round(128 * 20 / 0.46, 1) and f["value_lazy_consumer"] == round(128 * 20 / 0.42, 1)
+    assert f["surface"].startswith("dense") and "median of 3 windows of exactly 20 steps" in f["timing"] and "frozen" in f["gc"]
+    lz = b.surface_fields(1, 128, 20, [0.42], None, False, False)                                       # --lazy diagnosis run
+    assert lz["value_dense_surface"] is None and lz["value_lazy_consumer"] == round(128 * 20 / 0.42, 1)
+    dec = b.surface_fields(1, 128, 20, [0.5], None, False, True)                                         # config 3: neither surface key
+    assert dec["value_dense_surface"] is None and dec["value_lazy_consumer"] is None
+
+    class Enc:
+        lazy_output = True
+    e = Enc()
+    with b.surface_mode(e, True):
+        assert e.lazy_output is False and b._DENSE_HEAD[0] is True
+    assert e.lazy_output is True and b._DENSE_HEAD[0] is False

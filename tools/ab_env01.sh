@@ -7,6 +7,6 @@ for i in 1 2 3; do for h in 0 1; do
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/bench_ab_$h.log") if x.startswith("{")][-1]
-d=json.loads(l); print("$V=$h", d["value"], d.get("value_dense_surface"), d["ms_per_step"])
+d=json.loads(l); print("$V=$h", d["value"], d.get("value_lazy_consumer"), d["ms_per_step"], d.get("windows_ms_per_step"))
 PY
 done; done

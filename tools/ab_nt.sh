@@ -10,6 +10,6 @@ for i in 1 2; do for c in ${1:-0:tree 1:tree}; do
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/bench_nt.log") if x.startswith("{")][-1]
-d=json.loads(l); print("PPV_NT_STORE=$nt lib=$lib", d["value"], d.get("value_dense_surface"), d["ms_per_step"])
+d=json.loads(l); print("PPV_NT_STORE=$nt lib=$lib", d["value"], d.get("value_lazy_consumer"), d["ms_per_step"], d.get("windows_ms_per_step"))
 PY
 done; done

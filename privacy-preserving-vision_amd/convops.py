@@ -408,11 +408,26 @@ def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, wan
 # The kernels compute train-mode g_x = k0 g + k1 x + k2 with k1, k2 proportional to 1 / count (csrc/trunk_ops.hip): an infinite
 # sample count makes both exactly zero while d gamma / d beta (which do not contain the count) stay right.  Set by the trunk's backward
 # around an eval-mode pass (encoder._TrunkFn.backward).
-EVAL_BN = False
+# Thread-local (autograd runs backward on per-device engine threads: a process-global flag would leak into a concurrent train-mode
+# backward of another encoder / device); use `with eval_bn():` around the pass.
+import contextlib as _contextlib
+import threading as _threading
+
+_BN_TLS = _threading.local()
+
+
+@_contextlib.contextmanager
+def eval_bn():
+    prev = getattr(_BN_TLS, "eval", False)
+    _BN_TLS.eval = True
+    try:
+        yield
+    finally:
+        _BN_TLS.eval = prev
 
 
 def _bn_count(rows):
-    return float("inf") if EVAL_BN else float(rows)
+    return float("inf") if getattr(_BN_TLS, "eval", False) else float(rows)
 
 
 def bn_bwd(gy, y, x, coef, relu, want_gpre=False, want_affine=True, part=None, part_ready=False, sums2=None, out_affine=None):

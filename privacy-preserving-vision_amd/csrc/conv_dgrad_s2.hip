@@ -229,11 +229,11 @@ int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* st
     static const int bk = getenv("PPV_S2_BK") ? atoi(getenv("PPV_S2_BK")) : 32;                    // A/B: 64 = one 144-KB workgroup per CU
     auto go = [&](auto BK_) {
         constexpr int BK = decltype(BK_)::value, LDS = s2_lds<BK>();
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<false, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            (void)hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<true, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr_set = true;
+        static PpvDevOnce attr_once;
+        if (attr_once.need()) {
+            PPV_ATTR(hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<false, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            PPV_ATTR(hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<true, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_once.done();
         }
         if (red_x)
             conv_dgrad_s2_kernel<true, BK><<<4 * tpc, 512, LDS, stream>>>(X, Wt, (bf16_t*)out, stat_part, zero_page, gc, tab, tpc, tiles_n, stat_rows, red_x, red_coef);

@@ -587,12 +587,12 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, false>;                                         \
         auto kt = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, true, false>;                                          \
         auto kr = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, REDOK_>;                                        \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
-            (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
-            (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
-            attr_set = true;                                                                                            \
+        static PpvDevOnce attr_once;                                                                                   \
+        if (attr_once.need()) {                                                                                                \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
+            attr_once.done();                                                                                            \
         }                                                                                                               \
         if (rx && !(REDOK_)) return PPV_ERR_BAD_SIZE;                                                                   \
         if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef, CoopBn{});           \
@@ -672,15 +672,15 @@ int ppv_conv_bn_relu_coop(const void* X, const void* Wt, void* x_raw, void* y, f
     constexpr int ring = NS_ * (BM_ + BN_) * BK_ * 2, epi = BM_ * (BN_ * 2 + 32) + 4096 + 8192, lds = ring > epi ? ring : epi;
     const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;
     auto k = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, 1, false, false, true>;
-    static bool attr_set = false;
+    static PpvDevOnce attr_once;
     static int per_cu = 0, cus = 0;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, BM_ * 2, lds)) return -(int)e;
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return -(int)e;
-        attr_set = true;
+        attr_once.done();
     }
     if ((long)tm * tn > (long)per_cu * cus) return PPV_ERR_BAD_SIZE;       // a grid barrier needs every workgroup resident
     CoopBn cb;

@@ -390,11 +390,11 @@ int conv3x3_halo64_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* s
                           const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
                           const ConvGeom& g, int stat_rows, hipStream_t stream) {
     if (!conv3x3_halo64_supported(g, g.Cs, 1)) return PPV_ERR_BAD_SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, H6_LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, H6_LDS);
-        attr_set = true;
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)conv3x3_halo64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, H6_LDS));
+        PPV_ATTR(hipFuncSetAttribute((const void*)conv3x3_halo64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, H6_LDS));
+        attr_once.done();
     }
     const int grid = (int)(g.M / 256);
     if (red_x)
@@ -439,11 +439,11 @@ static int halo_launch_t(const bf16_t* X, const bf16_t* Wt, void* out, float* st
     HaloGeom hg;
     if (!halo_geom(g, g.Cs, 1, &hg, BN)) return PPV_ERR_BAD_SIZE;
     constexpr int LDS = HaloCfg<BN>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        PPV_ATTR(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_once.done();
     }
     const int grid = (int)(g.M / HL_BM) * hg.tiles_n;
     if (red_x)

@@ -385,12 +385,12 @@ static int stream_launch_k(const bf16_t* X, const bf16_t* Wt, void* out, float* 
         {{conv1x1_stream_kernel<KC, false, true, false, false>, conv1x1_stream_kernel<KC, false, true, false, true>},
          {conv1x1_stream_kernel<KC, false, true, true, false>, conv1x1_stream_kernel<KC, false, true, true, true>}}};
     const kern_t kt = conv1x1_stream_kernel<KC, true, false, false, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
         for (int i = 0; i < 8; ++i)
-            (void)hipFuncSetAttribute((const void*)tab[i >> 2][(i >> 1) & 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+            PPV_ATTR(hipFuncSetAttribute((const void*)tab[i >> 2][(i >> 1) & 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PPV_ATTR(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_once.done();
     }
     const unsigned grid = (unsigned)(tiles_m * n_splits);
     const kern_t k = out_f32 ? kt : tab[red_x ? 1 : 0][addend ? 1 : 0][mask_bits ? 1 : 0];

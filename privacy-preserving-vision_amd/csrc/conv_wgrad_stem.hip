@@ -1775,9 +1775,9 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
             constexpr int lds2 = 4 * (64 * 256 + 2 * 8192), lds3 = 3 * (64 * 256 + 3 * 8192);   // four 32-KB stages (W <= 16), three 40-KB stages (W = 32)
             static bool attr9 = false;
             if (!attr9) {
-                (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+                PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+                PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad3x3_t9_kernel<3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
                 attr9 = true;
             }
             if (Wo == 32)
@@ -1802,8 +1802,8 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
         // 72-KB convolution workgroup of the main stream (PPV_WGRAD3_NS)
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W3_STAGE);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE);
+            PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W3_STAGE));
+            PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE));
             attr = true;
         }
         const int log2W = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
@@ -1836,12 +1836,12 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
         if (TN == 256) {
             constexpr int lds = 6 * 3 * 32 * 256 + 64;
             static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_stream_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+            if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_stream_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
             conv_wgrad_stream_kernel<256><<<grid, 768, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
         } else {
             constexpr int lds = 8 * 2 * 32 * 256 + 64;
             static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_stream_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+            if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_stream_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
             conv_wgrad_stream_kernel<128><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
         }
         wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, (int)splits);
@@ -1886,19 +1886,19 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
     if (TN == 256 && wide_stages == 2) {
         constexpr int lds = 2 * 3 * 64 * 256;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
         conv_wgrad_pipe_kernel<256, 2><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     } else if (TN == 256) {
         constexpr int lds = 3 * 3 * 64 * 256;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
         conv_wgrad_pipe_kernel<256, 3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     } else if (small_ring) {
         constexpr int lds = 2 * 2 * 64 * 256;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr = true;
         }
         // cooperative L2 prefetch (see wgrad_pipe_body): 1x1 / unit stride with the m-slice's tiles grouped on one XCD
@@ -1913,7 +1913,7 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
     } else {
         constexpr int lds = 4 * 2 * 64 * 256;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+        if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
         conv_wgrad_pipe_kernel<128, 4><<<grid, 256, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     }
     if (g.native_slabs && deferred) {
@@ -1945,7 +1945,7 @@ int ppv_conv_wgrad_group(const void* const* G, const void* const* X, float* cons
     const int tiles = (N / 128) * (Cs / 128);
     constexpr int lds = 2 * 2 * 64 * 256;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_group_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
     conv_wgrad_group_kernel<128, 2><<<(unsigned)(8 * ((P + 7) / 8) * tiles), 256, lds, stream>>>(ptrs, P, (const bf16_t*)zero_page, g);
     return ppv_last_error();
 }
@@ -1987,12 +1987,12 @@ int ppv_stem_conv(const float* img, const void* wst, void* out, float* stat_part
     const int grid = tiles < 1024 ? tiles : 1024;
     constexpr int lds3 = 192 * 24 * 16 + 1024;
     static bool attr3 = false;
-    if (!attr3) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3); attr3 = true; }
+    if (!attr3) { PPV_ATTR(hipFuncSetAttribute((const void*)stem_conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3)); attr3 = true; }
     static const int rows_form = getenv("PPV_STEM_ROWS") ? atoi(getenv("PPV_STEM_ROWS")) : 1;
     if (rows_form && (W / 2) % 128 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {                      // one output row segment per tile: staged input rows, no gathers
         constexpr int ldsr = 12288 + 64 * 384 + 128 * 144 + 1024;
         static bool attrr = false;
-        if (!attrr) { (void)hipFuncSetAttribute((const void*)stem_conv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsr); attrr = true; }
+        if (!attrr) { PPV_ATTR(hipFuncSetAttribute((const void*)stem_conv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsr)); attrr = true; }
         stem_conv_rows_kernel<<<tiles < 512 ? (tiles + 7) / 8 * 8 : 512, 256, ldsr, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, stat_part, B, H, W, tiles,
                                                                             stat_rows < 1 ? 1 : stat_rows);
         return ppv_last_error();
@@ -2011,7 +2011,7 @@ int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, i
     const int grid = tiles < 512 ? tiles : 512;
     constexpr int lds6 = 192 * 48 * 16 + 1024;
     static bool attr6 = false;
-    if (!attr6) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6); attr6 = true; }
+    if (!attr6) { PPV_ATTR(hipFuncSetAttribute((const void*)stem_conv_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds6)); attr6 = true; }
     stem_conv_kernel<6><<<grid, 256, lds6, stream>>>(img, (const bf16_t*)wst, (bf16_t*)out, nullptr, B, H, W, tiles, 1);
     return ppv_last_error();
 }
@@ -2025,8 +2025,8 @@ int ppv_stem_dgrad(const void* g_raw, const void* wsd, float* g_img, const void*
     constexpr int lds = 2 * 4 * 136 * 128 + 6 * 256 * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)stem_dgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)stem_dgrad_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 136 * 128 + 6 * 256 * 4);
+        PPV_ATTR(hipFuncSetAttribute((const void*)stem_dgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        PPV_ATTR(hipFuncSetAttribute((const void*)stem_dgrad_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 136 * 128 + 6 * 256 * 4));
         attr = true;
     }
     static const int strip_form = getenv("PPV_STEM_DGRAD_STRIP") ? atoi(getenv("PPV_STEM_DGRAD_STRIP")) : 1;

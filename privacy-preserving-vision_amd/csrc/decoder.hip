@@ -774,11 +774,11 @@ static int dec_enc_grad_launch(const float* part, const float* dmean, const floa
     if (!part || !dmean || !alpha || !dawe || !order || !out) return PPV_ERR_NULL;
     if (B < 1 || P < 1 || E % 256 || T < 1 || T > 128) return PPV_ERR_BAD_SIZE;
     const size_t lds = (size_t)T * (256 + 48) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dec_enc_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4);
-        (void)hipFuncSetAttribute((const void*)dec_enc_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4);
-        attr_set = true;
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)dec_enc_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4));
+        PPV_ATTR(hipFuncSetAttribute((const void*)dec_enc_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (256 + 48) * 4));
+        attr_once.done();
     }
     const dim3 grid(B, (P + 47) / 48, E / 256);
     if (out_bf16) dec_enc_grad_kernel<true><<<grid, 256, lds, stream>>>(part, dmean, alpha, dawe, order, gamma, out, B, P, E, T);
@@ -823,7 +823,7 @@ int ppv_decc_attend_fwd(const void* att1c, const void* feat, const float* hproj,
     const size_t lds = (size_t)(C + 1) * A * 2 + (size_t)(2 * A + 6 * Q + C) * 4;
     if (bt < 1 || A % 8 || E % 8 || A > 2048 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)decc_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
     ClassTables tb{cls_cells, cls_w, cls_mult, pix_class};
     decc_score_fwd_kernel<<<bt, 512, lds, stream>>>((const bf16_t*)att1c, hproj, ldh, wfull, tb, alpha_out, alq_out, beta_out, P, Q, C, A);
     dec_ctx_fwd_kernel<false><<<dim3(bt, (E + 255) / 256), 256, (C + 8 * 256) * sizeof(float), stream>>>(
@@ -846,7 +846,7 @@ int ppv_decc_attend_bwd(const void* att1c, const void* feat, const float* hproj,
     const size_t lds = (size_t)(C + 1) * A * 2 + (size_t)(4 * A + 7 * Q + 12 * C) * 4;
     if (bt < 1 || A % 8 || E % 8 || lds > 150 * 1024 || ldh < A + E) return PPV_ERR_BAD_SIZE;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)decc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)decc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
     const int PS = dec_slab(C);
     dec_ctx_bwd_kernel<<<dim3(bt, (C + PS - 1) / PS), 256, E * sizeof(float), stream>>>(
         (const bf16_t*)feat, dxh, ldx, x_off, hproj, ldh, A, awe_save, nullptr, dhproj, dawe_out, dfb, C, E, PS);

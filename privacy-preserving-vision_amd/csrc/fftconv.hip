@@ -253,11 +253,12 @@ static void launch_cols_mul_ic(const float2* S1, float2* S2, const float2* otfT,
                                int planes, hipStream_t stream);
 
 template <int R> static void cols_mul_lds_attr() {
-    static bool done = false;
-    if (!done) {
+    static PpvDevOnce once;                  // per device: the attribute is a per-device property
+    if (once.need()) {
         // (R = 16: only the IC geometry exists -- at most N / 2 = 512 rows of data; the tile shares the CU's 160 KB with 78 KB of static LDS)
+        // (a failed call surfaces as the launch's own error: ppv_last_error() of the caller)
         (void)hipFuncSetAttribute((const void*)cols_mul_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (R >= 16 ? 32 : 64) * R * 17 * (int)sizeof(float2));
-        done = true;
+        once.done();
     }
 }
 

@@ -737,10 +737,10 @@ int ppv_gemm_bf16x3_tn(const float* a, long lda, const float* b, long ldb, float
     if (!a || !b || !out) return PPV_ERR_NULL;
     if (M < 1 || N < 1 || K < 1 || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
     constexpr int lds = 2 * 4 * X3_IMG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)gemm_bf16x3_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_once.done();
     }
     const dim3 grid((unsigned)((N + X3_BN - 1) / X3_BN), (unsigned)ksplit, (unsigned)((M + X3_BM - 1) / X3_BM));
     if (ksplit == 1) {
@@ -774,10 +774,10 @@ int ppv_gemm_bf16x3_nt(const float* x, long ldx, const float* W, long ldw, const
     if (!x || !W || !out) return PPV_ERR_NULL;
     if (M < 1 || N < 1 || K < 4 || K % 4 || ldx % 4 || ldw % 4 || ((size_t)x % 16) || ((size_t)W % 16) || ksplit < 1 || ksplit > 64) return PPV_ERR_BAD_SIZE;
     constexpr int lds = 2 * 4 * X3N_IMG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)gemm_bf16x3_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_once.done();
     }
     const dim3 grid((unsigned)((N + X3_BN - 1) / X3_BN), (unsigned)ksplit, (unsigned)((M + X3_BM - 1) / X3_BM));
     if (ksplit == 1) {

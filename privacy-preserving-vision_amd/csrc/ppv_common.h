@@ -15,6 +15,27 @@ static inline int ppv_last_error() {
     return e == hipSuccess ? PPV_OK : -(int)e;
 }
 
+// Once-per-DEVICE guard for function attributes (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property: a process-wide
+// flag would leave a second GPU of the same process without it).  Racing threads may both set the attribute: idempotent.
+struct PpvDevOnce {
+    unsigned done_mask = 0;
+    bool need() const {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return !(__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & (1u << (d & 31)));
+    }
+    void done() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        __atomic_fetch_or(&done_mask, 1u << (d & 31), __ATOMIC_RELEASE);
+    }
+};
+// a failed attribute call is a status code of the entry point, not a silently failing launch later
+#define PPV_ATTR(call)                         \
+    do {                                       \
+        if (hipError_t e_ = (call)) return -(int)e_; \
+    } while (0)
+
 extern "C" {
 // exp(-2 pi i t / N) tables (float2 / double2) resident on the current device; created once per (device, N)
 // under a mutex with a blocking copy -- call ppv_init() before stream capture.

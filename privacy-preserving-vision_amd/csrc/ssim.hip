@@ -161,8 +161,8 @@ int ppv_ssim_bwd(const float* img1, const float* img2, const float* gscale, floa
     ppv::SsimWin w;
     for (int k = 0; k < 11; ++k) w.w[k] = win[k];
     constexpr int lds = (2 * 52 * 53 + 5 * 52 * 42 + 3 * 42 * 43 + 3 * 42 * 32) * 4;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ppv::ssim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) { PPV_ATTR(hipFuncSetAttribute((const void*)ppv::ssim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_once.done(); }
     ppv::ssim_bwd_kernel<<<dim3((W + 31) / 32, (H + 31) / 32, B * C), 256, lds, stream>>>(img1, img2, gscale, d_img2, C, H, W, w);
     return ppv_last_error();
 }

@@ -484,12 +484,9 @@ class _TrunkFn(torch.autograd.Function):
         if not ctx.train:
             # eval-mode BatchNorm (running statistics are constants; outside the reference's use -- validate() runs under no_grad,
             # train.py:355-451 -- but a saliency / attack pass through the frozen trunk needs it): the same launches with an infinite
-            # sample count, which removes the batch-mean terms of the train-mode formula (convops.EVAL_BN)
-            co.EVAL_BN = True
-            try:
+            # sample count, which removes the batch-mean terms of the train-mode formula (convops.eval_bn: thread-local)
+            with co.eval_bn():
                 return _TrunkFn._backward(ctx, g_out, g_cells)
-            finally:
-                co.EVAL_BN = False
         return _TrunkFn._backward(ctx, g_out, g_cells)
 
     @staticmethod
@@ -721,7 +718,7 @@ class _TrunkFn(torch.autograd.Function):
         # configuration: single process, no taps / per-class timing, default weight-gradient schedule.
         fast_bwd = (_os.environ.get("PPV_BLOCK_EXEC", "1") != "0" and (sync is None or (bucketed and side is not None)) and taps is None
                     and co.PROFILE is None and not group_min and wsched == [0, 2, 4] and red_level == 3
-                    and ctx.train)       # (eval-mode BatchNorm backward goes through convops.EVAL_BN: the per-kernel calls)
+                    and ctx.train)       # (eval-mode BatchNorm backward goes through convops.eval_bn(): the per-kernel calls)
         if fast_bwd:
             bwa = _lib.BottleneckBwd()
             bwa.zero_page = co.zero_page(dev0).data_ptr()

@@ -26,8 +26,22 @@ class Adam(torch.optim.Optimizer):
                                       foreach=None, capturable=False, differentiable=False, fused=None))
         self._tables = {}                      # group index -> (key of data pointers, device descriptor table, total blocks)
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)    # new exp_avg / exp_avg_sq tensors: every cached descriptor table is stale
+        self._tables = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
+
     def _table(self, gi, ps):
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        # the key holds EVERY pointer the records hold (parameter, gradient, both moments): a reloaded state or a re-allocated gradient
+        # rebuilds the table instead of updating freed buffers
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
@@ -68,8 +82,11 @@ class Adam(torch.optim.Optimizer):
             for p in ps:
                 by_step.setdefault(float(self.state[p]["step"]), []).append(p)
             b1, b2 = group["betas"]
-            for t, sub in sorted(by_step.items()):
-                desc, blocks = self._table((gi, t) if len(by_step) > 1 else gi, sub)
+            if len(by_step) > 1:               # split case: tables keyed by (group, slot), slots reused every step -> no growth with t
+                for k in [k for k in self._tables if isinstance(k, tuple) and k[0] == gi and k[1] >= len(by_step)]:
+                    del self._tables[k]
+            for slot, (t, sub) in enumerate(sorted(by_step.items())):
+                desc, blocks = self._table((gi, slot) if len(by_step) > 1 else gi, sub)
                 n = t + 1.0
                 _lib.check(L.ppv_adam_multi(desc.data_ptr(), len(sub), blocks, group["lr"], b1, b2, group["eps"], group["weight_decay"],
                                             1.0 - b1 ** n, 1.0 - b2 ** n, _lib.stream_ptr()), "ppv_adam_multi")

@@ -69,3 +69,49 @@ def test_adam_refuses_what_it_does_not_implement():
     p64[0].grad = torch.zeros(4, device="cuda", dtype=torch.float64)
     with pytest.raises(NotImplementedError):
         o.step()
+
+
+def test_adam_follows_a_reloaded_state_and_does_not_grow_its_tables():
+    """the descriptor table holds the moment pointers too -- after load_state_dict() on an optimiser that has already stepped
+    the loaded moments (new tensors) must be the ones that advance; parameters with different step counts reuse their table slots."""
+    from ppv_amd.optim import Adam
+    sizes = [(300,), (64, 16, 3, 3), (4099,)]
+    ref = [torch.nn.Parameter(t.clone()) for t in _make(0, sizes)]
+    got = [torch.nn.Parameter(t.cuda()) for t in _make(0, sizes)]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, foreach=False)
+    o_got = Adam(got, lr=1e-2)
+
+    def both(step, skip=None):
+        for i, (p, q, g) in enumerate(zip(ref, got, _make(200 + step, sizes))):
+            p.grad, q.grad = (None, None) if i == skip else (g.clone(), g.cuda())
+        o_ref.step()
+        o_got.step()
+
+    both(0)
+    both(1)
+    snap_ref, snap_got = {k: v for k, v in o_ref.state_dict().items()}, o_got.state_dict()
+    import copy
+    snap_ref, snap_got = copy.deepcopy(snap_ref), copy.deepcopy(snap_got)
+    w_ref, w_got = [p.detach().clone() for p in ref], [q.detach().clone() for q in got]
+    both(2)
+    both(3)
+    # roll back: parameters and optimiser state of step 2, then step again with the same gradients
+    with torch.no_grad():
+        for p, w in zip(ref, w_ref):
+            p.copy_(w)
+        for q, w in zip(got, w_got):
+            q.copy_(w)
+    o_ref.load_state_dict(snap_ref)
+    o_got.load_state_dict(snap_got)
+    both(2)
+    both(3, skip=1)                                                              # split step counts from here on
+    for s in range(4, 12):
+        both(s)
+    torch.cuda.synchronize()
+    for p, q in zip(ref, got):
+        assert torch.allclose(p.detach(), q.detach().cpu(), rtol=2e-5, atol=2e-6)
+        a, b = o_ref.state[p], o_got.state[q]
+        assert float(a["step"]) == float(b["step"])
+        assert torch.allclose(a["exp_avg"], b["exp_avg"].cpu(), rtol=2e-5, atol=1e-7)
+        assert torch.allclose(a["exp_avg_sq"], b["exp_avg_sq"].cpu(), rtol=2e-5, atol=1e-9)
+    assert len(o_got._tables) <= 2                                               # (group, slot) keys: bounded, not one per step count

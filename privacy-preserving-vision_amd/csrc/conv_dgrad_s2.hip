@@ -227,7 +227,7 @@ int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* st
     gc.Ho = g.Hs; gc.Wo = g.Ws; gc.M = (long)g.B * g.Hs * g.Ws; gc.sh = 0; gc.flat = 0; gc.chunked = 0;
     const int tiles_n = g.N / S2_BN, tiles_m = (int)((gc.M + S2_BM - 1) / S2_BM), tpc = tiles_m * tiles_n;
     static const int bk = getenv("PPV_S2_BK") ? atoi(getenv("PPV_S2_BK")) : 32;                    // A/B: 64 = one 144-KB workgroup per CU
-    auto go = [&](auto BK_) {
+    auto go = [&](auto BK_) -> int {
         constexpr int BK = decltype(BK_)::value, LDS = s2_lds<BK>();
         static PpvDevOnce attr_once;
         if (attr_once.need()) {
@@ -239,10 +239,9 @@ int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* st
             conv_dgrad_s2_kernel<true, BK><<<4 * tpc, 512, LDS, stream>>>(X, Wt, (bf16_t*)out, stat_part, zero_page, gc, tab, tpc, tiles_n, stat_rows, red_x, red_coef);
         else
             conv_dgrad_s2_kernel<false, BK><<<4 * tpc, 512, LDS, stream>>>(X, Wt, (bf16_t*)out, nullptr, zero_page, gc, tab, tpc, tiles_n, stat_rows, nullptr, nullptr);
+        return ppv_last_error();
     };
-    if (bk == 64) go(std::integral_constant<int, 64>{});
-    else go(std::integral_constant<int, 32>{});
-    return ppv_last_error();
+    return bk == 64 ? go(std::integral_constant<int, 64>{}) : go(std::integral_constant<int, 32>{});
 }
 
 }  // namespace ppv

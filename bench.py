@@ -216,6 +216,9 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         caplens = caplens_host.to(device)                                         # train.py:263
 
     opt_stream = torch.cuda.Stream(device=device) if (os.environ.get("PPV_OPT_OVERLAP", "1") != "0" and not graph) else None
+    fused_mse = not ssim_loss and os.environ.get("PPV_BENCH_TORCH_MSE", "0") == "0"      # PPV_BENCH_TORCH_MSE=1: the three torch ops (A/B)
+    if fused_mse:
+        from ppv_amd.losses import camera_mse_tap
 
     def step():
         nonlocal imgs
@@ -226,6 +229,9 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         sensor, psf, coeffs, loss_psf = camera(imgs, None, "3")
         if opt_stream is not None:             # the encoder's (and decoder's) Adam of the previous step ran beside the camera forward
             torch.cuda.current_stream().wait_stream(opt_stream)
+        loss_cam = None
+        if fused_mse:                          # train.py:284-288 on ppv_amd.losses: the encoder reads the sensor THROUGH the loss node, whose
+            sensor, loss_cam = camera_mse_tap(imgs, sensor)     # backward adds the encoder's gradient to its own in one pass
         enc_out = encoder(sensor)
         if decoder is not None:                                                   # train.py:274-282
             scores, caps_sorted, dec_len, alphas, _ = decoder(enc_out, caps, caplens)
@@ -239,7 +245,7 @@ def make_step(camera, encoder, batch, device, sync, decoder=None, ssim_loss=Fals
         if ssim_loss:                                                             # camera_loss = 'SSIM', train.py:172-173
             from ppv_amd.ssim import ssim
             loss_cam = 1 - ssim(imgs, sensor)
-        else:
+        elif loss_cam is None:
             loss_cam = 1 - torch.nn.functional.mse_loss(imgs, sensor)
         loss = 0.4 * loss_head + 6 * loss_cam + 30 * loss_psf
         opt_enc.zero_grad(set_to_none=True)

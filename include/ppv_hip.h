@@ -106,6 +106,10 @@ int ppv_ic_psf_state_offsets(int RR, int P, int K, size_t* off_h, size_t* off_F0
 /* 1: the Fresnel transforms and the saved fields F0 / U are c64 (default since round 5: the reference feeds its transform c64-valued
  * fields, Utils.py:80-85, so c64 adds ~5e-7 against the 1e-3 tolerance), 0: c128 (PPV_PSF_F32=0) */
 int ppv_ic_psf_fields_f32(void);
+/* 1 / 0: c64 / c128 Fresnel fields from now on (-1: the environment variable PPV_PSF_F32 decides again); returns the previous setting.
+ * The state layout depends on it: choose BEFORE ppv_ic_psf_state_bytes / ppv_ic_psf_state_init of a state and keep it while that state
+ * lives (a module-level choice; the reference's fields are complex128 by type promotion, Image_Caption/Camera/Utils.py:328-378). */
+int ppv_ic_psf_set_fields_f32(int on);
 
 /* ---- Zernike basis (poppy.zernike.zernike_basis, IC Utils.py:75-77 / FD Utils.py:60-63) ---------------------
  * terms: K device records {int n, m, off, cnt; double norm}; coefs: device doubles of the radial polynomials. */
@@ -125,6 +129,20 @@ int ppv_zernike_max_order(void);
 int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, const void* addend, const void* mask_bits,
                   const void* zero_page, int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a,
                   int off, int div, int out_f32, int stat_rows, ppv_stream_t stream);
+/* conv2 of an identity bottleneck with bn1 + ReLU applied INSIDE the convolution (round 6: the LDS-resident halo tile of conv_halo.hip is
+ * activated once per 64-channel chunk; the element-wise launch between conv1 and conv2 disappears).  Train-mode BatchNorm of
+ * Image_Caption/train.py:245 on the torchvision Bottleneck behind Image_Caption/models.py:17-21.  x_raw [B,H,W,C] bf16 = conv1's raw
+ * output, sums [T][2][C] its partial sums (the stat_part of that ppv_conv_gemm call), count = B*H*W.  Leaves what ppv_bn_act_fold_rows
+ * left: coef [4][C] (scale, shift, mean, invstd), running statistics updated (run_mean / run_var may be null), y_act [B,H,W,C] bf16 =
+ * relu(bn(x_raw)) (the operand of conv2's weight gradient; null: not written); out [B,H,W,N] bf16 = conv3x3(y_act), stride 1, pad 1,
+ * wt [N][3][3][C], with its own statistics in stat_part [stat_rows][2][N] (PRE-ZEROED).  ppv_conv3x3_bnin_supported: 1 where this form
+ * runs (16- / 32-wide maps, N % 128 == 0, C % 64 == 0, C <= 512, launches that fill the chip): callers keep the two-launch form
+ * elsewhere (ppv_bottleneck_fwd uses it under PPV_BNIN=1). */
+int ppv_conv3x3_bnin_supported(int B, int H, int W, int C, int N);
+int ppv_conv3x3_bnin(const void* x_raw, const float* sums, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                     float* run_var, float momentum, float eps, float* coef, void* y_act, const void* wt, void* out, float* stat_part,
+                     int stat_rows, const void* zero_page, int B, int H, int W, int C, int N, ppv_stream_t stream);
+
 /* data-gradient launch that also takes the sums the following BatchNorm backward needs (torch's batch_norm_backward reduce):
  * red_part [red_rows][2][N] f32, PRE-ZEROED, receives sum g and sum g * red_x per column, g = the tensor as stored (addend
  * added, rounded to bf16, masked), red_x [M][N] bf16 = the raw convolution output that BatchNorm normalised.  bf16 output,
@@ -421,6 +439,18 @@ int ppv_alt_corr_bwd(const float* fmap1, const float* fmap2, const float* coords
 int ppv_ssim_fwd(const float* img1, const float* img2, double* sums, const float* win, int B, int C, int H, int W, ppv_stream_t stream);
 int ppv_ssim_bwd(const float* img1, const float* img2, const float* gscale, float* d_img2, const float* win, int B, int C, int H, int W,
                  ppv_stream_t stream);
+
+/* ---- camera MSE loss of the harness, Image_Caption/train.py:170-171,284-288 (`loss_cam = 1 - nn.MSELoss()(imgs, sensor)`), fused.
+ * ppv_mse_fwd: out[0] = mean((a - b)^2) in one pass, deterministic (per-workgroup f64 partials, summed in index order by the last
+ * workgroup); `workspace` = ppv_mse_workspace_bytes() bytes, 16-byte aligned, ZEROED ONCE by the caller at allocation (the kernel
+ * leaves it ready for the next call).  ppv_mse_bwd: g_b = g_in + k (b - a), k = coef * gscalar[0] (gscalar: DEVICE scalar, the
+ * gradient autograd hands to the loss; coef = 2 / n for mse, -2 / n for 1 - mse); g_in = the gradient that reaches b through its
+ * other consumer (null: none), i.e. autograd's accumulation of the two gradients happens in the same pass; g_a (null: not wanted)
+ * = -k (b - a).  a, b, g_* f32, n elements, 16-byte aligned. */
+size_t ppv_mse_workspace_bytes(void);
+int ppv_mse_fwd(const float* a, const float* b, long n, void* workspace, float* out, ppv_stream_t stream);
+int ppv_mse_bwd(const float* g_in, const float* a, const float* b, const float* gscalar, float coef, float* g_b, float* g_a, long n,
+                ppv_stream_t stream);
 
 /* ---- soft-attention LSTM caption decoder, Image_Caption/models.py:57-218.  encoder_att is hoisted out
  * of the time loop (models.py:83 recomputes it every step) and runs through ppv_conv_gemm; these are the per-step kernels.

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -45,6 +45,7 @@ PROTOTYPES = {
     "ppv_ic_psf_symmetric": (_I, [_P, _I, _I, _I, _P]),
     "ppv_ic_psf_state_offsets": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "ppv_ic_psf_fields_f32": (_I, []),
+    "ppv_ic_psf_set_fields_f32": (_I, [_I]),
     "ppv_zernike_basis": (_I, [_P, _P, _P, _I, _I, _c.c_double, _c.c_double, _P]),
     "ppv_zernike_max_order": (_I, []),
     "ppv_fftconv_fd_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -65,6 +66,11 @@ PROTOTYPES = {
     "ppv_fan_head": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_ssim_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_ssim_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_conv3x3_bnin_supported": (_I, [_I, _I, _I, _I, _I]),
+    "ppv_conv3x3_bnin": (_I, [_P, _P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_mse_workspace_bytes": (_Z, []),
+    "ppv_mse_fwd": (_I, [_P, _P, _L, _P, _P, _P]),
+    "ppv_mse_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _P]),
     "ppv_dec_prepare": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ppv_dec_attend_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ppv_dec_attend_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

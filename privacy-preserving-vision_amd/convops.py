@@ -393,6 +393,27 @@ def bn_act_fold(x, sums, count, bn, momentum, res=None, relu=True, want_bits=Fal
     return y, bits, coef
 
 
+def conv3x3_bnin_supported(B, H, W, C, N):
+    return bool(L().ppv_conv3x3_bnin_supported(B, H, W, C, N))
+
+
+def conv3x3_bnin(x_raw, sums, count, bn, momentum, wt, stat_part=None, want_act=True):
+    """conv3x3(relu(bn(x_raw))) with the train-mode BatchNorm `bn` + ReLU applied INSIDE the convolution (csrc/conv_halo.hip BNIN, round 6):
+    x_raw [B,H,W,C] bf16 raw output of the previous convolution, sums [T,2,C] its partial sums, wt [N,3,3,C] bf16.
+    -> (out [B,H,W,N] bf16 raw, y_act [B,H,W,C] bf16 or None, coef [4,C]); running statistics updated in place; stat_part [rows,2,N] PRE-ZEROED."""
+    B, H, W, C = x_raw.shape
+    N = wt.shape[0]
+    out = torch.empty((B, H, W, N), dtype=BF16, device=x_raw.device)
+    y = torch.empty_like(x_raw) if want_act else None
+    coef = torch.empty((4, C), dtype=F32, device=x_raw.device)
+    _timed("conv3x3_bnin", 2.0 * B * H * W * N * 9 * C, lambda: check(
+        L().ppv_conv3x3_bnin(ptr(x_raw), ptr(sums), sums.shape[0], float(count), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                             ptr(bn.running_mean), ptr(bn.running_var), momentum, bn.eps, ptr(coef), ptr(y), ptr(wt), ptr(out), ptr(stat_part),
+                             0 if stat_part is None else stat_part.shape[0], ptr(zero_page(x_raw.device)), B, H, W, C, N, stream_ptr()),
+        "ppv_conv3x3_bnin"), nbytes=x_raw.numel() * 2.0 * (2 if want_act else 1) + wt.numel() * 2.0 + out.numel() * 2.0)
+    return out, y, coef
+
+
 def bn_act(x, coef, res=None, coef_res=None, relu=True, res_broadcast=False, want_bits=False):
     """y = act(x*scale + shift + res); res_broadcast: res holds one image's worth of elements shared by the batch.
     want_bits: also return the (y > 0) bit mask (uint8, numel / 8 bytes) that conv_dgrad(relu_bits=...) consumes."""

@@ -4,8 +4,11 @@
 // the Python step crosses ctypes ~1000 times (15 ms per 22-ms step on a fast host, 23 ms on a slow one: the step then runs at the
 // speed of the interpreter); per bottleneck that is 6 crossings forward and ~12 backward, here one each.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ppv_common.h"
 #include "ppv_hip.h"
+
+namespace ppv { void conv_set_output_nt_once(int nt); }       // conv_gemm.hip
 
 extern "C" {
 
@@ -20,11 +23,24 @@ int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, hipStream_t stream) {
     const long M1 = (long)B * H * W, M2 = (long)B * H2 * W2;
     int e;
     // conv1 1x1 -> bn1 + ReLU
+    // PPV_BNIN=1: bn1 + ReLU inside conv2's halo kernel.  Opt-in: faster alone (45 against 52 us at the layer-3 shape, tools/bench_bnin.py)
+    // but not in the step (profiles/r06_bnin_ab.json)
+    static const int bnin_on = getenv("PPV_BNIN") ? atoi(getenv("PPV_BNIN")) : 0;
+    const bool bnin = bnin_on && st == 1 && ppv_conv3x3_bnin_supported(B, H, W, P, P);
+    static const int x1_temporal = getenv("PPV_BNIN_X1T") ? atoi(getenv("PPV_BNIN_X1T")) : 1;     // A/B: conv1's raw output kept in the L2 for the BNIN kernel
+    if (bnin && x1_temporal) ppv::conv_set_output_nt_once(0);
     if ((e = ppv_conv_gemm(a->xin, a->w1, a->x1, a->stats1, nullptr, nullptr, a->zero_page, B, H, W, Cin, H, W, P, 1, 1, 1, 0, 1, 0, a->T1, stream))) return e;
-    if ((e = ppv_bn_act_fold_rows(a->x1, a->stats1, a->T1, (double)M1, a->g1, a->b1, a->rm1, a->rv1, a->mom1, a->eps1, a->coef1, nullptr, a->y1,
-                                  nullptr, M1 * P, P, 0, 1, stream))) return e;
-    // conv2 3x3 (stride on the 3x3: torchvision v1.5) -> bn2 + ReLU
-    if ((e = ppv_conv_gemm(a->y1, a->w2, a->x2, a->stats2, nullptr, nullptr, a->zero_page, B, H, W, P, H2, W2, P, 3, 3, st, -1, 1, 0, a->T2, stream))) return e;
+    // bn1 + ReLU: inside conv2 where its halo form runs (round 6: the activation is applied to the LDS-resident input tile; y1 is still
+    // written, from that kernel, for conv2's weight gradient), a launch of its own elsewhere
+    if (bnin) {
+        if ((e = ppv_conv3x3_bnin(a->x1, a->stats1, a->T1, (double)M1, a->g1, a->b1, a->rm1, a->rv1, a->mom1, a->eps1, a->coef1, a->y1, a->w2, a->x2,
+                                  a->stats2, a->T2, a->zero_page, B, H, W, P, P, stream))) return e;
+    } else {
+        if ((e = ppv_bn_act_fold_rows(a->x1, a->stats1, a->T1, (double)M1, a->g1, a->b1, a->rm1, a->rv1, a->mom1, a->eps1, a->coef1, nullptr, a->y1,
+                                      nullptr, M1 * P, P, 0, 1, stream))) return e;
+        // conv2 3x3 (stride on the 3x3: torchvision v1.5) -> bn2 + ReLU
+        if ((e = ppv_conv_gemm(a->y1, a->w2, a->x2, a->stats2, nullptr, nullptr, a->zero_page, B, H, W, P, H2, W2, P, 3, 3, st, -1, 1, 0, a->T2, stream))) return e;
+    }
     if ((e = ppv_bn_act_fold_rows(a->x2, a->stats2, a->T2, (double)M2, a->g2, a->b2, a->rm2, a->rv2, a->mom2, a->eps2, a->coef2, nullptr, a->y2,
                                   nullptr, M2 * P, P, 0, 1, stream))) return e;
     // conv3 1x1 -> bn3 + identity + ReLU (+ the (y > 0) bit mask the backward pass reads)

@@ -170,6 +170,9 @@ int conv3x3_halo_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* sta
 // The next ppv_conv_gemm / ppv_conv_gemm_red call of this thread takes its addend in the compact form of ConvGeom::add_lw (internal: the
 // whole-trunk executor; the launch fails if it does not land on conv_stream.hip -- ask conv_addend_compact_supported first).
 void conv_set_addend_compact(bool on);
+// The next ppv_conv_gemm call of this thread stores its bf16 output temporally (0) / non-temporally (1) whatever PPV_NT_STORE says: an
+// output whose consumer is the very next launch AND reads it through a latency-bound path (the BNIN halo kernel) wants it in the L2.
+void conv_set_output_nt_once(int nt);
 bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N);
 // conv_dgrad_s2.hip: data gradient of the stride-2 3x3 / 1x1 convolutions as four parity-class problems (bf16, no addend, no bit mask).
 bool conv_dgrad_s2_supported(const ConvGeom& g, int Cs, int div);
@@ -177,6 +180,20 @@ int conv_dgrad_s2_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* st
                          const float* red_coef, const ConvGeom& g, int stat_rows, hipStream_t stream);
 // ... its 64-column tile on 8-wide maps (layer 4: four images per tile) ...
 bool conv3x3_halo_n64_supported(const ConvGeom& g, int Cs, int div);
+// BNIN (conv_halo.hip, round 6): train-mode BatchNorm + ReLU of the convolution's INPUT applied to the LDS-resident halo tile
+struct HaloBn {
+    const float* sums;     // [T][2][Cs] partial sums of the raw input
+    int T;
+    double inv_count, unbias;
+    const float *gamma, *beta;
+    float *run_mean, *run_var;
+    float momentum, eps;
+    float* coef;           // [4][Cs] out
+    bf16_t* y_act;         // [M][Cs] out (null: not wanted)
+};
+bool conv3x3_halo_bnin_supported(const ConvGeom& g, int Cs);
+int conv3x3_halo_bnin_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* zero_page, const ConvGeom& g,
+                             int stat_rows, const HaloBn& bn, hipStream_t stream);
 int conv3x3_halo_n64_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* addend,
                             const unsigned char* mask_bits, const bf16_t* zero_page, const bf16_t* red_x, const float* red_coef,
                             const ConvGeom& g, int stat_rows, hipStream_t stream);

@@ -474,6 +474,8 @@ namespace ppv { __device__ unsigned long long* g_stamps = nullptr; }
 
 namespace ppv {
 void conv_set_addend_compact(bool on) { g_addend_compact = on; }
+static thread_local int g_nt_once = -1;                       // conv_set_output_nt_once: one-shot, consumed by the next conv_gemm_impl
+void conv_set_output_nt_once(int nt) { g_nt_once = nt; }
 bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N) {
     static const int on = getenv("PPV_ADDEND_COMPACT") ? atoi(getenv("PPV_ADDEND_COMPACT")) : 1;   // A/B: 0 = dense shortcut gradient
     if (!on || g_conv_variant != 0 || H < 2 || W < 2 || (H & (H - 1)) || (W & (W - 1))) return false;
@@ -509,6 +511,8 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
                           int out_f32, int stat_rows, hipStream_t stream) {
     const bool compact = g_addend_compact;                   // one-shot request of conv_set_addend_compact, consumed whatever happens below
     g_addend_compact = false;
+    const int nt_once = g_nt_once;
+    g_nt_once = -1;
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
@@ -522,7 +526,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.flat = (R == 1 && S == 1 && a == 1 && off == 0 && g.offw == 0 && div == 1 && Hs == Ho && Ws == Wo) ? 1 : 0;
     g.chunked = 0;
     static const int nt_store = getenv("PPV_NT_STORE") ? atoi(getenv("PPV_NT_STORE")) : 1;         // A/B: 0 = ordinary output stores
-    g.nt = nt_store;
+    g.nt = nt_once >= 0 ? nt_once : nt_store;
     static const int conv_debug = getenv("PPV_CONV_DEBUG") ? atoi(getenv("PPV_CONV_DEBUG")) : 0;   // 1 = loads only, 2 = compute only (wrong results: timing experiments)
     if (conv_debug > 0) g.chunked = 1 + conv_debug;
     if (g_conv_variant & 0x1000) {            // layout A/B (tools/bench_layout_ab.py): flat launches on the BK = 64 tiles read a chunked source
@@ -647,6 +651,35 @@ int ppv_conv_gemm(const void* X, const void* Wt, void* out, float* stat_part, co
 // red_coef (may be null; not together with addend): that BatchNorm's [scale | shift] rows (ppv_bn_finalize's coef) when it is
 // followed by a ReLU without residual: lanes with x * scale + shift <= 0 are stored as 0 and left out of the sums, so the
 // BatchNorm backward runs with relu = 0.  bf16 output; N % 128 == 0, or N % 64 == 0 with M >= 128 Ki rows (the 128 x 64 tile).
+// conv2 of an identity bottleneck with bn1 + ReLU in its operand path (conv_halo.hip BNIN): x_raw = conv1's raw output [B,H,W,C] bf16,
+// sums [T][2][C] its partial sums, count = B*H*W; leaves coef [4][C] + running statistics (as ppv_bn_act_fold_rows), y_act = relu(bn(x_raw))
+// (may be null), out [B,H,W,N] = conv3x3(y_act) raw and its statistics in stat_part [stat_rows][2][N] (PRE-ZEROED).
+int ppv_conv3x3_bnin_supported(int B, int H, int W, int C, int N) {
+    ConvGeom g;
+    g.B = B; g.Hs = H; g.Ws = W; g.Cs = C; g.Ho = H; g.Wo = W; g.N = N; g.R = 3; g.S = 3; g.a = 1; g.off = -1; g.offw = -1; g.sh = 0;
+    g.M = (long)B * H * W; g.flat = 0; g.chunked = 0;
+    return (g_conv_variant == 0 && C % 64 == 0 && N % 128 == 0 && conv3x3_halo_bnin_supported(g, C)) ? 1 : 0;
+}
+
+int ppv_conv3x3_bnin(const void* x_raw, const float* sums, int T, double count, const float* gamma, const float* beta, float* run_mean,
+                     float* run_var, float momentum, float eps, float* coef, void* y_act, const void* wt, void* out, float* stat_part,
+                     int stat_rows, const void* zero_page, int B, int H, int W, int C, int N, hipStream_t stream) {
+    if (!x_raw || !sums || !gamma || !beta || !coef || !wt || !out || !zero_page) return PPV_ERR_NULL;
+    if (T < 1 || count < 1 || (stat_part && stat_rows < 1) || C % 64 || N % 128) return PPV_ERR_BAD_SIZE;
+    ConvGeom g;
+    g.B = B; g.Hs = H; g.Ws = W; g.Cs = C; g.Ho = H; g.Wo = W; g.N = N; g.R = 3; g.S = 3; g.a = 1; g.off = -1; g.offw = -1; g.sh = 0;
+    g.M = (long)B * H * W; g.flat = 0; g.chunked = 0;
+    static const int nt_store = getenv("PPV_NT_STORE") ? atoi(getenv("PPV_NT_STORE")) : 1;
+    g.nt = nt_store;
+    if (!conv3x3_halo_bnin_supported(g, C)) return PPV_ERR_BAD_SIZE;
+    HaloBn bn;
+    bn.sums = sums; bn.T = T; bn.inv_count = 1.0 / count; bn.unbias = count > 1 ? count / (count - 1.0) : 1.0;
+    bn.gamma = gamma; bn.beta = beta; bn.run_mean = run_mean; bn.run_var = run_mean ? run_var : nullptr; bn.momentum = momentum; bn.eps = eps;
+    bn.coef = coef; bn.y_act = (bf16_t*)y_act;
+    if (run_mean && !run_var) return PPV_ERR_NULL;
+    return conv3x3_halo_bnin_launch((const bf16_t*)x_raw, (const bf16_t*)wt, out, stat_part, (const bf16_t*)zero_page, g, stat_rows, bn, stream);
+}
+
 int ppv_conv_gemm_red(const void* X, const void* Wt, void* out, float* red_part, const void* red_x, const float* red_coef,
                       const void* addend, const void* mask_bits, const void* zero_page,
                       int B, int Hs, int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int a, int off, int div,

@@ -22,8 +22,15 @@
 #include <utility>
 #include "conv_common.h"
 #include "conv_tile_epilogue.h"
+#include "bn_coef.h"
 
 namespace ppv {
+
+// BNIN (round 6): the convolution's INPUT is the raw output of the previous convolution; train-mode BatchNorm + ReLU (coefficients folded
+// from that convolution's partial sums by every workgroup's prologue) is applied to the LDS-resident halo tile once per 64-channel
+// chunk, so the element-wise bn1 + ReLU launch between conv1 and conv2 of a bottleneck (read 2 B + write 2 B per element, one dispatch)
+// disappears.  Workgroup 0 publishes coef [4][C] and the running statistics (what ppv_bn_act_fold_rows did); the column-tile-0
+// workgroups write the activated tile back (y_act: the operand of conv2's weight gradient) from the registers that transform it.
 
 struct HaloGeom {
     int H, W, TH, IMGS;      // image rows / columns, tile rows per image, images per tile (IMGS * TH * W == 256)
@@ -52,14 +59,32 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-unifo
     else if (n == 1) wait_vmcnt_le<1>();
     else wait_vmcnt_le<0>();
 }
+// the BNIN form also has up to MAXS write-back stores in flight (stores and loads retire through the same in-order counter)
+__device__ __forceinline__ void wait_vmcnt_dyn_wide(int n) {  // n is wave-uniform, any value >= 0 (larger values wait for less)
+    switch (n < 11 ? n : 11) {
+        case 0: wait_vmcnt_le<0>(); break;
+        case 1: wait_vmcnt_le<1>(); break;
+        case 2: wait_vmcnt_le<2>(); break;
+        case 3: wait_vmcnt_le<3>(); break;
+        case 4: wait_vmcnt_le<4>(); break;
+        case 5: wait_vmcnt_le<5>(); break;
+        case 6: wait_vmcnt_le<6>(); break;
+        case 7: wait_vmcnt_le<7>(); break;
+        case 8: wait_vmcnt_le<8>(); break;
+        case 9: wait_vmcnt_le<9>(); break;
+        case 10: wait_vmcnt_le<10>(); break;
+        default: wait_vmcnt_le<11>(); break;
+    }
+}
 
-template <bool RED, int HL_BN>
+template <bool RED, int HL_BN, bool BNIN = false>
 __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                 void* __restrict__ Out, float* __restrict__ stat_part,
                                                                 const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                 const bf16_t* __restrict__ zero_page, ConvGeom g, HaloGeom hg,
                                                                 int stat_rows, const bf16_t* __restrict__ red_x,
-                                                                const float* __restrict__ red_coef) {
+                                                                const float* __restrict__ red_coef, HaloBn bn = HaloBn{}) {
+    static_assert(!(BNIN && RED), "BNIN is a forward form");
     using Cfg = HaloCfg<HL_BN>;
     constexpr int MI = Cfg::MI, NI = Cfg::NI, WN = Cfg::WN, WROWS = MI * 16, WCOLS = 64, WI = Cfg::WI;
     constexpr int HL_HALO_BYTES = Cfg::HALO_BYTES, HL_WSTAGE = Cfg::WSTAGE, HL_LDS = Cfg::LDS;
@@ -86,6 +111,7 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     long h_off[MAXS];
     int h_inc[MAXS];
     const int img_px = (hg.TH + 2) * hg.pitch;
+    unsigned bn_ok = 0, bn_wb = 0, bn_hx7 = 0;              // BNIN, per slice t: pixel inside the image / inside THIS tile's rows / halo column & 7
 #pragma unroll
     for (int t = 0; t < MAXS; ++t) {
         const int hp = (t * 8 + wave) * 8 + rl;
@@ -96,6 +122,11 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
         const int gch = p8 ^ (hx & 7);
         h_off[t] = (ok ? ((long)(b0 + img) * HW + (long)y * hg.W + x) * g.Cs * 2 : zdelta) + gch * 16;
         h_inc[t] = ok ? HL_BK * 2 : 0;
+        if constexpr (BNIN) {
+            bn_ok |= (ok ? 1u : 0u) << t;
+            bn_wb |= ((ok && hy >= 1 && hy <= hg.TH) ? 1u : 0u) << t;
+            bn_hx7 |= (unsigned)(hx & 7) << (3 * t);
+        }
     }
     auto issue_halo_slice = [&](int t, int buf) __attribute__((always_inline)) {       // t < hg.hpw, t * 8 + wave < hg.hpi checked by caller
         GLDS16(reinterpret_cast<const char*>(X) + h_off[t], s_halo + buf * HL_HALO_BYTES + (t * 8 + wave) * 1024);
@@ -144,6 +175,23 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = g.Cs / HL_BK, T = nchunks * 9;
+    // ---- BNIN: scale / shift of every input channel, folded from the producer's partial sums (thread c <-> channel c; the arithmetic of
+    // bn_act_fold_wg_kernel, bn_coef.h), in a table behind the ring.  The sums are requested BEFORE the DMA prologue and consumed after it.
+    static_assert(!BNIN || HL_BN == 128, "BNIN: the 128-column form (halo slices all issued by tap 5)");
+    float* const s_sc = reinterpret_cast<float*>(smem + HL_LDS);
+    float* const s_sh = s_sc + g.Cs;
+    float bn_ps[4], bn_pq[4], bn_g = 0.f, bn_b = 0.f;
+    if constexpr (BNIN) {
+        const int cc = min(tid, g.Cs - 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long o = ((long)min(t, bn.T - 1) * 2) * g.Cs + cc;
+            bn_ps[t] = bn.sums[o];
+            bn_pq[t] = bn.sums[o + g.Cs];
+        }
+        bn_g = bn.gamma[cc];
+        bn_b = bn.beta[cc];
+    }
     // prologue: halo tile of chunk 0, weight slices of steps 0, 1, 2
 #pragma unroll
     for (int t = 0; t < MAXS; ++t)
@@ -151,8 +199,79 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
     issue_w(0, 0, 0);
     issue_w(1, 1, 0);
     issue_w(2, 2, 0);
+    if constexpr (BNIN) {
+        if (tid < g.Cs) {
+            double s_ = 0, q_ = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < bn.T) { s_ += (double)bn_ps[t]; q_ += (double)bn_pq[t]; }
+            for (int t = 4; t < bn.T; ++t) { s_ += (double)bn.sums[((long)t * 2) * g.Cs + tid]; q_ += (double)bn.sums[((long)t * 2 + 1) * g.Cs + tid]; }
+            const BnCoef k = bn_coef_pinned(s_, q_, bn.inv_count, bn.unbias, bn_g, bn_b, bn.eps);
+            s_sc[tid] = k.sc;
+            s_sh[tid] = k.sh;
+            if (blockIdx.x == 0) {                            // what ppv_bn_act_fold_rows left behind: coefficients for backward, running statistics
+                const int C = g.Cs;
+                bn.coef[tid] = k.sc; bn.coef[C + tid] = k.sh; bn.coef[2 * C + tid] = k.mean; bn.coef[3 * C + tid] = k.invstd;
+                if (bn.run_mean) {
+                    bn.run_mean[tid] = (1.f - bn.momentum) * bn.run_mean[tid] + bn.momentum * k.mean;
+                    bn.run_var[tid] = (1.f - bn.momentum) * bn.run_var[tid] + bn.momentum * k.var_unbiased;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is written before the barrier below publishes it
+        if (blockIdx.x == 0) wait_vmcnt_le<0>();              // (workgroup 0's coefficient stores are younger than the DMA: plain full wait there)
+    }
     wait_vmcnt_le<2 * WI>();                                  // halo 0 and slice 0 are older than slices 1, 2
     __builtin_amdgcn_s_barrier();
+
+    // BNIN: BatchNorm + ReLU on this wave's OWN slices of a landed halo tile, in place (lane = pixel rl of the slice, LOGICAL chunk p8 --
+    // the same eight channels for every slice, so one set of coefficients per chunk; physical position p8 ^ (halo column & 7)); pixels
+    // outside the image stay zero (the convolution's padding is applied AFTER the activation).  Column tile 0 also stores the activated
+    // interior pixels to y_act from the same registers.  Returns nothing; bn_nst = store instructions issued (wave-uniform, exact: the
+    // counted vmcnt waits of the next two steps allow exactly that many more operations in flight).
+    int bn_nst = 0, bn_pending = 0;
+    const bool bn_wb_tile = BNIN && bn.y_act != nullptr && tile_n == 0;
+    auto bn_transform = [&](int c, char* hbuf) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        const int cb = c * HL_BK + p8 * 8;
+        const float4 sa = *reinterpret_cast<const float4*>(s_sc + cb), sb = *reinterpret_cast<const float4*>(s_sc + cb + 4);
+        const float4 ta = *reinterpret_cast<const float4*>(s_sh + cb), tb = *reinterpret_cast<const float4*>(s_sh + cb + 4);
+        const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w}, sh[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+        int nst = 0;
+#pragma unroll
+        for (int t = 0; t < MAXS; ++t) {
+            if (t < hg.hpw && t * 8 + wave < hg.hpi) {
+                const int phys = (p8 ^ ((bn_hx7 >> (3 * t)) & 7)) * 16;
+                char* a = hbuf + (t * 8 + wave) * 1024 + rl * 128 + phys;
+                const uint4 v = *reinterpret_cast<const uint4*>(a);
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                unsigned o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = bn_relu_pinned(__builtin_bit_cast(float, w[i] << 16), sc[2 * i], sh[2 * i]);
+                    const float hi = bn_relu_pinned(__builtin_bit_cast(float, w[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]);
+                    o[i] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                }
+                const bool ok = (bn_ok >> t) & 1;
+                const uint4 r = ok ? uint4{o[0], o[1], o[2], o[3]} : uint4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<uint4*>(a) = r;
+                const bool mine = (bn_wb >> t) & 1;
+                if (bn_wb_tile && __builtin_amdgcn_ballot_w64(mine) != 0) {     // wave-uniform: the store instruction is issued or not
+                    ++nst;
+                    if (mine) store16_nt(reinterpret_cast<char*>(bn.y_act) + (h_off[t] - HL_BK * 2 - phys + p8 * 16), r, g.nt);   // read next in backward
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the in-place writes are done before the next barrier publishes the tile
+        __builtin_amdgcn_sched_barrier(0);
+        bn_nst = nst;
+        bn_pending = 2;                                       // the stores may stay in flight across the next two counted waits
+    };
+    if constexpr (BNIN) {
+        bn_transform(0, s_halo);
+        __builtin_amdgcn_s_barrier();
+    }
 
     // Register pipeline: a step's first-half fragments (kk = 0) are read during the PREVIOUS step's second-half MFMAs, its
     // second-half fragments during its own first-half MFMAs -- the matrix pipe never waits for the LDS round trip that used to
@@ -191,7 +310,12 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
         for (int tap = 0; tap < 9; ++tap) {
             const int r = tap / 3, s = tap % 3;
             // slice step + 1 (and, at a chunk's last tap, the next halo tile: older than that slice) has landed for this wave ...
-            wait_vmcnt_dyn((step + 2 < T ? WI : 0) + (had_prev ? 1 : 0));
+            if constexpr (BNIN) {
+                wait_vmcnt_dyn_wide((step + 2 < T ? WI : 0) + (had_prev ? 1 : 0) + (bn_pending > 0 ? bn_nst : 0));
+                bn_pending = bn_pending > 0 ? bn_pending - 1 : 0;
+            } else {
+                wait_vmcnt_dyn((step + 2 < T ? WI : 0) + (had_prev ? 1 : 0));
+            }
             __builtin_amdgcn_s_barrier();                    // ... and for every wave; every wave is past step - 1
             had_prev = false;
             if (tap < MAXS) {
@@ -204,6 +328,11 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
                 int t3 = tap + 3, c3 = c;
                 if (t3 >= 9) { t3 -= 9; ++c3; }
                 issue_w((slot + 3) & 3, t3, c3 * HL_BK);
+            }
+            if constexpr (BNIN) {
+                // tap 7: every slice of the next halo tile that THIS wave requested (taps 0-5) has landed (the wait above left only tap 6's
+                // filter slice in flight); the barrier of tap 8 publishes the activated tile to the look-ahead reads of that step
+                if (tap == 7 && more) bn_transform(c + 1, const_cast<char*>(hoth));
             }
             const char* sb = s_w + slot * HL_WSTAGE;
             const int shift = (r * hg.pitch + s) * 128;
@@ -450,6 +579,27 @@ static int halo_launch_t(const bf16_t* X, const bf16_t* Wt, void* out, float* st
         conv3x3_halo_kernel<true, BN><<<grid, HL_NT, LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, red_x, red_coef);
     else
         conv3x3_halo_kernel<false, BN><<<grid, HL_NT, LDS, stream>>>(X, Wt, out, stat_part, addend, mask_bits, zero_page, g, hg, stat_rows, nullptr, nullptr);
+    return ppv_last_error();
+}
+
+// BNIN launch (forward of an identity bottleneck's conv2 with bn1 + ReLU in its operand path): 128-column form, 16- / 32-wide maps
+bool conv3x3_halo_bnin_supported(const ConvGeom& g, int Cs) {
+    HaloGeom hg;
+    return halo_geom(g, Cs, 1, &hg, 128) && Cs <= 512 && hg.hpw <= 6 && (g.M / 256) * (g.N / 128) >= 200;
+}
+
+int conv3x3_halo_bnin_launch(const bf16_t* X, const bf16_t* Wt, void* out, float* stat_part, const bf16_t* zero_page, const ConvGeom& g,
+                             int stat_rows, const HaloBn& bn, hipStream_t stream) {
+    HaloGeom hg;
+    if (!conv3x3_halo_bnin_supported(g, g.Cs) || !halo_geom(g, g.Cs, 1, &hg, 128)) return PPV_ERR_BAD_SIZE;
+    const int LDS = HaloCfg<128>::LDS + 2 * 512 * (int)sizeof(float);        // + the scale / shift table
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_once.done();
+    }
+    const int grid = (int)(g.M / HL_BM) * hg.tiles_n;
+    conv3x3_halo_kernel<false, 128, true><<<grid, HL_NT, LDS, stream>>>(X, Wt, out, stat_part, nullptr, nullptr, zero_page, g, hg, stat_rows, nullptr, nullptr, bn);
     return ppv_last_error();
 }
 

@@ -1065,9 +1065,11 @@ static void launch_dfft_cols(const float2* T1, float2* T2, const float2* Ht, con
 }
 
 // element type of the Fresnel transforms and of the fields kept for backward (F0, U): c64 unless PPV_PSF_F32=0 (c128, rounds 1-4)
+static int g_psf_f32 = -1;                                    // -1: the environment decides; 0 / 1: ppv_ic_psf_set_fields_f32
 static bool psf_f32() {
-    static const bool on = !(getenv("PPV_PSF_F32") && atoi(getenv("PPV_PSF_F32")) == 0);
-    return on;
+    static const bool env_on = !(getenv("PPV_PSF_F32") && atoi(getenv("PPV_PSF_F32")) == 0);
+    const int v = __atomic_load_n(&g_psf_f32, __ATOMIC_RELAXED);
+    return v < 0 ? env_on : v != 0;
 }
 }  // extern "C" (templates need C++ linkage)
 
@@ -1142,6 +1144,9 @@ extern "C" {
 
 // 1: the Fresnel transforms and the saved fields F0 / U (ppv_ic_psf_state_offsets) are c64, 0: c128 (PPV_PSF_F32=0)
 int ppv_ic_psf_fields_f32(void) { return psf_f32() ? 1 : 0; }
+// on = 1 / 0: c64 / c128 fields from now on; -1: back to the environment's choice.  The state buffer's layout depends on it: set it BEFORE
+// sizing (ppv_ic_psf_state_bytes) and initialising a state, and keep it while that state is in use.  Returns the previous setting.
+int ppv_ic_psf_set_fields_f32(int on) { return __atomic_exchange_n(&g_psf_f32, on < 0 ? -1 : (on ? 1 : 0), __ATOMIC_RELAXED); }
 
 
 // Optional, once per (state, Z): mark where the basis Z [K][RR][RR] is non-zero, so that ppv_ic_psf_fwd / _bwd skip the pixel groups

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "ppv_common.h"
+#include "bn_coef.h"
 
 namespace ppv {
 
@@ -242,20 +243,15 @@ __global__ __launch_bounds__(256) void bn_act_fold_wg_kernel(const bf16_t* __res
 #pragma unroll
         for (int t = 0; t < TR; ++t) { s_ += (double)ps[j][t]; q_ += (double)pq[j][t]; }
         for (int t = TR; t < T; ++t) { if (c < C) { s_ += (double)sums[((long)t * 2) * C + c]; q_ += (double)sums[((long)t * 2 + 1) * C + c]; } }
-        const double mean = s_ * inv_count;
-        double var = q_ * inv_count - mean * mean;
-        if (var < 0) var = 0;
-        const float ve = (float)(var + (double)eps);
-        float invstd = __builtin_amdgcn_rsqf(ve);
-        invstd = invstd * (1.5f - 0.5f * ve * invstd * invstd);
-        const float sc = pg[j] * invstd, sh = pb[j] - (float)mean * sc;
+        const BnCoef k = bn_coef_pinned(s_, q_, inv_count, unbias, pg[j], pb[j], eps);      // bn_coef.h: the BNIN halo kernel derives the same bits
+        const float sc = k.sc, sh = k.sh;
         if (c < C) {
             s_sc[c] = sc; s_sh[c] = sh;
             if (blockIdx.x == 0) {
-                coef[c] = sc; coef[C + c] = sh; coef[2 * C + c] = (float)mean; coef[3 * C + c] = invstd;
+                coef[c] = sc; coef[C + c] = sh; coef[2 * C + c] = k.mean; coef[3 * C + c] = k.invstd;
                 if (run_mean) {
-                    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
-                    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * unbias);
+                    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * k.mean;
+                    run_var[c] = (1.f - momentum) * run_var[c] + momentum * k.var_unbiased;
                 }
             }
         }
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_act_fold_wg_kernel(const bf16_t* __res
         unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float v = xv[k] * sc[k] + sh[k];
+            float v = __builtin_fmaf(xv[k], sc[k], sh[k]);          // pinned (bn_coef.h bn_relu_pinned): the BNIN halo kernel applies the same
             if (RES == 1) v += rv[k];
             o[k] = RELU ? fmaxf(v, 0.f) : v;
             bits |= (o[k] > 0.f ? 1u : 0u) << k;

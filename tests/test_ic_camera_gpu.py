@@ -53,7 +53,7 @@ def _mid_cam(layout="B", prueba_masks=False):
     return cam
 
 
-def test_mid_size_every_stage_and_grads():
+def test_mid_size_every_stage_and_grads(field_mode):
     """RR=448 (FFT 672 = 2^5*3*7), P=128 (FFT 256), K=36: same code paths as 896/1344/256, oracle-sized."""
     from oracle import ic_camera as ic
     cam = _mid_cam()
@@ -97,10 +97,22 @@ def test_mid_size_grad_wrt_image():
     assert rel_err(ig.grad.cpu(), io.grad) < TOL
 
 
+@pytest.fixture(params=["c64", "c128"])
+def field_mode(request):
+    """Both element types of the Fresnel chain inside ONE test run (the c128 mode -- the reference's own precision, by
+    type promotion -- was covered by nothing the default run executed): set before the camera sizes its state, restored afterwards."""
+    from ppv_amd import _lib
+    prev = _lib.lib().ppv_ic_psf_set_fields_f32(1 if request.param == "c64" else 0)
+    yield request.param
+    _lib.lib().ppv_ic_psf_set_fields_f32(prev)
+
+
 @pytest.mark.parametrize("tag", ["init", "modelpth"])
-def test_real_size_against_reference_golden(tag):
+def test_real_size_against_reference_golden(tag, field_mode):
     """train.py:64-66 configuration (896/350/256, prueba '3'); golden = the reference's own output."""
     from ppv_amd.camera_lens import OpticsZernike
+    from ppv_amd import _lib
+    assert _lib.lib().ppv_ic_psf_fields_f32() == (1 if field_mode == "c64" else 0)
     g = load_golden("ic_real.npz")
     cam = OpticsZernike(input_shape=[None, 256, 256, 3], device=torch.device("cuda"), zernike_terms=350,
                         patch_size=256, height_tolerance=2e-8, sensor_distance=0.025, wave_resolution=[896, 896],

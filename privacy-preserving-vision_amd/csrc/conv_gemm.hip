@@ -23,6 +23,7 @@
 // store loop, the sums the following BatchNorm backward needs (sum g, sum g * x per channel; optional recomputed ReLU mask), so
 // that BatchNorm's own reduce pass over the stored tensor disappears.
 #include <climits>
+#include <utility>
 #include "conv_common.h"
 #include "conv_tile_epilogue.h"
 
@@ -233,7 +234,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
 // extra read of x (1 T) in this store loop.  red_coef (BN scale / shift [2][N], may be null): the BatchNorm is followed by a ReLU
 // without residual, so its mask (x * scale + shift > 0, the forward kernel's expression) is recomputed here, applied to the
 // stored gradient and to the sums (single-pass store path only: launches without addend).
-template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false, bool COOP = false>
+// LOOK (round 6, BK = 32 stages in a ring of six): the fragments of K-step t + 1 are read from LDS while the MFMAs of step t run.  The
+// plain loop reads a step's fragments behind the step's barrier: all eight waves sit out the same LDS round trip with the matrix pipe idle,
+// then issue MFMAs with the LDS pipe idle -- tools/ladder_1x1.py, 1024 -> 256 @16x16: K loop alone 21.8 us for 16 x (512 MFMA cycles + 512
+// LDS cycles per SIMD) = 7 us of either pipe, loads alone 22.5 us, whole launch 29.4 us.  Here step t's counted wait covers stage t + 1 (one
+// stage deeper), the barrier publishes it, and the look-ahead reads go out in front of the MFMA batch (two static register sets: the loop is
+// unrolled by two).  Bytes in flight per workgroup stay 96 KB (four 24-KB stages instead of two 48-KB ones).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_pipe_(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for_pipe(F&& f) { static_for_pipe_(f, std::make_integer_sequence<int, N>{}); }
+template <int OFF> __device__ __forceinline__ void lds_read128_off(bf16x8& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int STRIDE, int N, int... Is>
+__device__ __forceinline__ void lds_read_frags(bf16x8 (&f)[N], unsigned addr, std::integer_sequence<int, Is...>) {
+    (lds_read128_off<Is * STRIDE>(f[Is], addr), ...);
+}
+template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false, bool COOP = false, bool LOOK = false>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
@@ -380,9 +397,122 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
         if (s0 < nk) stage(s0);
     PPV_STAMP(1);
     int rd = 0, wr = (NSTAGE - 1) % NSTAGE;
-    for (int t = 0; t < nk; ++t) {
-        // stages issued so far: min(nk, t + NSTAGE - 1); those younger than stage t may stay in flight
-        const int younger = min(nk, t + NSTAGE - 1) - (t + 1);
+    if constexpr (LOOK) {
+        static_assert(BK == 32 && NSTAGE >= 4, "LOOK: one k-half per stage, a ring deep enough to keep stage t + 1 landed");
+        bf16x8 afA[MI], bfA[NI], afB[MI], bfB[NI];
+        // inline asm + hand-counted lgkmcnt (LDS returns in order): left to hipcc the MFMA batch sits behind s_waitcnt lgkmcnt(0), i.e. behind
+        // the look-ahead reads issued just before it (its waitcnt pass loses the per-register picture across the loop back-edge)
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+        const unsigned a_base = lds0 + (wm * WROWS + fr) * ROWB + (fq ^ key(fr)) * 16;
+        const unsigned b_base = lds0 + A_BYTES + (wn * WCOLS + fr) * ROWB + (fq ^ key(fr)) * 16;
+        auto read_frags = [&](int buf, bf16x8 (&af)[MI], bf16x8 (&bfr)[NI]) __attribute__((always_inline)) {
+            const unsigned a = a_base + buf * STAGE_BYTES, b = b_base + buf * STAGE_BYTES;
+            lds_read_frags<16 * ROWB>(af, a, std::make_integer_sequence<int, MI>{});
+            lds_read_frags<16 * ROWB>(bfr, b, std::make_integer_sequence<int, NI>{});
+        };
+        constexpr int LOOKN = MI + NI;
+        auto frags_of_previous_step_are_in = [&]() __attribute__((always_inline)) {         // all but the MI + NI reads issued last
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LOOKN) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfmas = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        };
+        // own loads of every stage <= s have landed when at most (issued - (s + 1)) stages' worth of instructions are outstanding
+        auto wait_stage = [&](int s, int issued) __attribute__((always_inline)) {
+            const int younger = issued - (s + 1);
+            if (younger >= NSTAGE - 2) wait_vmcnt_le<(NSTAGE - 2) * L>();
+            else if (younger == NSTAGE - 3) wait_vmcnt_le<(NSTAGE - 3) * L>();
+            else if (NSTAGE >= 5 && younger == NSTAGE - 4) wait_vmcnt_le<(NSTAGE >= 5 ? (NSTAGE - 4) * L : 0)>();
+            else if (NSTAGE >= 6 && younger == NSTAGE - 5) wait_vmcnt_le<(NSTAGE >= 6 ? (NSTAGE - 5) * L : 0)>();
+            else wait_vmcnt_le<0>();
+        };
+        static_assert(NSTAGE == 6, "the tail below is written for a ring of six");
+        wait_stage(0, min(nk, NSTAGE - 1));                                // (the one ladder of the workgroup)
+        __builtin_amdgcn_s_barrier();
+        PPV_STAMP(2);
+        read_frags(0, afA, bfA);                                           // the one exposed LDS round trip of the workgroup
+        const bool do_stage = g.chunked != 3, do_comp = g.chunked != 2;    // PPV_CONV_DEBUG timing modes
+        // One step.  W = stages that may stay in flight across its wait (stage t + 1 has landed: this wave's part ... and, behind the
+        // barrier, everybody's); every wave is past the MFMAs of step t - 1, i.e. past its wait for the fragments of stage t - 1, whose
+        // buffer takes the DMA of stage t + NSTAGE - 1 (ISSUE).  W and ISSUE are compile-time: the steady-state loop carries NO scalar
+        // branch ladder (tools/micro/lds_mfma_rate.hip: a four-way ladder costs ~90 ns per step, a third of the step).
+        auto step = [&](auto W_, auto ISSUE_, const bf16x8 (&afc)[MI], const bf16x8 (&bfc)[NI], bf16x8 (&afn)[MI], bf16x8 (&bfn)[NI]) __attribute__((always_inline)) {
+            wait_vmcnt_le<decltype(W_)::value * L>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (decltype(ISSUE_)::value) {
+                if (do_stage) stage(wr);
+            }
+            const int nxt = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+            if (do_comp) {
+                read_frags(nxt, afn, bfn);                                 // (the last step re-reads a landed buffer for nothing: no branch in the loop)
+                frags_of_previous_step_are_in();
+                mfmas(afc, bfc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rd = nxt;
+            wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+        };
+        using std::integral_constant;
+        int t = 0;
+        for (; t + NSTAGE < nk; t += 2) {                                  // both steps of the pair issue a stage (nk is even: Cs % 64 == 0)
+            step(integral_constant<int, NSTAGE - 3>{}, integral_constant<bool, true>{}, afA, bfA, afB, bfB);
+            step(integral_constant<int, NSTAGE - 3>{}, integral_constant<bool, true>{}, afB, bfB, afA, bfA);
+        }
+        // tail: 2, 4 or 6 steps remain; their waits shrink with the stages left in flight (ladder: <= 6 times per workgroup), the first
+        // of six still issues the last stage
+        int issued = min(nk, t + NSTAGE - 1);
+        auto step_tail = [&](int tt, const bf16x8 (&afc)[MI], const bf16x8 (&bfc)[NI], bf16x8 (&afn)[MI], bf16x8 (&bfn)[NI]) __attribute__((always_inline)) {
+            wait_stage(min(tt + 1, nk - 1), issued);
+            __builtin_amdgcn_s_barrier();
+            if (tt + NSTAGE - 1 < nk) {
+                if (do_stage) stage(wr);
+                ++issued;
+            }
+            const int nxt = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+            if (do_comp) {
+                read_frags(nxt, afn, bfn);
+                frags_of_previous_step_are_in();
+                mfmas(afc, bfc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rd = nxt;
+            wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+        };
+        for (; t < nk; t += 2) {
+            step_tail(t, afA, bfA, afB, bfB);
+            step_tail(t + 1, afB, bfB, afA, bfA);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the stale look-ahead of the last step: its registers are free only now
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(afA[i]), "v"(afB[i]));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(bfA[i]), "v"(bfB[i]));
+        __builtin_amdgcn_sched_barrier(0);
+    } else
+    {
+    const bool do_stage = g.chunked != 3, do_comp = g.chunked != 2;       // chunked 2 / 3: timing experiments (PPV_CONV_DEBUG: loads / compute only)
+    int t = 0;
+    // steady state (round 6): every step issues a stage and NSTAGE - 2 younger stages stay in flight -- one constant wait, no per-step
+    // ladder of scalar branches (tools/micro/lds_mfma_rate.hip: ~90 ns per step)
+    for (; t + NSTAGE - 1 < nk; ++t) {
+        wait_vmcnt_le<(NSTAGE - 2) * L>();
+        __builtin_amdgcn_s_barrier();
+#ifdef PPV_STAMPS
+        if (t == 0) PPV_STAMP(2);
+#endif
+        if (do_stage) stage(wr);
+        if (do_comp) compute(rd);
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
+    for (; t < nk; ++t) {                                                  // tail: nothing left to issue
+        // stages issued: nk; those younger than stage t may stay in flight
+        const int younger = nk - (t + 1);
         if (NSTAGE >= 3 && younger >= NSTAGE - 2) wait_vmcnt_le<(NSTAGE - 2) * L>();
         else if (NSTAGE >= 4 && younger == NSTAGE - 3) wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
         else wait_vmcnt_le<0>();
@@ -390,10 +520,9 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
 #ifdef PPV_STAMPS
         if (t == 0) PPV_STAMP(2);
 #endif
-        if (t + NSTAGE - 1 < nk && g.chunked != 3) stage(wr);             // chunked 2 / 3: timing experiments (PPV_CONV_DEBUG: loads / compute only)
-        if (g.chunked != 2) compute(rd);
+        if (do_comp) compute(rd);
         rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
-        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
     }
     __syncthreads();
     PPV_STAMP(3);
@@ -603,6 +732,22 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         else if (out_f32) kt<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
         else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
     } while (0)
+#define PPV_LAUNCH_PIPE_LOOK(BM_, BN_, NS_, BK_, WG_)                                                                    \
+    do {                                                                                                                \
+        constexpr int ring = NS_ * (BM_ + BN_) * BK_ * 2, epi = BM_ * (BN_ * 2 + 32) + 4096 + 8192, lds = ring > epi ? ring : epi; \
+        const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;                                                      \
+        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, false, false, true>;                            \
+        auto kr = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, true, false, true>;                             \
+        static PpvDevOnce attr_once;                                                                                    \
+        if (attr_once.need()) {                                                                                         \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds));            \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));            \
+            attr_once.done();                                                                                           \
+        }                                                                                                               \
+        if (out_f32) return PPV_ERR_BAD_SIZE;                                                                           \
+        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef, CoopBn{}); \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
+    } while (0)
 #define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, false)
 #define PPV_LAUNCH_PIPE_R(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, true)
     // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages (BK 64),
@@ -622,10 +767,14 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         else if (t256 >= CUS) v = (no_v3 == 1 || (no_v3 == 2 && rx)) ? 4 : 3;            // one round: deepest prefetch per workgroup
         else v = 2;                             // the 256-row tile only when it still fills the chip
     }
-    if (rx && (v < 2 || v > 4)) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the three production tiles only
+    static const int look = getenv("PPV_CONV_LOOK") ? atoi(getenv("PPV_CONV_LOOK")) : 0;          // A/B: 1 = the look-ahead form of the one-round 256 x 128 tile
+    if (v == 3 && look && !out_f32 && (g_conv_variant & 0xfff) == 0 && g.chunked != 1) v = 6;
+    if (v == 6 && (out_f32 || g.chunked == 1)) v = 3;     // (forced variant 6: the f32-output / layout-experiment launches stay on the plain tile)
+    if (rx && (v < 2 || (v > 4 && v != 6))) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the production tiles only
     if (v == 5) PPV_LAUNCH_PIPE(128, 128, 3, 32, 3);      // 16 KB stages, three 4-wave workgroups per CU
     else if (v == 4) PPV_LAUNCH_PIPE_R(256, 128, 3, 32, 2); // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
     else if (v == 3) PPV_LAUNCH_PIPE_R(256, 128, 3, 64, 1);
+    else if (v == 6) PPV_LAUNCH_PIPE_LOOK(256, 128, 6, 32, 1);  // fragment reads of step t + 1 under the MFMAs of step t (round 6)
     else if (v == 2) PPV_LAUNCH_PIPE_R(128, 128, 4, 64, 1);
     else if (N == 16) PPV_LAUNCH(16, 4, 1);
     else if (N % 128 == 0) PPV_LAUNCH(128, 2, N / 128);
@@ -634,6 +783,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
 #undef PPV_LAUNCH_PIPE
 #undef PPV_LAUNCH_PIPE_R
 #undef PPV_LAUNCH_PIPE_
+#undef PPV_LAUNCH_PIPE_LOOK
     return ppv_last_error();
 }
 

@@ -440,6 +440,30 @@ int ppv_ssim_fwd(const float* img1, const float* img2, double* sums, const float
 int ppv_ssim_bwd(const float* img1, const float* img2, const float* gscale, float* d_img2, const float* win, int B, int C, int H, int W,
                  ppv_stream_t stream);
 
+/* ---- fp32 trunk, element-wise side (round 6: Encoder(precision="fp32")): train-mode BatchNorm2d (+ residual) (+ ReLU), the stem's
+ * max-pool and the adaptive average pool on NHWC float32 activations, forward and backward; the torchvision ResNet-101 behind
+ * Image_Caption/models.py:17-41 trained in fp32 (train.py:245).  Deterministic (per-row-block f64 partial sums added in block order).
+ * ppv_bn_f32_fwd: x [rows][C] -> y = act(x * scale + shift + res) (res null: none), coef [4][C] OUT (scale, shift, mean, invstd: what
+ * the backward call reads); train = 1: batch statistics (biased variance), running statistics updated (null: not tracked);
+ * train = 0: the running statistics.  workspace: ppv_bn_f32_workspace_bytes(C) bytes, no zeroing.  C % 64 == 0.
+ * ppv_bn_f32_bwd: g = dL/dy, y (only read behind a ReLU: the mask y > 0), x, coef of the forward call -> gx, gres (null: no residual
+ * branch; else the masked gradient), dgamma / dbeta (null: not wanted), sums [2][C] OUT (d beta, d gamma).
+ * ppv_maxpool_f32_*: 3 x 3, stride 2, padding 1; arg [B,Ho,Wo,C] u8 = window offset of the FIRST maximum in row-major order
+ * (torch.nn.MaxPool2d's choice); backward is a gather (no atomics).  ppv_adaptive_pool_f32_*: AdaptiveAvgPool2d((E, E)), models.py:27.
+ * ppv_split6_rows: x [rows][C] f32 -> y [rows][Cp] bf16 = [h | m | h | l | h | m | 0 ...] of the three-way bf16 split x = h + m + l: the
+ * operand of an f32-level convolution on the bf16 MFMA kernels against the K-concatenated filter [H | H | M | H | L | M]
+ * (ppv_amd.nn_ops.conv2d_f32(exact=True)).  C % 4 == 0, Cp % 4 == 0, Cp >= 6 C. */
+size_t ppv_bn_f32_workspace_bytes(int C);
+int ppv_split6_rows(const float* x, void* y, long rows, int C, int Cp, ppv_stream_t stream);
+int ppv_bn_f32_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                   const float* res, float* y, float* coef, void* workspace, long rows, int C, int relu, int train, ppv_stream_t stream);
+int ppv_bn_f32_bwd(const float* g, const float* y, const float* x, const float* coef, float* gx, float* gres, float* dgamma, float* dbeta,
+                   float* sums, void* workspace, long rows, int C, int relu, int train, ppv_stream_t stream);
+int ppv_maxpool_f32_fwd(const float* x, float* y, void* arg, int B, int H, int W, int C, ppv_stream_t stream);
+int ppv_maxpool_f32_bwd(const float* gy, const void* arg, float* gx, int B, int H, int W, int C, ppv_stream_t stream);
+int ppv_adaptive_pool_f32_fwd(const float* x, float* y, int B, int H, int W, int C, int E, ppv_stream_t stream);
+int ppv_adaptive_pool_f32_bwd(const float* gy, float* gx, int B, int H, int W, int C, int E, ppv_stream_t stream);
+
 /* ---- camera MSE loss of the harness, Image_Caption/train.py:170-171,284-288 (`loss_cam = 1 - nn.MSELoss()(imgs, sensor)`), fused.
  * ppv_mse_fwd: out[0] = mean((a - b)^2) in one pass, deterministic (per-workgroup f64 partials, summed in index order by the last
  * workgroup); `workspace` = ppv_mse_workspace_bytes() bytes, 16-byte aligned, ZEROED ONCE by the caller at allocation (the kernel

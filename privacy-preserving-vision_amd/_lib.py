@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -68,6 +68,14 @@ PROTOTYPES = {
     "ppv_ssim_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ppv_conv3x3_bnin_supported": (_I, [_I, _I, _I, _I, _I]),
     "ppv_conv3x3_bnin": (_I, [_P, _P, _I, _c.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_bn_f32_workspace_bytes": (_Z, [_I]),
+    "ppv_split6_rows": (_I, [_P, _P, _L, _I, _I, _P]),
+    "ppv_bn_f32_fwd": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "ppv_bn_f32_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "ppv_maxpool_f32_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_maxpool_f32_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_adaptive_pool_f32_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ppv_adaptive_pool_f32_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_mse_workspace_bytes": (_Z, []),
     "ppv_mse_fwd": (_I, [_P, _P, _L, _P, _P, _P]),
     "ppv_mse_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _P]),

@@ -894,8 +894,13 @@ class _TrunkFn(torch.autograd.Function):
 class Encoder(nn.Module):
     """Encoder (models.py:8-54).  ``layers`` (extra, keyword) shrinks the trunk for tests; default = ResNet-101."""
 
-    def __init__(self, encoded_image_size=36, *, layers=LAYERS, lazy_output=True):
+    def __init__(self, encoded_image_size=36, *, layers=LAYERS, lazy_output=True, precision="bf16"):
         super().__init__()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("ppv_amd Encoder: precision is 'bf16' (bf16 storage, f32 accumulate: BASELINE configs 3 / 5) or 'fp32' (the "
+                             "reference's own precision, models.py:31-41 under train.py:245)")
+        self.precision = precision         # "fp32": f32 activations end to end, every convolution at f32 level on the MFMA kernels (six bf16
+        #                                    products of a three-way operand split), BatchNorm / ReLU / residual / pools on csrc/bn_f32.hip
         self.enc_image_size = encoded_image_size
         self.lazy_output = lazy_output     # the dense [B,E,E,2048] f32 output is written on first access (LazyEncoderOut)
         # the reference loads ImageNet weights (models.py:17); offline there are none: torchvision's random init
@@ -1028,12 +1033,47 @@ class Encoder(nn.Module):
     def forward(self, images):
         if not images.is_cuda:
             raise RuntimeError("ppv_amd Encoder runs on an MI355X (images must be a cuda tensor); no CPU path")
+        if getattr(self, "precision", "bf16") == "fp32":
+            return self._forward_fp32(images)
         object.__setattr__(self, "_grad_wanted", torch.is_grad_enabled())      # (autograd.Function.forward runs with grad mode off)
         out, cells = _TrunkFn.apply(self, images, *self._param_list())
         if getattr(self, "lazy_output", False):
             fill = self.__dict__.pop("_last_fill", None)
             out = LazyEncoderOut.wrap(out, fill)
         out._ppv_cells = cells             # the 8x8 map behind the up-sampled output (consumed by ppv_amd.decoder, ignored otherwise)
+        return out
+
+    # ------------------------------------------------------------------ the fp32 product mode (round 6)
+    def _forward_fp32(self, images, taps=None):
+        """Encoder(precision="fp32").forward: the reference's precision (models.py:31-41; train.py:245 trains the trunk in fp32) as a product
+        path.  f32 NHWC activations end to end; every convolution on the hand-written MFMA kernels at f32 level -- forward, data gradient
+        and weight gradient as six bf16 products of a three-way operand split (ppv_amd.nn_ops.conv2d_f32(exact=True), ~2^-24 per product);
+        BatchNorm (batch statistics in train mode WITH the running-statistics update, running statistics in eval mode) + residual + ReLU,
+        the stem's max-pool and the adaptive average pool on csrc/bn_f32.hip (ppv_bn_f32_*, ppv_maxpool_f32_*, ppv_adaptive_pool_f32_*):
+        no torch element-wise op between the convolutions.  Differentiable through autograd (custom Functions per layer); deterministic
+        element-wise side.  ~10x the bf16 path's time per image: the precision mode, not the throughput mode.
+        ``taps``: optional list that receives every block's output [B,H,W,C] f32 (stem pool output first)."""
+        from .nn_ops import adaptive_avg_pool_f32, batch_norm_f32, conv2d_f32, max_pool3x3s2_f32
+        x = torch.nn.functional.pad(images.float().permute(0, 2, 3, 1), (0, 5)).contiguous()       # NHWC f32, 3 -> 8 channels (vector split)
+
+        def conv(t, rec, w=None):
+            w = rec.conv.weight if w is None else w
+            return conv2d_f32(t, w, None, rec.stride, rec.pad, weight_grad=rec.conv.weight.requires_grad, accurate_wgrad=True, exact=True)
+
+        st = self._stem
+        y = batch_norm_f32(conv(x, st, torch.nn.functional.pad(st.conv.weight, (0, 0, 0, 0, 0, 5))), st.bn)
+        y = max_pool3x3s2_f32(y)
+        if taps is not None:
+            taps.append(y)
+        for r1, r2, r3, rd in self._blocks:
+            o = batch_norm_f32(conv(y, r1), r1.bn)
+            o = batch_norm_f32(conv(o, r2), r2.bn)
+            idn = y if rd is None else batch_norm_f32(conv(y, rd), rd.bn, relu=False)
+            y = batch_norm_f32(conv(o, r3), r3.bn, res=idn)
+            if taps is not None:
+                taps.append(y)
+        out = adaptive_avg_pool_f32(y, self.enc_image_size)
+        out._ppv_cells = None          # (the compact hand-over to ppv_amd.decoder is a bf16 map: the fp32 mode hands over the dense tensor only)
         return out
 
     # ------------------------------------------------------------------ fp32-accurate forward (parity instrument, not the product path)

@@ -45,12 +45,12 @@ def _layouts(w, exact=False):
         bwd = _pad_to(_pad_to(torch.cat([hi, hi, lo], dim=0), 0, 64), 1, 64)                # [pad64(3 Cout), Cinp, R, S]
         second = None
         if exact:
-            # the other three of the six products of a three-way split (x = h + m + l, W = H + M + L; `lo` above is M):
-            # [x_l | x_h | x_m] against [W_H | W_L | W_M]
+            # all six products of a three-way split that matter (x = h + m + l, W = H + M + L; `lo` above is M) in ONE convolution:
+            # [x_h | x_m | x_h | x_l | x_h | x_m] (ppv_split6_rows) against the K-concatenated filter [W_H | W_H | W_M | W_H | W_L | W_M]
             l3 = (wf - hi - lo).bfloat16().float()
-            fwd2 = _pad_to(_pad_to(torch.cat([hi, l3, lo], dim=1), 1, 64), 0, 64)
-            bwd2 = _pad_to(_pad_to(torch.cat([hi, l3, lo], dim=0), 0, 64), 1, 64)
-            second = (co.weight_layout(fwd2.contiguous(), 0), co.weight_layout(bwd2.contiguous(), 1))
+            fwd6 = _pad_to(_pad_to(torch.cat([hi, hi, lo, hi, l3, lo], dim=1), 1, 64), 0, 64)
+            bwd6 = _pad_to(_pad_to(torch.cat([hi, hi, lo, hi, l3, lo], dim=0), 0, 64), 1, 64)
+            second = (co.weight_layout(fwd6.contiguous(), 0), co.weight_layout(bwd6.contiguous(), 1))
         ent = (ver, co.weight_layout(fwd.contiguous(), 0), co.weight_layout(bwd.contiguous(), 1),
                weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), second)
         _wcache[key] = ent
@@ -75,15 +75,17 @@ def _split3(t):
     return y
 
 
-def _split3b(t):
-    """[l | h | m] of the three-way bf16 split t = h + m + l (h = bf16(t), m = bf16(t - h), l = bf16(t - h - m)), zero padded to a
-    multiple of 64 channels: the operand of the SECOND convolution of conv2d_f32(exact=True).  Element-wise torch ops (a parity
-    instrument, not a hot path)."""
-    h = t.bfloat16()
-    r = t - h.float()
-    m = r.bfloat16()
-    l = (r - m.float()).bfloat16()
-    return _pad_to(torch.cat([l, h, m], dim=-1), 3, 64).contiguous()
+def _split6(t):
+    """[h | m | h | l | h | m] of the three-way bf16 split t = h + m + l (h = bf16(t), m = bf16(t - h), l = bf16(t - h - m)), zero padded to a
+    multiple of 64 channels: the operand of conv2d_f32(exact=True) (csrc/bn_f32.hip split6_kernel; C % 4 == 0)."""
+    B, H, W, C = t.shape
+    if C % 4:
+        t = _pad_to(t, 3, 4).contiguous()
+        C = t.shape[-1]
+    cp = (6 * C + 63) // 64 * 64
+    y = torch.empty((B, H, W, cp), dtype=torch.bfloat16, device=t.device)
+    check(_lib.lib().ppv_split6_rows(ptr(t), ptr(y), B * H * W, C, cp, stream_ptr()), "ppv_split6_rows")
+    return y
 
 
 def _wgrad_padded(gy, x, wshape, stride, pad, exact=False):
@@ -131,9 +133,10 @@ class _ConvF32(torch.autograd.Function):
         assert R == S and x.shape[-1] == Cin
         ctx.wd = wd
         ctx.wd2 = second[1] if second is not None else None
-        y = co.conv_fwd(_split3(x), wf, stride, pad, out_f32=True)
-        if second is not None:                       # exact: the three remaining products of the three-way split
-            y = y + co.conv_fwd(_split3b(x), second[0], stride, pad, out_f32=True)
+        if second is not None:                       # exact: six products of the three-way split, one K-concatenated convolution
+            y = co.conv_fwd(_split6(x), second[0], stride, pad, out_f32=True)
+        else:
+            y = co.conv_fwd(_split3(x), wf, stride, pad, out_f32=True)
         if y.shape[-1] != Cout:
             y = y[..., :Cout].contiguous()
         if bias is not None:
@@ -150,9 +153,10 @@ class _ConvF32(torch.autograd.Function):
         gy = gy.contiguous().float()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = co.conv_dgrad(_split3(gy), ctx.wd, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
             if ctx.wd2 is not None:
-                gx = gx + co.conv_dgrad(_split3b(gy), ctx.wd2, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
+                gx = co.conv_dgrad(_split6(gy), ctx.wd2, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
+            else:
+                gx = co.conv_dgrad(_split3(gy), ctx.wd, stride, pad, (x.shape[1], x.shape[2]), out_f32=True)
             if gx.shape[-1] != Cin:
                 gx = gx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
@@ -172,8 +176,9 @@ def conv2d_f32(x, weight, bias=None, stride=1, pad=0, weight_grad=True, accurate
     the bf16-split operands (~2^-16) for every shape (default: one bf16 product where the channel counts fit the kernel's tiles)."""
     if exact:
         # reference precision: a THREE-way bf16 split of both operands and all six products that matter (h H, m H, h M, l H, h L, m M;
-        # the dropped ones are <= 2^-32 of the product), i.e. ~2^-24 per product -- f32 -- instead of 2^-16, as a second convolution
-        # over [x_l | x_h | x_m] against [W_H | W_L | W_M]; forward, data gradient and weight gradient (parity instrument: 2x the work)
+        # the dropped ones are <= 2^-32 of the product), i.e. ~2^-24 per product -- f32 -- instead of 2^-16, as ONE convolution over the
+        # K-concatenated operands [x_h | x_m | x_h | x_l | x_h | x_m] x [W_H | W_H | W_M | W_H | W_L | W_M]; forward, data gradient and
+        # weight gradient (the fp32 product mode of ppv_amd.encoder.Encoder: 2x the work of the three-product form)
         wf, wd, wf2, wd2 = _layouts(weight, exact=True)
         second = (wf2, wd2)
         accurate_wgrad = True
@@ -221,3 +226,116 @@ class _InstNormAct(torch.autograd.Function):
 def instance_norm_act(x, scale, shift, slope=1.0, eps=1e-5):
     """lrelu_slope( InstanceNorm(x) * scale + shift ) on x [B,H,W,C] f32; scale / shift [C] (affine InstanceNorm2d) or [B,C] (AdaIN)."""
     return _InstNormAct.apply(x, scale, shift, float(slope), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# fp32 trunk, element-wise side (csrc/bn_f32.hip, round 6): what Encoder(precision="fp32") puts between the f32 convolutions
+
+_BN_WS = {}
+
+
+def _bn_ws(dev, C):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, C)
+    if key not in _BN_WS:
+        _BN_WS[key] = torch.empty(int(_lib.lib().ppv_bn_f32_workspace_bytes(C)), dtype=torch.uint8, device=dev)
+    return _BN_WS[key]
+
+
+class _BatchNormF32(torch.autograd.Function):
+    """train-mode (or eval-mode) BatchNorm2d (+ residual) (+ ReLU) on NHWC f32; running statistics are updated by the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, bn, relu):
+        if not x.is_cuda:
+            raise RuntimeError("ppv_amd batch_norm_f32 runs on an MI355X (cuda tensors); no CPU path")
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        train = bool(bn.training or bn.running_mean is None)
+        y = torch.empty_like(x)
+        coef = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        r = None if res is None else res.contiguous()
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = train and bn.track_running_stats and bn.running_mean is not None
+        if track and bn.momentum is None:                        # cumulative moving average (nn.BatchNorm2d(momentum=None))
+            mom = 1.0 / float(int(bn.num_batches_tracked) + 1)
+        check(_lib.lib().ppv_bn_f32_fwd(ptr(x), ptr(weight.detach()), ptr(bias.detach()), ptr(bn.running_mean) if (track or not train) else None,
+                                        ptr(bn.running_var) if (track or not train) else None, mom, float(bn.eps), ptr(r), ptr(y), ptr(coef),
+                                        ptr(_bn_ws(x.device, C)), rows, C, int(relu), int(train), stream_ptr()), "ppv_bn_f32_fwd")
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, y if relu else None, coef)
+        ctx.relu, ctx.train, ctx.has_res = relu, train, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, coef = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        want_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dg = torch.empty(C, dtype=torch.float32, device=x.device) if want_affine else None
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if want_affine else None
+        sums = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ppv_bn_f32_bwd(ptr(g), ptr(y), ptr(x), ptr(coef), ptr(gx), ptr(gres), ptr(dg), ptr(db), ptr(sums), ptr(_bn_ws(x.device, C)),
+                                        rows, C, int(ctx.relu), int(ctx.train), stream_ptr()), "ppv_bn_f32_bwd")
+        return (gx if ctx.needs_input_grad[0] else None, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
+                gres if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None)
+
+
+def batch_norm_f32(x, bn, res=None, relu=True):
+    """act(bn(x) + res) for an nn.BatchNorm2d module `bn` on NHWC f32 `x` [B,H,W,C] (C % 64 == 0): batch statistics + running-statistics update
+    in train mode, running statistics in eval mode; gradients to x, bn.weight, bn.bias and res."""
+    return _BatchNormF32.apply(x, bn.weight, bn.bias, res, bn, relu)
+
+
+class _MaxPoolF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        check(_lib.lib().ppv_maxpool_f32_fwd(ptr(x), ptr(y), ptr(arg), B, H, W, C, stream_ptr()), "ppv_maxpool_f32_fwd")
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        B, H, W, C = ctx.shape
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(_lib.lib().ppv_maxpool_f32_bwd(ptr(g.contiguous()), ptr(arg), ptr(gx), B, H, W, C, stream_ptr()), "ppv_maxpool_f32_bwd")
+        return gx
+
+
+def max_pool3x3s2_f32(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (resnet.3) on NHWC f32."""
+    return _MaxPoolF32.apply(x)
+
+
+class _AdaptivePoolF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, E):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty((B, E, E, C), dtype=torch.float32, device=x.device)
+        check(_lib.lib().ppv_adaptive_pool_f32_fwd(ptr(x), ptr(y), B, H, W, C, E, stream_ptr()), "ppv_adaptive_pool_f32_fwd")
+        ctx.shape, ctx.E = (B, H, W, C), E
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C = ctx.shape
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(_lib.lib().ppv_adaptive_pool_f32_bwd(ptr(g.contiguous()), ptr(gx), B, H, W, C, ctx.E, stream_ptr()), "ppv_adaptive_pool_f32_bwd")
+        return gx, None
+
+
+def adaptive_avg_pool_f32(x, E):
+    """nn.AdaptiveAvgPool2d((E, E)) (models.py:27) on NHWC f32 [B,H,W,C] -> [B,E,E,C] (already the layout models.py:40 permutes to)."""
+    return _AdaptivePoolF32.apply(x, E)

@@ -133,3 +133,28 @@ def test_one_training_iteration_batch4_matches_the_oracle():
     print(f"six-product training pass: encoder output {out_err_x:.2e}; lens gradient vs oracle (full loss): cos {cos_x:.6f}, rel L2 {rl2_x:.3e}; "
           f"smallest weight-gradient cosine {worst_x:.5f}")
     assert out_err_x < out_err and cos_x > 0.999 and rl2_x < 5e-2 and worst_x > 0.99
+    # ---- round 6: the same step through the PRODUCT's fp32 mode -- Encoder(precision="fp32").forward (VERDICT r5 task 5): f32-level
+    # convolutions as above, BatchNorm / ReLU / residual / pools on csrc/bn_f32.hip (no torch element-wise op between the convolutions:
+    # tests/test_encoder_fp32_gpu.py), running statistics updated
+    for p in encoder.parameters():
+        p.grad = None
+    camera.zernike_coeffs_train.grad = None
+    encoder.precision = "fp32"
+    try:
+        s_p, _, _, lp_p = camera(img.to(dev), None, "3", noise_u01=noise.to(dev))
+        out_p = encoder(s_p)
+        loss_p = loss_of(out_p, s_p, img.to(dev), lp_p)
+        loss_p.backward()
+    finally:
+        encoder.precision = "bf16"
+    g_p = camera.zernike_coeffs_train.grad.cpu().flatten()
+    cos_p, rl2_p = _cos(g_p, g_o), ((g_p.double() - g_o.double()).norm() / g_o.double().norm()).item()
+    out_err_p = ((out_p.detach().cpu().double() - out_o.detach().double()).abs().max() / out_o.detach().abs().max()).item()
+    worst_p = 1.0
+    for n, p in encoder.named_parameters():
+        if p.requires_grad and p.dim() == 4:
+            worst_p = min(worst_p, _cos(p.grad, ref_grads[n].grad))
+    print(f"fp32 PRODUCT mode: encoder output {out_err_p:.2e}; lens gradient vs oracle (full loss): cos {cos_p:.6f}, rel L2 {rl2_p:.3e}; "
+          f"smallest weight-gradient cosine {worst_p:.5f}")
+    assert out_err_p < 5e-3 and abs(float(loss_p.detach()) - float(loss_o.detach())) < 1e-5 * abs(float(loss_o.detach()))
+    assert cos_p > 0.999 and rl2_p < 5e-2 and worst_p > 0.99

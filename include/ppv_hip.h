@@ -233,6 +233,15 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
                    int Ws, int Cs, int Ho, int Wo, int N, int R, int S, int stride, int pad, ppv_stream_t stream, PpvWgradReduce* deferred);
 int ppv_wgrad_reduce_multi(const PpvWgradReduce* probs, int n, ppv_stream_t stream);
 
+/* Two 1x1 / unit-stride weight gradients of different shapes in ONE launch + one reduce launch (round 6: conv1 of the bottleneck whose
+ * backward just finished and conv3 of the next one; each problem takes half the chip with m-slices twice as long -- half the slabs, half
+ * the per-workgroup fixed cost per unit of work).  G[k] [B,H[k],W[k],N[k]] bf16, X[k] [B,H[k],W[k],Cs[k]] bf16 -> dW[k] [N[k]][Cs[k]]
+ * f32; N[k] % 256 == 0, Cs[k] % 128 == 0.  scratch: scratch_bytes bytes, no zeroing (PPV_ERR_WORKSPACE when too small: the two problems'
+ * ppv_conv_wgrad_scratch_bytes added are always enough).  ppv_conv_wgrad_pair_supported: 1 where this form runs. */
+int ppv_conv_wgrad_pair_supported(int B, int H0, int W0, int Cs0, int N0, int H1, int W1, int Cs1, int N1);
+int ppv_conv_wgrad_pair(const void* G0, const void* X0, float* dW0, int H0, int W0, int Cs0, int N0, const void* G1, const void* X1, float* dW1,
+                        int H1, int W1, int Cs1, int N1, void* scratch, size_t scratch_bytes, const void* zero_page, int B, ppv_stream_t stream);
+
 /* P <= 24 weight gradients of ONE 1x1 / unit-stride shape in one launch, each reduced over all its rows by one workgroup per
  * tile (no split-M slabs, no scratch, no reduce launch): G[p] [B,H,W,N] bf16, X[p] [B,H,W,Cs] bf16 -> out[p] [N][Cs] f32.
  * Host arrays of device pointers.  Replaces P cuDNN weight-gradient calls of the bottleneck 1x1 convolutions behind

@@ -126,6 +126,8 @@ PROTOTYPES = {
     "ppv_gru_out": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "ppv_conv_set_variant": (_I, [_I]),
     "ppv_conv_wgrad_scratch_bytes": (_Z, [_L, _I, _I, _I, _I]),
+    "ppv_conv_wgrad_pair_supported": (_I, [_I] * 9),
+    "ppv_conv_wgrad_pair": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _I, _P]),
     "ppv_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "ppv_conv_wgrad_group": (_I, [_P, _P, _P, _I, _P] + [_I] * 5 + [_P]),
     "ppv_wgrad_set_variant": (_I, [_I]),

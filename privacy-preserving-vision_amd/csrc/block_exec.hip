@@ -56,7 +56,41 @@ int ppv_bottleneck_fwd(const PpvBottleneckFwd* a, hipStream_t stream) {
 namespace {
 // event record on `main` + wait on `side` through the guarded per-device event ring of trunk_plan.hip
 int fork_to(hipStream_t main, hipStream_t side) { return ppv_stream_fork(main, side); }
+
+// Paired weight gradients (round 6, ppv_conv_wgrad_pair): inside a ppv_trunk_bwd call (wgrad_pair_begin .. wgrad_pair_end) an identity
+// bottleneck does NOT launch its conv1 weight gradient; the next bottleneck to run launches it together with its own conv3 weight
+// gradient (both operands exist by then; the buffers are per block and outlive the call).  Per thread: the executor is re-entrant.
+struct PendingW1 {
+    bool valid;
+    const void *G, *X, *zero_page;
+    float* dW;
+    void* scratch;
+    int B, H, W, Cs, N;
+};
+thread_local PendingW1 t_pend = {false, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+thread_local size_t t_pair_scratch = 0;         // > 0: pairing is on, bytes of the shared slab region
 }  // namespace
+
+}  // extern "C" (the executor-internal hooks below have C++ linkage: trunk_plan.hip declares them in namespace ppv)
+
+namespace ppv {
+void wgrad_pair_begin(size_t scratch_bytes) { t_pair_scratch = scratch_bytes; t_pend.valid = false; }
+// the weight gradient still pending (if any) on its own; `main` != null: `ws` first waits for what `main` has enqueued so far
+int wgrad_pair_flush(hipStream_t main, hipStream_t ws) {
+    if (!t_pend.valid) return PPV_OK;
+    t_pend.valid = false;
+    if (main && main != ws) { if (int e = ppv_stream_fork(main, ws)) return e; }
+    return ppv_conv_wgrad(t_pend.G, t_pend.X, t_pend.dW, t_pend.scratch, t_pend.zero_page, t_pend.B, t_pend.H, t_pend.W, t_pend.Cs, t_pend.H, t_pend.W,
+                          t_pend.N, 1, 1, 1, 0, ws);
+}
+int wgrad_pair_end(hipStream_t main, hipStream_t ws) {
+    const int e = wgrad_pair_flush(main, ws);
+    t_pair_scratch = 0;
+    return e;
+}
+}  // namespace ppv
+
+extern "C" {
 
 int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t side) {
     if (!a) return PPV_ERR_NULL;
@@ -72,9 +106,19 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     char* wsb = (char*)a->wscratch;
     // bn3 backward (gradient arrives masked by the block output's ReLU; sums possibly taken by the data-gradient launch that produced it)
     if ((e = ppv_bn_bwd(a->g, nullptr, a->x3, a->c3, (double)M, a->gx3, nullptr, a->dg3, a->db3, a->part3, a->kc3, M, C3, 0, a->part3_ready ? 2 : 1, main))) return e;
+    const bool pairing = t_pair_scratch > 0 && !defer;
     if (a->dw3) {
         if (side && (e = fork_to(main, side))) return e;
-        if ((e = ppv_conv_wgrad_ex(a->gx3, a->y2, a->dw3, wsb, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws, defer ? &red[0] : nullptr))) return e;
+        if (pairing && t_pend.valid && t_pend.B == B &&
+            ppv_conv_wgrad_pair_supported(B, t_pend.H, t_pend.W, t_pend.Cs, t_pend.N, H, W, P, C3)) {
+            // conv1 of the bottleneck that ran before this one + this conv3: one launch, one reduce launch
+            t_pend.valid = false;
+            if ((e = ppv_conv_wgrad_pair(t_pend.G, t_pend.X, t_pend.dW, t_pend.H, t_pend.W, t_pend.Cs, t_pend.N, a->gx3, a->y2, a->dw3, H, W, P, C3, wsb,
+                                         t_pair_scratch, a->zero_page, B, ws))) return e;
+        } else {
+            if (pairing && (e = ppv::wgrad_pair_flush(nullptr, ws))) return e;     // (a pending one of another shape: on its own, same point)
+            if ((e = ppv_conv_wgrad_ex(a->gx3, a->y2, a->dw3, wsb, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws, defer ? &red[0] : nullptr))) return e;
+        }
     }
     // conv3 data gradient (+ bn2's sums and recomputed ReLU mask)
     if (a->red2) e = ppv_conv_gemm_red(a->gx3, a->wd3, a->gy2, a->part2, a->x2, a->c2, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 8, main);
@@ -91,9 +135,15 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     if (e) return e;
     if ((e = ppv_bn_bwd(a->gy1, nullptr, a->x1, a->c1, (double)M, a->gx1, nullptr, a->dg1, a->db1, a->part1, a->kc1, M, P, a->red1 ? 0 : 2, a->red1 ? 2 : 1, main))) return e;
     if (a->dw1) {
-        if (side && (e = fork_to(main, side))) return e;
-        if ((e = ppv_conv_wgrad_ex(a->gx1, a->xin, a->dw1, wsb + (defer ? 2 * a->wstride : 0), a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws, defer ? &red[2] : nullptr))) return e;
-        if (defer && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;
+        if (pairing && P % 256 == 0) {
+            // left for the next bottleneck's call (or the executor's flush): operands gx1 / xin live in per-block buffers
+            if ((e = ppv::wgrad_pair_flush(main, ws))) return e;
+            t_pend = PendingW1{true, a->gx1, a->xin, a->zero_page, a->dw1, (void*)wsb, B, H, W, C3, P};
+        } else {
+            if (side && (e = fork_to(main, side))) return e;
+            if ((e = ppv_conv_wgrad_ex(a->gx1, a->xin, a->dw1, wsb + (defer ? 2 * a->wstride : 0), a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws, defer ? &red[2] : nullptr))) return e;
+            if (defer && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;
+        }
     }
     if (defer && !a->dw1 && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;      // (a block whose conv1 alone is frozen)
     // conv1 data gradient + the identity branch's gradient + the block input's ReLU mask (+ the sums bn3 of the NEXT block to run needs)

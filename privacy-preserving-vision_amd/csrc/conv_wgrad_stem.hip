@@ -422,6 +422,39 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
     wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0, tl);
 }
 
+// TWO 1x1 / unit-stride weight gradients of DIFFERENT shapes in one launch (round 6): conv1 of the bottleneck that just finished its
+// backward and conv3 of the next one to run become ready within ~75 us of each other (trunk_plan.hip).  Launched one after the other each
+// fills the chip with 8 tiles x 32 m-slices: 16 stages per workgroup, of whose ~35 us ~15 are fixed (first DMA round trip, address
+// set-up, the 128-KB slab store: tools/look_timeline.py measures the same 4.8 us of 23 on the forward tile) and 32 slabs per problem are
+// written and read back.  Together each problem takes half the workgroups: 16 m-slices of 32 stages -- half the slabs, half the
+// prologues / slab stores per unit of work, one launch and one reduce launch instead of two each.  Body: wgrad_pipe_body, unchanged.
+struct WgradPair {
+    const bf16_t* G[2];
+    const bf16_t* X[2];
+    float* slabs[2];
+    WgradGeom g[2];
+    int wgs0;                // workgroups of problem 0 (a multiple of 8: the XCD decode of problem 1 starts on XCD 0)
+};
+
+template <int TN, int NSTAGE>
+__global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pair_kernel(WgradPair p, const bf16_t* __restrict__ zero_page) {
+    const int which = (int)blockIdx.x >= p.wgs0 ? 1 : 0;
+    const int bx = which ? (int)blockIdx.x - p.wgs0 : (int)blockIdx.x;
+    const WgradGeom g = which ? p.g[1] : p.g[0];
+    const bf16_t* G = which ? p.G[1] : p.G[0];
+    const bf16_t* X = which ? p.X[1] : p.X[0];
+    float* dW = which ? p.slabs[1] : p.slabs[0];
+    const int ctiles = g.Cs / 128;
+    const int tiles = (g.N / TN) * ctiles;
+    const int xcd = bx & 7, idx = bx >> 3;
+    const int zslice = (idx / tiles) * 8 + xcd, tl = idx % tiles;
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % (g.N / TN)) * TN, c0 = (tl / (g.N / TN)) * 128;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    wgrad_pipe_body<TN, NSTAGE>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, 0, c0, false, tl);
+}
+
 // Several weight gradients of ONE shape (1x1, unit stride: the conv1 / conv3 of a layer's bottlenecks) in one launch, each reduced
 // over ALL its rows by one workgroup per tile: no split-M slabs, no reduce launch, the result goes straight to the torch tensor.
 // tools/micro/wgrad_longk.py: the slab form costs 59-64 us per layer-3 problem (kernel + reduce), the un-split steady state 39-43 us.
@@ -1923,6 +1956,65 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
     if (g.native_slabs) wgrad_reduce_native_kernel<0><<<(unsigned)((elems / 4 + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab, TN);
     else wgrad_to_torch_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>(slabs, dW_out, N, Cs, R, S, nslab);
     return ppv_last_error();
+}
+
+// Two 1x1 / unit-stride weight gradients in ONE launch (conv_wgrad_pair_kernel) + ONE reduce launch: G[k] [B,H[k],W[k],N[k]] bf16,
+// X[k] [B,H[k],W[k],Cs[k]] bf16 -> dW[k] [N[k]][Cs[k]] f32 (torch layout of a 1x1 weight).  N[k] % 256 == 0, Cs[k] % 128 == 0.
+// scratch: scratch_bytes bytes (PPV_ERR_WORKSPACE if the two slab sets do not fit).  ppv_conv_wgrad_pair_supported: 1 where this form
+// runs (callers fall back to two ppv_conv_wgrad calls elsewhere).
+int ppv_conv_wgrad_pair_supported(int B, int H0, int W0, int Cs0, int N0, int H1, int W1, int Cs1, int N1) {
+    if (B < 1 || N0 % 256 || N1 % 256 || Cs0 % 128 || Cs1 % 128) return 0;
+    const long M0 = (long)B * H0 * W0, M1 = (long)B * H1 * W1;
+    if (M0 < 64 * 64 || M1 < 64 * 64 || M0 >= (1L << 24) || M1 >= (1L << 24) || M0 % 64 || M1 % 64) return 0;
+    return (g_wgrad_variant & 0xff) == 0 && !(g_wgrad_variant & 0x1f00) && wgrad_native_slabs() ? 1 : 0;
+}
+
+int ppv_conv_wgrad_pair(const void* G0, const void* X0, float* dW0, int H0, int W0, int Cs0, int N0, const void* G1, const void* X1, float* dW1,
+                        int H1, int W1, int Cs1, int N1, void* scratch, size_t scratch_bytes, const void* zero_page, int B, hipStream_t stream) {
+    if (!G0 || !X0 || !dW0 || !G1 || !X1 || !dW1 || !scratch || !zero_page) return PPV_ERR_NULL;
+    if (!ppv_conv_wgrad_pair_supported(B, H0, W0, Cs0, N0, H1, W1, Cs1, N1)) return PPV_ERR_BAD_SIZE;
+    static const int target = getenv("PPV_WGRAD_PAIR_WGS") ? atoi(getenv("PPV_WGRAD_PAIR_WGS")) : 128;    // workgroups per problem
+    WgradPair p;
+    PpvWgradReduce red[2];
+    const void* Gs[2] = {G0, G1};
+    const void* Xs[2] = {X0, X1};
+    float* outs[2] = {dW0, dW1};
+    const int Hs_[2] = {H0, H1}, Ws_[2] = {W0, W1}, Cs_[2] = {Cs0, Cs1}, Ns_[2] = {N0, N1};
+    size_t off = 0;
+    unsigned grid = 0;
+    for (int k = 0; k < 2; ++k) {
+        WgradGeom& g = p.g[k];
+        g.B = B; g.Hs = Hs_[k]; g.Ws = Ws_[k]; g.Cs = Cs_[k]; g.Ho = Hs_[k]; g.Wo = Ws_[k]; g.N = Ns_[k]; g.R = 1; g.S = 1; g.st = 1; g.pad = 0;
+        g.M = (long)B * Hs_[k] * Ws_[k];
+        g.xcc_slabs = 0; g.pf_dist = 0; g.chunked = 0; g.native_slabs = 1; g.xcd_group = 1;
+        int TN, sps;
+        long splits;
+        wgrad_plan(g.M, g.N, 1, 1, g.Cs, 3, &TN, &splits, &sps, target < 16 ? 16 : target);
+        if (TN != 256) return PPV_ERR_BAD_SIZE;
+        g.stages_per_split = sps;
+        g.splits = (int)splits;
+        const long elems = (long)g.N * g.Cs;
+        g.slab_elems = elems;
+        const int tiles = (g.N / 256) * (g.Cs / 128);
+        const unsigned wgs = (unsigned)(8 * ((splits + 7) / 8) * tiles);
+        if (k == 0) p.wgs0 = (int)wgs;
+        grid += wgs;
+        p.G[k] = (const bf16_t*)Gs[k]; p.X[k] = (const bf16_t*)Xs[k];
+        p.slabs[k] = (float*)((char*)scratch + off);
+        red[k] = PpvWgradReduce{p.slabs[k], outs[k], g.N, g.Cs, 1, 1, (int)splits, 256, 0, (int)((elems / 4 + 255) / 256)};
+        off += (size_t)splits * elems * sizeof(float);
+        off = (off + 255) & ~(size_t)255;
+    }
+    if (off > scratch_bytes) return PPV_ERR_WORKSPACE;
+    constexpr int lds = 3 * 3 * 64 * 256;
+    static PpvDevOnce attr_once;
+    if (attr_once.need()) {
+        PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pair_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_once.done();
+    }
+    conv_wgrad_pair_kernel<256, 3><<<grid, 512, lds, stream>>>(p, (const bf16_t*)zero_page);
+    if (int e = ppv_last_error()) return e;
+    return ppv_wgrad_reduce_multi(red, 2, stream);
 }
 
 // P <= 24 weight gradients of one 1x1 / unit-stride shape in one launch, each reduced over all its rows (no scratch, no reduce

@@ -16,6 +16,7 @@
 //   work       : the gradients that never leave a block; every block has its own (the side stream reads them for the weight gradients,
 //                so a buffer shared between blocks would need a cross-stream wait per block).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include "ppv_common.h"
 #include "ppv_hip.h"
@@ -23,6 +24,10 @@
 namespace ppv {                            // conv_gemm.hip (declared in conv_common.h): compact addend of the next ppv_conv_gemm* call
 void conv_set_addend_compact(bool on);
 bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N);
+// block_exec.hip: paired weight gradients across consecutive identity bottlenecks (ppv_conv_wgrad_pair)
+void wgrad_pair_begin(size_t scratch_bytes);
+int wgrad_pair_flush(hipStream_t main, hipStream_t ws);
+int wgrad_pair_end(hipStream_t main, hipStream_t ws);
 }
 
 namespace {
@@ -297,11 +302,21 @@ int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, co
         if (g_kind != 0)
             TRY(ppv_adaptive_pool_bwd(g_top, A + L.gtop, cells, B, o.H2, o.W2, 4 * o.P, E, g_kind == 1, main));
     }
+    // PPV_WGRAD_PAIR=1: conv1's weight gradient of an identity bottleneck waits for the next bottleneck's conv3 and the two run as one launch
+    // (ppv_conv_wgrad_pair); flushed before every projection block and at the end of this call (a gradient bucket is complete when it returns)
+    static const int pair_on = getenv("PPV_WGRAD_PAIR") ? atoi(getenv("PPV_WGRAD_PAIR")) : 0;
+    if (pair_on && !d->wgrad_reduce3) ppv::wgrad_pair_begin(L.wstride);
+    struct PairGuard {
+        hipStream_t m, w; bool on; int rc = PPV_OK; bool done = false;
+        int finish() { if (on && !done) { done = true; rc = ppv::wgrad_pair_end(m, w); } return rc; }
+        ~PairGuard() { (void)finish(); }
+    } pair_guard{main, ws, pair_on && !d->wgrad_reduce3};
     for (int i = blk_hi - 1; i >= blk_lo; i--) {
         const BlkOff& o = L.b[i];
         const PpvTrunkConv &k1 = conv_of(cv, i, 0), &k2 = conv_of(cv, i, 1), &k3 = conv_of(cv, i, 2), &kd = conv_of(cv, i, 3);
         const int P = o.P, C3 = 4 * P;
         const long M1 = (long)B * o.Hin * o.Win, M2 = (long)B * o.H2 * o.W2;
+        if (o.proj && pair_guard.on) TRY(ppv::wgrad_pair_flush(main, ws));
         // gradient w.r.t. this block's output (masked by its ReLU where it was produced) and whether bn3's sums came with it
         const void* g = (i == nb - 1) ? ((g_kind == 0) ? g_top : (const void*)(A + L.gtop)) : (const void*)(A + L.b[i + 1].gin);
         const int part3_ready = (i < nb - 1) && red_ok(M2, C3);
@@ -383,6 +398,7 @@ int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, co
         else
             TRY(ppv_conv_gemm(A + o.gx1, k1.wd, A + o.gin, nullptr, A + o.gind, xin_bits, zero_page, B, o.Hin, o.Win, P, o.Hin, o.Win, o.Cin, 1, 1, 1, 0, 1, 0, 0, main));
     }
+    TRY(pair_guard.finish());
     if (blk_lo == 0) {
         // ---- stem: max-pool + ReLU + BatchNorm backward in two passes over the pooled tensors, then the 7x7 data gradient
         const int Hs = d->H / 2, Ws = d->W / 2;

@@ -1,0 +1,83 @@
+"""ppv_conv_wgrad_pair (round 6: conv1's weight gradient of one bottleneck and conv3's of the next in ONE launch) against two ppv_conv_wgrad
+calls and against torch CPU autograd; and the whole-trunk executor with PPV_WGRAD_PAIR=1 against PPV_WGRAD_PAIR=0 (separate processes: the
+switch is read once).  Reference semantics: autograd of the 1x1 convolutions of torchvision's Bottleneck, Image_Caption/models.py:17-21."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("B,H", [(16, 16), (128, 16), (33, 16)])
+def test_pair_equals_two_single_launches(B, H):
+    import ppv_amd.convops as co
+    from ppv_amd._lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(0)
+    P = 256
+    g1 = torch.randn(B, H, H, P, generator=g).bfloat16().cuda()           # gradient of conv1's output, conv1: 1024 -> 256
+    x1 = torch.randn(B, H, H, 4 * P, generator=g).bfloat16().cuda()
+    g3 = torch.randn(B, H, H, 4 * P, generator=g).bfloat16().cuda()       # gradient of conv3's output, conv3: 256 -> 1024
+    x3 = torch.randn(B, H, H, P, generator=g).bfloat16().cuda()
+    L = co.L()
+    assert L.ppv_conv_wgrad_pair_supported(B, H, H, 4 * P, P, H, H, P, 4 * P) == (1 if B * H * H >= 4096 and (B * H * H) % 64 == 0 else 0)
+    if not L.ppv_conv_wgrad_pair_supported(B, H, H, 4 * P, P, H, H, P, 4 * P):
+        return
+    want1 = co.conv_wgrad(g1, x1, 1, 1, 1, 0)
+    want3 = co.conv_wgrad(g3, x3, 1, 1, 1, 0)
+    nbytes = co.wgrad_scratch_bytes(B * H * H, P, 1, 1, 4 * P) + co.wgrad_scratch_bytes(B * H * H, 4 * P, 1, 1, P)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    d1 = torch.empty(P, 4 * P, 1, 1, device="cuda")
+    d3 = torch.empty(4 * P, P, 1, 1, device="cuda")
+    check(L.ppv_conv_wgrad_pair(ptr(g1), ptr(x1), ptr(d1), H, H, 4 * P, P, ptr(g3), ptr(x3), ptr(d3), H, H, P, 4 * P, ptr(scratch), nbytes,
+                                ptr(co.zero_page(g1.device)), B, stream_ptr()), "ppv_conv_wgrad_pair")
+    torch.cuda.synchronize()
+    for got, want in ((d1, want1), (d3, want3)):
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-6       # same products, another summation order of the m-slices
+    # and against f64 on a slice of the rows' contribution: the full product on the CPU
+    ref1 = torch.einsum("mn,mc->nc", g1.float().view(-1, P).cpu().double(), x1.float().view(-1, 4 * P).cpu().double())
+    assert ((d1.view(P, 4 * P).cpu().double() - ref1).abs().max() / ref1.abs().max()).item() < 1e-5
+    # too small a workspace is refused before any launch
+    assert L.ppv_conv_wgrad_pair(ptr(g1), ptr(x1), ptr(d1), H, H, 4 * P, P, ptr(g3), ptr(x3), ptr(d3), H, H, P, 4 * P, ptr(scratch), 1024,
+                                 ptr(co.zero_page(g1.device)), B, stream_ptr()) == -1004
+
+
+_CHILD = r'''
+import sys, json
+sys.path.insert(0, %r)
+import torch
+import ppv_amd
+from ppv_amd.encoder import Encoder
+torch.manual_seed(2)
+enc = Encoder(layers=(1, 1, 3, 2)).cuda().train()
+img = torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(0)).cuda().requires_grad_(True)
+out = enc(img)
+w = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).cuda()
+(out * w).sum().backward()
+torch.cuda.synchronize()
+res = {n: [float(p.grad.double().sum()), float(p.grad.double().norm())] for n, p in enc.named_parameters() if p.grad is not None}
+res["__img"] = [float(img.grad.double().sum()), float(img.grad.double().norm())]
+print(json.dumps(res))
+''' % ROOT
+
+
+def test_executor_with_paired_weight_gradients_equals_the_unpaired_schedule():
+    import json
+    outs = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _CHILD], env=dict(os.environ, PPV_WGRAD_PAIR=flag), capture_output=True, text=True, timeout=600)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert rows, r.stderr[-2000:]
+        outs.append(json.loads(rows[-1]))
+    a, b = outs
+    assert a.keys() == b.keys() and len(a) > 60
+    worst = 0.0
+    for k in a:
+        worst = max(worst, abs(a[k][1] - b[k][1]) / (abs(a[k][1]) + 1e-12))
+    print(f"paired vs unpaired schedule: worst relative difference of a gradient norm {worst:.1e} over {len(a)} tensors")
+    # the paired launches sum their m-slices in another order; everything else is the same arithmetic (the BatchNorm atomics give the
+    # bf16 trunk a run-to-run band of its own: norms agree to 1e-3 between ANY two runs)
+    assert worst < 5e-3

@@ -3,7 +3,10 @@ step and enqueue it at the same moment -- what N interpreters on one host cost e
 threads, the kernel driver's submission path).  Every rank measures the host time to enqueue one step into an EMPTY queue (2 steps
 after a synchronise, repeated), the number that must stay below the device's ~22 ms for the device to set the pace.
 
-    python tools/host_contention.py [N=6] [cores_per_rank=2] [batch=8]      # parent: spawns the ranks, prints one JSON line
+    python tools/host_contention.py [N=6] [cores_per_rank=2] [batch=8] [hogs=0]      # parent: spawns the ranks, prints one JSON line
+
+hogs (round 6): that many extra processes, each pinned to the next cores_per_rank cores, run an interpreter-bound loop for the duration of
+the "together" round WITHOUT touching the GPU -- the host load of ranks 7 and 8 of an 8-GPU node on a box whose card admits six processes.
 
 The device is shared here, so a small batch keeps the device time of a step short (the launch sequence, and with it the host work,
 is the same at any batch); at most 6 processes may use the card on the GPU box."""
@@ -47,19 +50,43 @@ def child(rank, n, cores, batch, go_at):
           flush=True)
 
 
+def hog(rank, cores, until):
+    first = rank * cores
+    try:
+        os.sched_setaffinity(0, set(range(first, first + cores)))
+    except Exception:
+        pass
+    d, n = {}, 0
+    while time.time() < until:                                # interpreter + allocator traffic, like a rank's enqueue loop
+        for i in range(20000):
+            d[i & 1023] = [i, str(i)]
+        n += 1
+    print(json.dumps({"hog": rank, "loops": n}), flush=True)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child(*(int(v) for v in sys.argv[2:6]), float(sys.argv[6]))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--hog":
+        hog(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
+        return
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     cores = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    out = {"ranks": n, "cores_per_rank": cores, "batch": batch, "host_cores": os.cpu_count()}
+    hogs = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    out = {"ranks": n, "cores_per_rank": cores, "batch": batch, "host_cores": os.cpu_count(), "cpu_only_hogs": hogs}
     for label, count in (("alone", 1), ("together", n)):
         go_at = time.time() + (75 if count > 1 else 60)      # model build + first torch import on a fresh box
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), str(n), str(cores), str(batch), str(go_at)],
                                   stdout=subprocess.PIPE, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(count)]
+        hps = []
+        if count > 1:
+            hps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--hog", str(n + h), str(cores), str(go_at + 30)], stdout=subprocess.PIPE, text=True)
+                   for h in range(hogs)]
         res = []
+        for p in hps:
+            p.communicate(timeout=600)
         for p in procs:
             o, _ = p.communicate(timeout=600)
             res += [json.loads(l) for l in o.splitlines() if l.startswith("{")]

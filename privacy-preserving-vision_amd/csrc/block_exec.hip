@@ -66,26 +66,40 @@ struct PendingW1 {
     float* dW;
     void* scratch;
     int B, H, W, Cs, N;
+    int R = 1, pad = 0;
 };
 thread_local PendingW1 t_pend = {false, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+thread_local PendingW1 t_pend2 = {false, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};     // conv2's (PPV_WGRAD_FORKS=3)
 thread_local size_t t_pair_scratch = 0;         // > 0: pairing is on, bytes of the shared slab region
+thread_local bool t_hold_next = false;          // PPV_WGRAD_FORKS=3 inside a ppv_trunk_bwd call: conv2 / conv1 wait for the next block's fork
+
+int launch_pending(PendingW1& p, hipStream_t ws) {
+    if (!p.valid) return PPV_OK;
+    p.valid = false;
+    return ppv_conv_wgrad(p.G, p.X, p.dW, p.scratch, p.zero_page, p.B, p.H, p.W, p.Cs, p.H, p.W, p.N, p.R, p.R, 1, p.pad, ws);
+}
 }  // namespace
 
 }  // extern "C" (the executor-internal hooks below have C++ linkage: trunk_plan.hip declares them in namespace ppv)
 
 namespace ppv {
-void wgrad_pair_begin(size_t scratch_bytes) { t_pair_scratch = scratch_bytes; t_pend.valid = false; }
-// the weight gradient still pending (if any) on its own; `main` != null: `ws` first waits for what `main` has enqueued so far
-int wgrad_pair_flush(hipStream_t main, hipStream_t ws) {
-    if (!t_pend.valid) return PPV_OK;
-    t_pend.valid = false;
-    if (main && main != ws) { if (int e = ppv_stream_fork(main, ws)) return e; }
-    return ppv_conv_wgrad(t_pend.G, t_pend.X, t_pend.dW, t_pend.scratch, t_pend.zero_page, t_pend.B, t_pend.H, t_pend.W, t_pend.Cs, t_pend.H, t_pend.W,
-                          t_pend.N, 1, 1, 1, 0, ws);
+void wgrad_pair_begin(size_t scratch_bytes, bool defer_to_next_block) {
+    t_pair_scratch = scratch_bytes;
+    t_hold_next = defer_to_next_block;
+    t_pend.valid = t_pend2.valid = false;
+}
+// the weight gradients still pending (if any) on their own; join: `ws` first waits for what `main` has enqueued so far (`main` may be the
+// null stream: a flag, not the pointer, says whether to wait)
+int wgrad_pair_flush(hipStream_t main, hipStream_t ws, bool join) {
+    if (!t_pend.valid && !t_pend2.valid) return PPV_OK;
+    if (join && main != ws) { if (int e = ppv_stream_fork(main, ws)) return e; }
+    if (int e = launch_pending(t_pend2, ws)) return e;
+    return launch_pending(t_pend, ws);
 }
 int wgrad_pair_end(hipStream_t main, hipStream_t ws) {
-    const int e = wgrad_pair_flush(main, ws);
+    const int e = wgrad_pair_flush(main, ws, true);
     t_pair_scratch = 0;
+    t_hold_next = false;
     return e;
 }
 }  // namespace ppv
@@ -107,7 +121,14 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     // bn3 backward (gradient arrives masked by the block output's ReLU; sums possibly taken by the data-gradient launch that produced it)
     if ((e = ppv_bn_bwd(a->g, nullptr, a->x3, a->c3, (double)M, a->gx3, nullptr, a->dg3, a->db3, a->part3, a->kc3, M, C3, 0, a->part3_ready ? 2 : 1, main))) return e;
     const bool pairing = t_pair_scratch > 0 && !defer;
-    if (a->dw3) {
+    // PPV_WGRAD_FORKS (round 6 A/B): every fork is an event record on `main`, and the kernel trace shows ~6 us of idle main chain behind each
+    // (none between the forward launches).  0 (default): one fork per weight gradient (three per block); 1: conv2's weight gradient waits
+    // for conv1's fork (two per block); 2: all three behind ONE fork after bn1' (operands up to ~150 us older when they are read).
+    static const int fork_mode = getenv("PPV_WGRAD_FORKS") ? atoi(getenv("PPV_WGRAD_FORKS")) : 0;
+    // 3 (inside ppv_trunk_bwd): ONE fork per block, behind bn3': this block's conv3 + conv2 / conv1 of the block that ran before
+    const bool hold = t_hold_next && fork_mode == 3 && !defer && !pairing;
+    const int fm = (pairing || defer) ? 0 : (fork_mode == 3 ? (hold ? 3 : 1) : fork_mode);
+    if (a->dw3 && fm != 2) {
         if (side && (e = fork_to(main, side))) return e;
         if (pairing && t_pend.valid && t_pend.B == B &&
             ppv_conv_wgrad_pair_supported(B, t_pend.H, t_pend.W, t_pend.Cs, t_pend.N, H, W, P, C3)) {
@@ -116,7 +137,7 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
             if ((e = ppv_conv_wgrad_pair(t_pend.G, t_pend.X, t_pend.dW, t_pend.H, t_pend.W, t_pend.Cs, t_pend.N, a->gx3, a->y2, a->dw3, H, W, P, C3, wsb,
                                          t_pair_scratch, a->zero_page, B, ws))) return e;
         } else {
-            if (pairing && (e = ppv::wgrad_pair_flush(nullptr, ws))) return e;     // (a pending one of another shape: on its own, same point)
+            if ((pairing || hold) && (e = ppv::wgrad_pair_flush(main, ws, false))) return e;     // (pending ones: on their own, same point; forked above)
             if ((e = ppv_conv_wgrad_ex(a->gx3, a->y2, a->dw3, wsb, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws, defer ? &red[0] : nullptr))) return e;
         }
     }
@@ -125,7 +146,7 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     else e = ppv_conv_gemm(a->gx3, a->wd3, a->gy2, nullptr, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 0, 0, main);
     if (e) return e;
     if ((e = ppv_bn_bwd(a->gy2, nullptr, a->x2, a->c2, (double)M, a->gx2, nullptr, a->dg2, a->db2, a->part2, a->kc2, M, P, a->red2 ? 0 : 2, a->red2 ? 2 : 1, main))) return e;
-    if (a->dw2) {
+    if (a->dw2 && fm == 0) {
         if (side && (e = fork_to(main, side))) return e;
         if ((e = ppv_conv_wgrad_ex(a->gx2, a->y1, a->dw2, wsb + (defer ? a->wstride : 0), a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws, defer ? &red[1] : nullptr))) return e;
     }
@@ -134,10 +155,19 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     else e = ppv_conv_gemm(a->gx2, a->wd2, a->gy1, nullptr, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 0, 0, main);
     if (e) return e;
     if ((e = ppv_bn_bwd(a->gy1, nullptr, a->x1, a->c1, (double)M, a->gx1, nullptr, a->dg1, a->db1, a->part1, a->kc1, M, P, a->red1 ? 0 : 2, a->red1 ? 2 : 1, main))) return e;
-    if (a->dw1) {
+    if (fm == 3) {
+        if (!a->dw3 && (e = ppv::wgrad_pair_flush(main, ws, true))) return e;          // (no fork of this block took the pending ones along)
+        if (a->dw2) { t_pend2 = PendingW1{true, a->gx2, a->y1, a->zero_page, a->dw2, (void*)wsb, B, H, W, P, P, 3, 1}; }
+        if (a->dw1) { t_pend = PendingW1{true, a->gx1, a->xin, a->zero_page, a->dw1, (void*)wsb, B, H, W, C3, P, 1, 0}; }
+    } else if (fm != 0 && (a->dw3 || a->dw2 || a->dw1)) {
+        if (side && (e = fork_to(main, side))) return e;
+        if (fm == 2 && a->dw3 && (e = ppv_conv_wgrad(a->gx3, a->y2, a->dw3, wsb, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws))) return e;
+        if (a->dw2 && (e = ppv_conv_wgrad(a->gx2, a->y1, a->dw2, wsb, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws))) return e;
+        if (a->dw1 && (e = ppv_conv_wgrad(a->gx1, a->xin, a->dw1, wsb, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws))) return e;
+    } else if (a->dw1) {
         if (pairing && P % 256 == 0) {
             // left for the next bottleneck's call (or the executor's flush): operands gx1 / xin live in per-block buffers
-            if ((e = ppv::wgrad_pair_flush(main, ws))) return e;
+            if ((e = ppv::wgrad_pair_flush(main, ws, true))) return e;
             t_pend = PendingW1{true, a->gx1, a->xin, a->zero_page, a->dw1, (void*)wsb, B, H, W, C3, P};
         } else {
             if (side && (e = fork_to(main, side))) return e;

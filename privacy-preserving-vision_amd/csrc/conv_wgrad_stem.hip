@@ -422,6 +422,256 @@ __global__ __launch_bounds__(TN * 2, 1) void conv_wgrad_pipe_kernel(const bf16_t
     wgrad_pipe_body<TN, NSTAGE, PF>(G, X, dW + (long)zslice * g.slab_elems, zero_page, g, m_begin, m_end, n0, tap, c0, g.slab_elems == 0, tl);
 }
 
+// ----------------------------------------------------------------------------- 1x1 / unit stride: linear addresses (round 6)
+// The ISA of conv_wgrad_pipe_kernel<256, 3> showed ~500 instructions per 64-row stage and wave for 32 MFMAs: the general stage() rebuilds
+// every source address from (m, tap, geometry) with a float-reciprocal divmod, a zero-page select and a `chunked` branch per load (six
+// branch ladders per stage), and every transposed read recomputes row * 256 + (block ^ key) * 32: ~300 vector-ALU instructions x 4
+// cycles per wave and stage beside 32 x 16 cycles of MFMA, two waves per SIMD -- the loop was bound by vector-instruction ISSUE, as the
+// first nine-tap 3x3 kernel was.  For a 1x1 / unit-stride / unpadded convolution with M % 64 == 0 both operands are plain
+// row-major matrices: a lane's six source pointers advance by a constant per stage, and its eight LDS read offsets are fixed (the
+// second row group and the second k-half are immediate offsets of the DS instruction).  Same tile (256 n x 128 c, eight waves of 64 x 64),
+// same ring, same slabs as wgrad_pipe_body<256, NSTAGE>: bit-identical results.
+template <int NSTAGE>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_lin_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                                float* __restrict__ dW, WgradGeom g) {
+    constexpr int TN = 256, NW = 8, NH = 2, HALF = 64 * 256, STAGE_BYTES = (NH + 1) * HALF, GI = 4, XI = 2, L = GI + XI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntile = g.N / TN, tiles = ntile * (g.Cs / 128);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int zslice = (idx / tiles) * 8 + xcd, tl = idx % tiles;
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % ntile) * TN, c0 = (tl / ntile) * 128;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    const int nst = (int)((m_end - m_begin) >> 6);
+    if (nst <= 0) return;
+
+    // ---- staging: per lane six source pointers, advanced by one 64-row stage per call
+    const int rli = lane >> 4, lch = lane & 15;
+    const char* pg[GI];
+    const char* px[XI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        const int q = i * NW + wave, half = q >> 4, row = (q & 15) * 4 + rli;
+        const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+        pg[i] = reinterpret_cast<const char*>(G) + ((m_begin + row) * g.N + n0 + half * 128 + gch * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (i * NW + wave) * 4 + rli;
+        const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+        px[i] = reinterpret_cast<const char*>(X) + ((m_begin + row) * g.Cs + c0 + gch * 8) * 2;
+    }
+    const long step_g = 128L * g.N, step_x = 128L * g.Cs;                 // 64 rows x 2 bytes
+    auto stage = [&](int buf) {
+        char* sb = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int q = i * NW + wave;
+            GLDS16W(pg[i], sb + (q >> 4) * HALF + (q & 15) * 1024);
+            pg[i] += step_g;
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            GLDS16W(px[i], sb + NH * HALF + (i * NW + wave) * 1024);
+            px[i] += step_x;
+        }
+    };
+
+    // ---- fragment reads: fixed per-lane offsets inside a stage
+    const int wm = wave >> 1, wn = wave & 1;                              // wm: 64-column group of n, wn: of c
+    unsigned ao[4], bo[4];
+    {
+        const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+        const int r0 = 8 * fg + fq, key = trkey(r0);
+        const unsigned s0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ao[mi] = s0 + (wm >> 1) * HALF + r0 * 256 + ((((wm & 1) * 4 + mi) ^ key) << 5) + fp * 8;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bo[ni] = s0 + NH * HALF + r0 * 256 + (((wn * 4 + ni) ^ key) << 5) + fp * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const unsigned bofs = (unsigned)buf * STAGE_BYTES;
+        s16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { tr_read_off<0>(alo[0][mi], ao[mi] + bofs); tr_read_off<1024>(ahi[0][mi], ao[mi] + bofs); }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { tr_read_off<0>(blo[0][ni], bo[ni] + bofs); tr_read_off<1024>(bhi[0][ni], bo[ni] + bofs); }
+        tr_wait_all();
+        // second k-half's reads fly under the first half's MFMAs
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { tr_read_off<8192>(alo[1][mi], ao[mi] + bofs); tr_read_off<8192 + 1024>(ahi[1][mi], ao[mi] + bofs); }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { tr_read_off<8192>(blo[1][ni], bo[ni] + bofs); tr_read_off<8192 + 1024>(bhi[1][ni], bo[ni] + bofs); }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1) tr_wait_all();
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[kk][mi], ahi[kk][mi]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bfr[ni] = tr_pack(blo[kk][ni], bhi[kk][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nst) stage(s0);
+    int rd = 0, wr = NSTAGE - 1;
+    for (int t = 0; t < nst; ++t) {
+        // stages younger than t still in flight: NSTAGE - 2 in the steady state, fewer at the tail
+        if (t + NSTAGE - 1 <= nst) wg_wait_vmcnt_le<(NSTAGE - 2) * L>();
+        else if (NSTAGE >= 4 && t + NSTAGE - 2 <= nst) wg_wait_vmcnt_le<(NSTAGE >= 4 ? (NSTAGE - 3) * L : 0)>();
+        else wg_wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nst) stage(wr);
+        compute(rd);
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
+    // slab in accumulator order (wgrad_reduce_native_kernel<0>'s map): see wgrad_pipe_body
+    f32x4* d4 = reinterpret_cast<f32x4*>(dW + (long)zslice * g.slab_elems) + ((long)(tl * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) d4[(mi * 4 + ni) * 64] = acc[mi][ni];
+}
+
+// The same tile with the two waves of every SIMD in OPPOSITE phases (round 6; "ping-pong"): a stage is a READ phase (the lane's share of
+// the DMA for stage t + 2, all 32 transposed fragment reads of stage t, wait) and an MFMA phase (32 MFMAs), a barrier after each; waves
+// 4-7 run one barrier behind waves 0-3, so while one wave of a SIMD issues its MFMAs the other one's LDS reads and DMA requests fill the
+// issue slots between them -- in conv_wgrad_lin_kernel all eight waves read together behind the stage barrier (the first k-half's reads
+// exposed) and then all issue MFMAs together.  Barrier instance k: group A (waves 0-3) reads stage t behind instance 2t, group B behind
+// 2t + 1.  Visibility of stage t + 1: every wave waits for ITS DMA of stage t + 1 inside read phase t, i.e. before instance 2t + 1 (A) /
+// 2t + 2 (B), and the first read of stage t + 1 comes behind instance 2t + 2.  Re-use of ring slot (t + 2) % 3 = (t - 1) % 3 in read
+// phase t: the other group's reads of stage t - 1 retired (lgkmcnt(0)) before the instance this phase starts behind.  Results bit-identical.
+template <int NSTAGE>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_lin_pp_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                                   float* __restrict__ dW, WgradGeom g) {
+    static_assert(NSTAGE == 3, "the waits below are counted for a ring of three");
+    constexpr int TN = 256, NW = 8, NH = 2, HALF = 64 * 256, STAGE_BYTES = (NH + 1) * HALF, GI = 4, XI = 2, L = GI + XI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntile = g.N / TN, tiles = ntile * (g.Cs / 128);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int zslice = (idx / tiles) * 8 + xcd, tl = idx % tiles;
+    if (zslice >= g.splits) return;
+    const int n0 = (tl % ntile) * TN, c0 = (tl / ntile) * 128;
+    const long m_begin = (long)zslice * g.stages_per_split * 64;
+    const long m_end = min(g.M, m_begin + (long)g.stages_per_split * 64);
+    const int nst = (int)((m_end - m_begin) >> 6);
+    if (nst <= 0) return;
+
+    const int rli = lane >> 4, lch = lane & 15;
+    const char* pg[GI];
+    const char* px[XI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        const int q = i * NW + wave, half = q >> 4, row = (q & 15) * 4 + rli;
+        const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+        pg[i] = reinterpret_cast<const char*>(G) + ((m_begin + row) * g.N + n0 + half * 128 + gch * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (i * NW + wave) * 4 + rli;
+        const int gch = (((lch >> 1) ^ trkey(row)) << 1) | (lch & 1);
+        px[i] = reinterpret_cast<const char*>(X) + ((m_begin + row) * g.Cs + c0 + gch * 8) * 2;
+    }
+    const long step_g = 128L * g.N, step_x = 128L * g.Cs;
+    auto stage = [&](int buf) {
+        char* sb = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int q = i * NW + wave;
+            GLDS16W(pg[i], sb + (q >> 4) * HALF + (q & 15) * 1024);
+            pg[i] += step_g;
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            GLDS16W(px[i], sb + NH * HALF + (i * NW + wave) * 1024);
+            px[i] += step_x;
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned ao[4], bo[4];
+    {
+        const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+        const int r0 = 8 * fg + fq, key = trkey(r0);
+        const unsigned s0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ao[mi] = s0 + (wm >> 1) * HALF + r0 * 256 + ((((wm & 1) * 4 + mi) ^ key) << 5) + fp * 8;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bo[ni] = s0 + NH * HALF + r0 * 256 + (((wn * 4 + ni) ^ key) << 5) + fp * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0);
+    if (nst > 1) { stage(1); wg_wait_vmcnt_le<L>(); } else wg_wait_vmcnt_le<0>();     // own share of stage 0 has landed
+    const bool late = wave >= 4;                                                          // group B: one barrier behind
+    if (late) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    int rd = 0, wr = NSTAGE - 1;
+    for (int t = 0; t < nst; ++t) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- read phase
+        if (t + 2 < nst) stage(wr);
+        const unsigned bofs = (unsigned)rd * STAGE_BYTES;
+        s16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { tr_read_off<0>(alo[0][mi], ao[mi] + bofs); tr_read_off<1024>(ahi[0][mi], ao[mi] + bofs); }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { tr_read_off<0>(blo[0][ni], bo[ni] + bofs); tr_read_off<1024>(bhi[0][ni], bo[ni] + bofs); }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { tr_read_off<8192>(alo[1][mi], ao[mi] + bofs); tr_read_off<8192 + 1024>(ahi[1][mi], ao[mi] + bofs); }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { tr_read_off<8192>(blo[1][ni], bo[ni] + bofs); tr_read_off<8192 + 1024>(bhi[1][ni], bo[ni] + bofs); }
+        if (t + 2 < nst) wg_wait_vmcnt_le<L>();          // own share of stage t + 1 has landed (stage t + 2 may still fly)
+        else wg_wait_vmcnt_le<0>();
+        tr_wait_all();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA phase
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = tr_pack(alo[kk][mi], ahi[kk][mi]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bfr[ni] = tr_pack(blo[kk][ni], bhi[kk][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+        wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();             // every wave has executed 2 nst + 1 barriers
+    f32x4* d4 = reinterpret_cast<f32x4*>(dW + (long)zslice * g.slab_elems) + ((long)(tl * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) d4[(mi * 4 + ni) * 64] = acc[mi][ni];
+}
+
 // TWO 1x1 / unit-stride weight gradients of DIFFERENT shapes in one launch (round 6): conv1 of the bottleneck that just finished its
 // backward and conv3 of the next one to run become ready within ~75 us of each other (trunk_plan.hip).  Launched one after the other each
 // fills the chip with 8 tiles x 32 m-slices: 16 stages per workgroup, of whose ~35 us ~15 are fixed (first DMA round trip, address
@@ -1762,6 +2012,9 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
     if (deferred) deferred->blocks = 0;
     if (!G || !X || !dW_out || !scratch || !zero_page) return PPV_ERR_NULL;
     if (N % 128 || Cs % 128) return PPV_ERR_BAD_SIZE;
+    // DIAGNOSTIC (results wrong): PPV_WGRAD_SKIP=1 launches nothing -- what the step costs without the weight-gradient class
+    static const int skip_all = getenv("PPV_WGRAD_SKIP") ? atoi(getenv("PPV_WGRAD_SKIP")) : 0;
+    if (skip_all) return PPV_OK;
     WgradGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S; g.st = stride; g.pad = pad;
     g.M = (long)B * Ho * Wo;
@@ -1923,9 +2176,33 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
         conv_wgrad_pipe_kernel<256, 2><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
     } else if (TN == 256) {
         constexpr int lds = 3 * 3 * 64 * 256;
-        static bool attr = false;
-        if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
-        conv_wgrad_pipe_kernel<256, 3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        // 1x1 / unit stride / unpadded, whole 64-row stages: the linear-address form of the same tile (PPV_WGRAD_LIN=0 or variant bit 0x4000: the
+        // general kernel)
+        static const int lin_on = getenv("PPV_WGRAD_LIN") ? atoi(getenv("PPV_WGRAD_LIN")) : 1;
+        const bool lin = lin_on && !(g_wgrad_variant & 0x4000) && R * S == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo && !g.chunked && g.M % 64 == 0 && g.native_slabs &&
+                         !g.xcc_slabs && g.xcd_group && wgrad_debug == 0;
+        if (lin) {
+            static PpvDevOnce lin_once;
+            if (lin_once.need()) {
+                PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_lin_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                lin_once.done();
+            }
+            // PPV_WGRAD_PP / variant bit 0x8000 (toggles the default): the two waves of a SIMD in opposite phases
+            static const int pp_on = getenv("PPV_WGRAD_PP") ? atoi(getenv("PPV_WGRAD_PP")) : 0;
+            if ((pp_on != 0) != ((g_wgrad_variant & 0x8000) != 0)) {
+                static PpvDevOnce pp_once;
+                if (pp_once.need()) {
+                    PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_lin_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                    pp_once.done();
+                }
+                conv_wgrad_lin_pp_kernel<3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, g);
+            } else
+                conv_wgrad_lin_kernel<3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, g);
+        } else {
+            static bool attr = false;
+            if (!attr) { PPV_ATTR(hipFuncSetAttribute((const void*)conv_wgrad_pipe_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+            conv_wgrad_pipe_kernel<256, 3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, (const bf16_t*)zero_page, g);
+        }
     } else if (small_ring) {
         constexpr int lds = 2 * 2 * 64 * 256;
         static bool attr = false;

@@ -25,8 +25,8 @@ namespace ppv {                            // conv_gemm.hip (declared in conv_co
 void conv_set_addend_compact(bool on);
 bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N);
 // block_exec.hip: paired weight gradients across consecutive identity bottlenecks (ppv_conv_wgrad_pair)
-void wgrad_pair_begin(size_t scratch_bytes);
-int wgrad_pair_flush(hipStream_t main, hipStream_t ws);
+void wgrad_pair_begin(size_t scratch_bytes, bool defer_to_next_block);
+int wgrad_pair_flush(hipStream_t main, hipStream_t ws, bool join);
 int wgrad_pair_end(hipStream_t main, hipStream_t ws);
 }
 
@@ -305,18 +305,22 @@ int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, co
     // PPV_WGRAD_PAIR=1: conv1's weight gradient of an identity bottleneck waits for the next bottleneck's conv3 and the two run as one launch
     // (ppv_conv_wgrad_pair); flushed before every projection block and at the end of this call (a gradient bucket is complete when it returns)
     static const int pair_on = getenv("PPV_WGRAD_PAIR") ? atoi(getenv("PPV_WGRAD_PAIR")) : 0;
-    if (pair_on && !d->wgrad_reduce3) ppv::wgrad_pair_begin(L.wstride);
+    // PPV_WGRAD_FORKS=3: ONE fork per identity bottleneck (behind bn3'): conv2's and conv1's weight gradients of the bottleneck that ran before
+    // ride on it (block_exec.hip); same flush points as the pairing
+    static const int forks3 = getenv("PPV_WGRAD_FORKS") ? (atoi(getenv("PPV_WGRAD_FORKS")) == 3) : 0;
+    const bool hold = (pair_on || forks3) && !d->wgrad_reduce3;
+    if (hold) ppv::wgrad_pair_begin(pair_on ? L.wstride : 0, forks3 && !pair_on);
     struct PairGuard {
         hipStream_t m, w; bool on; int rc = PPV_OK; bool done = false;
         int finish() { if (on && !done) { done = true; rc = ppv::wgrad_pair_end(m, w); } return rc; }
         ~PairGuard() { (void)finish(); }
-    } pair_guard{main, ws, pair_on && !d->wgrad_reduce3};
+    } pair_guard{main, ws, hold};
     for (int i = blk_hi - 1; i >= blk_lo; i--) {
         const BlkOff& o = L.b[i];
         const PpvTrunkConv &k1 = conv_of(cv, i, 0), &k2 = conv_of(cv, i, 1), &k3 = conv_of(cv, i, 2), &kd = conv_of(cv, i, 3);
         const int P = o.P, C3 = 4 * P;
         const long M1 = (long)B * o.Hin * o.Win, M2 = (long)B * o.H2 * o.W2;
-        if (o.proj && pair_guard.on) TRY(ppv::wgrad_pair_flush(main, ws));
+        if (o.proj && pair_guard.on) TRY(ppv::wgrad_pair_flush(main, ws, true));
         // gradient w.r.t. this block's output (masked by its ReLU where it was produced) and whether bn3's sums came with it
         const void* g = (i == nb - 1) ? ((g_kind == 0) ? g_top : (const void*)(A + L.gtop)) : (const void*)(A + L.b[i + 1].gin);
         const int part3_ready = (i < nb - 1) && red_ok(M2, C3);

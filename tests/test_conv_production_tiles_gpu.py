@@ -315,6 +315,8 @@ WGRAD = [  # (B, H, Cin, Cout, k, stride, wgrad variant): M >= 32 768 rows -> th
     (128, 8, 2048, 512, 1, 1, 0),
     (128, 8, 512, 512, 3, 1, 0),
     (128, 32, 128, 128, 3, 1, 0),   # layer-2 3x3 at B = 128 (M = 131 072)
+    (32, 32, 1024, 256, 1, 1, 0x4000),   # round 6: the variant-0 1x1 launches above run conv_wgrad_lin_kernel; 0x4000 = the general kernel
+    (128, 8, 512, 2048, 1, 1, 0x4000),
 ]
 
 
@@ -336,6 +338,32 @@ def test_benchmark_sized_wgrad(B, H, Cin, Cout, k, stride, variant):
         co.L().ppv_wgrad_set_variant(0)
     assert got.shape == w.shape
     assert rel_err(got, w.grad) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(1, 8, 128, 256), (2, 8, 256, 256), (3, 8, 128, 512), (5, 8, 384, 256), (128, 16, 256, 1024), (128, 16, 1024, 256),
+                                          (128, 32, 512, 256), (33, 16, 256, 256)])
+def test_linear_address_wgrad_equals_the_general_kernel_bit_for_bit(B, H, Cin, Cout):
+    """conv_wgrad_lin_kernel (round 6: 1x1 / unit stride, constant pointer increments, immediate-offset transposed reads) runs the same
+    tile, ring and slab order as conv_wgrad_pipe_kernel<256, 3>: identical bits; one to a few 64-row stages exercise the ring's prologue
+    and tail (M = 64, 128, 192, 320), the layer-2 / layer-3 shapes the steady state.  Reference: autograd of the 1x1 convolutions of
+    torchvision's Bottleneck, Image_Caption/models.py:17-21."""
+    import ppv_amd.convops as co
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, H, Cin, generator=gen).bfloat16().cuda()
+    g = torch.randn(B, H, H, Cout, generator=gen).bfloat16().cuda()
+    co.zero_page(torch.device("cuda", 0))
+    a = co.conv_wgrad(g, x, 1, 1, 1, 0)
+    co.L().ppv_wgrad_set_variant(0x4000)
+    try:
+        b = co.conv_wgrad(g, x, 1, 1, 1, 0)
+        co.L().ppv_wgrad_set_variant(0x8000)       # the other scheduling of the linear kernel (waves of a SIMD in phase / in opposite phases)
+        c = co.conv_wgrad(g, x, 1, 1, 1, 0)
+    finally:
+        co.L().ppv_wgrad_set_variant(0)
+    assert torch.equal(a, b)
+    assert torch.equal(a, c)
+    ref = torch.einsum("mn,mc->nc", g.float().view(-1, Cout).cpu().double(), x.float().view(-1, Cin).cpu().double())
+    assert ((a.view(Cout, Cin).cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 
 @pytest.mark.parametrize("B,H,C", [(1, 8, 128), (2, 8, 128), (3, 8, 256), (5, 8, 128), (1, 16, 128), (3, 16, 128), (1, 32, 128), (2, 32, 256)])

@@ -64,20 +64,34 @@ print(json.dumps(res))
 ''' % ROOT
 
 
-def test_executor_with_paired_weight_gradients_equals_the_unpaired_schedule():
+def test_executor_schedules_of_the_weight_gradients_agree():
+    """The whole-trunk executor under its weight-gradient schedules -- PPV_WGRAD_PAIR=1 (paired launches), PPV_WGRAD_FORKS=0 / 1 / 3 (three,
+    two, one fork per identity bottleneck; 3 defers conv2 / conv1 to the next bottleneck's fork) -- against the default, separate
+    processes (the switches are read once)."""
     import json
-    outs = []
-    for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", _CHILD], env=dict(os.environ, PPV_WGRAD_PAIR=flag), capture_output=True, text=True, timeout=600)
+
+    def run(env):
+        r = subprocess.run([sys.executable, "-c", _CHILD], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert rows, r.stderr[-2000:]
-        outs.append(json.loads(rows[-1]))
-    a, b = outs
-    assert a.keys() == b.keys() and len(a) > 60
-    worst = 0.0
-    for k in a:
-        worst = max(worst, abs(a[k][1] - b[k][1]) / (abs(a[k][1]) + 1e-12))
-    print(f"paired vs unpaired schedule: worst relative difference of a gradient norm {worst:.1e} over {len(a)} tensors")
-    # the paired launches sum their m-slices in another order; everything else is the same arithmetic (the BatchNorm atomics give the
-    # bf16 trunk a run-to-run band of its own: norms agree to 1e-3 between ANY two runs)
-    assert worst < 5e-3
+        return json.loads(rows[-1])
+
+    def worst(u, v):
+        return max(abs(u[k][1] - v[k][1]) / (abs(u[k][1]) + 1e-12) for k in u)
+
+    a, a2 = run({}), run({})
+    band = worst(a, a2)
+    assert len(a) > 60
+    # Another launch order sums the same products (the paired launches: the m-slices in another order).  The bf16 trunk has a run-to-run
+    # band of its own at this size (f32 atomics in the BatchNorm sums of the 64 x 64 / 32 x 32 maps -> one-ulp flips -> train-mode BN:
+    # 2e-2 .. 7e-2 on a BatchNorm gradient norm between two runs of the SAME schedule), so the bound is that band; a weight gradient that
+    # is launched before its operand exists (the null-stream bug of the first pairing: 0.38 and 1.0) is far outside it.
+    for env in ({"PPV_WGRAD_PAIR": "1"}, {"PPV_WGRAD_FORKS": "0"}, {"PPV_WGRAD_FORKS": "2"}, {"PPV_WGRAD_FORKS": "3"}):
+        b = run(env)
+        assert a.keys() == b.keys()
+        diff = worst(a, b)
+        print(f"{env}: worst relative difference of a gradient norm {diff:.1e} over {len(a)} tensors; two runs of the default: {band:.1e}")
+        assert diff < 3 * band + 5e-3, env
+        for k in a:
+            if k.endswith(".weight") and "conv" in k:
+                assert b[k][1] > 0.3 * a[k][1], (env, k)

@@ -474,9 +474,8 @@ int ppv_adaptive_pool_f32_fwd(const float* x, float* y, int B, int H, int W, int
 int ppv_adaptive_pool_f32_bwd(const float* gy, float* gx, int B, int H, int W, int C, int E, ppv_stream_t stream);
 
 /* ---- camera MSE loss of the harness, Image_Caption/train.py:170-171,284-288 (`loss_cam = 1 - nn.MSELoss()(imgs, sensor)`), fused.
- * ppv_mse_fwd: out[0] = mean((a - b)^2) in one pass, deterministic (per-workgroup f64 partials, summed in index order by the last
- * workgroup); `workspace` = ppv_mse_workspace_bytes() bytes, 16-byte aligned, ZEROED ONCE by the caller at allocation (the kernel
- * leaves it ready for the next call).  ppv_mse_bwd: g_b = g_in + k (b - a), k = coef * gscalar[0] (gscalar: DEVICE scalar, the
+ * ppv_mse_fwd: out[0] = mean((a - b)^2) in one pass, deterministic (per-workgroup f64 partials, summed in index order by a
+ * one-workgroup launch); `workspace` = ppv_mse_workspace_bytes() bytes, 16-byte aligned (contents irrelevant).  ppv_mse_bwd: g_b = g_in + k (b - a), k = coef * gscalar[0] (gscalar: DEVICE scalar, the
  * gradient autograd hands to the loss; coef = 2 / n for mse, -2 / n for 1 - mse); g_in = the gradient that reaches b through its
  * other consumer (null: none), i.e. autograd's accumulation of the two gradients happens in the same pass; g_a (null: not wanted)
  * = -k (b - a).  a, b, g_* f32, n elements, 16-byte aligned. */

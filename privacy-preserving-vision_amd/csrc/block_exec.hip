@@ -8,7 +8,12 @@
 #include "ppv_common.h"
 #include "ppv_hip.h"
 
-namespace ppv { void conv_set_output_nt_once(int nt); }       // conv_gemm.hip
+namespace ppv {
+void conv_set_output_nt_once(int nt);       // conv_gemm.hip
+void bn_bwd_stop_event_once(hipEvent_t e);  // trunk_ops.hip
+bool bn_bwd_stop_event_unused();
+int fork_stop_event(hipEvent_t* out);       // trunk_plan.hip
+}
 
 extern "C" {
 
@@ -119,7 +124,29 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     const bool defer = a->wstride > 0;
     char* wsb = (char*)a->wscratch;
     // bn3 backward (gradient arrives masked by the block output's ReLU; sums possibly taken by the data-gradient launch that produced it)
+    // PPV_FORK_STOPEV (round 6; default 1, 0 = event records): the fork behind a BatchNorm-backward launch waits for an event that launch's OWN dispatch packet
+    // signals (hipExtLaunchKernel stopEvent) instead of an event-record packet enqueued behind it on the main chain
+    static const int stopev_on = getenv("PPV_FORK_STOPEV") ? atoi(getenv("PPV_FORK_STOPEV")) : 1;
+    const bool use_stop = stopev_on && side && side != main;
+    hipEvent_t ev3 = nullptr, ev2 = nullptr, ev1 = nullptr;
+    auto arm = [&](hipEvent_t& ev, bool wanted) -> int {
+        ev = nullptr;
+        if (!use_stop || !wanted) return PPV_OK;
+        if (int r = ppv::fork_stop_event(&ev)) return r;
+        ppv::bn_bwd_stop_event_once(ev);
+        return PPV_OK;
+    };
+    auto armed = [&](hipEvent_t& ev) { if (ev && ppv::bn_bwd_stop_event_unused()) ev = nullptr; };   // (not the fused apply kernel: plain fork)
+    auto fork_on = [&](hipEvent_t ev) -> int {
+        if (!side) return PPV_OK;
+        if (ev) { if (hipError_t r = hipStreamWaitEvent(side, ev, 0)) return -(int)r; return PPV_OK; }
+        return fork_to(main, side);
+    };
+    static const int fork_mode0 = getenv("PPV_WGRAD_FORKS") ? atoi(getenv("PPV_WGRAD_FORKS")) : 0;
+    const bool stop_ok = (fork_mode0 == 0 || fork_mode0 == 1) && !(a->wstride > 0) && !(t_pair_scratch > 0);     // three / two forks per block
+    if ((e = arm(ev3, stop_ok && a->dw3 != nullptr))) return e;
     if ((e = ppv_bn_bwd(a->g, nullptr, a->x3, a->c3, (double)M, a->gx3, nullptr, a->dg3, a->db3, a->part3, a->kc3, M, C3, 0, a->part3_ready ? 2 : 1, main))) return e;
+    armed(ev3);
     const bool pairing = t_pair_scratch > 0 && !defer;
     // PPV_WGRAD_FORKS (round 6 A/B): every fork is an event record on `main`, and the kernel trace shows ~6 us of idle main chain behind each
     // (none between the forward launches).  0 (default): one fork per weight gradient (three per block); 1: conv2's weight gradient waits
@@ -129,7 +156,7 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     const bool hold = t_hold_next && fork_mode == 3 && !defer && !pairing;
     const int fm = (pairing || defer) ? 0 : (fork_mode == 3 ? (hold ? 3 : 1) : fork_mode);
     if (a->dw3 && fm != 2) {
-        if (side && (e = fork_to(main, side))) return e;
+        if ((e = fork_on(ev3))) return e;
         if (pairing && t_pend.valid && t_pend.B == B &&
             ppv_conv_wgrad_pair_supported(B, t_pend.H, t_pend.W, t_pend.Cs, t_pend.N, H, W, P, C3)) {
             // conv1 of the bottleneck that ran before this one + this conv3: one launch, one reduce launch
@@ -145,22 +172,26 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     if (a->red2) e = ppv_conv_gemm_red(a->gx3, a->wd3, a->gy2, a->part2, a->x2, a->c2, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 8, main);
     else e = ppv_conv_gemm(a->gx3, a->wd3, a->gy2, nullptr, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 0, 0, main);
     if (e) return e;
+    if ((e = arm(ev2, stop_ok && fork_mode0 == 0 && a->dw2 != nullptr))) return e;
     if ((e = ppv_bn_bwd(a->gy2, nullptr, a->x2, a->c2, (double)M, a->gx2, nullptr, a->dg2, a->db2, a->part2, a->kc2, M, P, a->red2 ? 0 : 2, a->red2 ? 2 : 1, main))) return e;
+    armed(ev2);
     if (a->dw2 && fm == 0) {
-        if (side && (e = fork_to(main, side))) return e;
+        if ((e = fork_on(ev2))) return e;
         if ((e = ppv_conv_wgrad_ex(a->gx2, a->y1, a->dw2, wsb + (defer ? a->wstride : 0), a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws, defer ? &red[1] : nullptr))) return e;
     }
     // conv2 data gradient (+ bn1's sums)
     if (a->red1) e = ppv_conv_gemm_red(a->gx2, a->wd2, a->gy1, a->part1, a->x1, a->c1, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 8, main);
     else e = ppv_conv_gemm(a->gx2, a->wd2, a->gy1, nullptr, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 0, 0, main);
     if (e) return e;
+    if ((e = arm(ev1, stop_ok && (a->dw1 != nullptr || (fork_mode0 == 1 && a->dw2 != nullptr))))) return e;
     if ((e = ppv_bn_bwd(a->gy1, nullptr, a->x1, a->c1, (double)M, a->gx1, nullptr, a->dg1, a->db1, a->part1, a->kc1, M, P, a->red1 ? 0 : 2, a->red1 ? 2 : 1, main))) return e;
+    armed(ev1);
     if (fm == 3) {
         if (!a->dw3 && (e = ppv::wgrad_pair_flush(main, ws, true))) return e;          // (no fork of this block took the pending ones along)
         if (a->dw2) { t_pend2 = PendingW1{true, a->gx2, a->y1, a->zero_page, a->dw2, (void*)wsb, B, H, W, P, P, 3, 1}; }
         if (a->dw1) { t_pend = PendingW1{true, a->gx1, a->xin, a->zero_page, a->dw1, (void*)wsb, B, H, W, C3, P, 1, 0}; }
     } else if (fm != 0 && (a->dw3 || a->dw2 || a->dw1)) {
-        if (side && (e = fork_to(main, side))) return e;
+        if ((e = fork_on(fm == 1 ? ev1 : nullptr))) return e;
         if (fm == 2 && a->dw3 && (e = ppv_conv_wgrad(a->gx3, a->y2, a->dw3, wsb, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, ws))) return e;
         if (a->dw2 && (e = ppv_conv_wgrad(a->gx2, a->y1, a->dw2, wsb, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws))) return e;
         if (a->dw1 && (e = ppv_conv_wgrad(a->gx1, a->xin, a->dw1, wsb, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws))) return e;
@@ -170,7 +201,7 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
             if ((e = ppv::wgrad_pair_flush(main, ws, true))) return e;
             t_pend = PendingW1{true, a->gx1, a->xin, a->zero_page, a->dw1, (void*)wsb, B, H, W, C3, P};
         } else {
-            if (side && (e = fork_to(main, side))) return e;
+            if ((e = fork_on(ev1))) return e;
             if ((e = ppv_conv_wgrad_ex(a->gx1, a->xin, a->dw1, wsb + (defer ? 2 * a->wstride : 0), a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, ws, defer ? &red[2] : nullptr))) return e;
             if (defer && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;
         }

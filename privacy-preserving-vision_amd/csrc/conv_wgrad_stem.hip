@@ -1891,7 +1891,8 @@ static int wgrad_pf_dist() {
 static int wgrad3_target_wgs() {
     // whole step, same box: 384 -> 5177, 240 -> 5315, 192 -> 5330, 144 -> 5397, 120 -> 5395, 96 -> 5346, 72 -> 5329 images/s
     // (alone: 192 -> 77 us, 384 -> 89 us on the layer-3 shape: 16 instead of 32 nine-tap slabs)
-    static const int t = getenv("PPV_WGRAD3_WGS") ? atoi(getenv("PPV_WGRAD3_WGS")) : 144;
+    // round 6 (linear-address 1x1 kernels, stop-event forks): 144 / 96 / 72 -> 20.56 / 20.56 / 20.59 ms per step: 96 = a third fewer slab bytes
+    static const int t = getenv("PPV_WGRAD3_WGS") ? atoi(getenv("PPV_WGRAD3_WGS")) : 96;
     return t < 12 ? 12 : t;
 }
 // slabs in accumulator order + wgrad_reduce_native_kernel (PPV_WGRAD_NATIVE=0: the [N][R][S][C] slabs of rounds 1-2)

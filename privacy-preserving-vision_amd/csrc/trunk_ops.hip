@@ -5,6 +5,7 @@
 // BN + ReLU + MaxPool 3x3/2, and the Encoder's AdaptiveAvgPool2d(36) on an 8x8 map (models.py:27,39-40; output is
 // already NHWC so the reference's permute disappears).  All HBM-bound: 16-byte accesses, fp32 math.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <cstring>
 #include "ppv_common.h"
@@ -1078,6 +1079,16 @@ int ppv_bn_bwd_blocks(long rows, int C) {
 // (BN + ReLU without residual; y may be null).  Writes g_x (bf16), optionally g_pre (bf16, may be
 // null), dgamma / dbeta (f32 [C], may be null).  part: scratch >= 64 * C floats; part_prezeroed 0: zeroed here, 1: the caller
 // zeroed it, 2: it already holds the [8][2][C] sums (ppv_conv_gemm_red took them while storing gy; relu must be 0).  kc: scratch 3*C.
+}  // extern "C"
+namespace ppv {
+static thread_local hipEvent_t t_stop_event = nullptr;
+// one-shot: the next fused BatchNorm-backward apply launch of this thread signals `e` from its own dispatch packet (hipExtLaunchKernel)
+void bn_bwd_stop_event_once(hipEvent_t e) { t_stop_event = e; }
+// true (and cleared) when the launch that was to take the event did not run the fused apply kernel: the caller records an event itself
+bool bn_bwd_stop_event_unused() { const bool u = t_stop_event != nullptr; t_stop_event = nullptr; return u; }
+}  // namespace ppv
+using ppv::t_stop_event;
+extern "C" {
 static int bn_bwd_impl(const void* gy, const void* y, const void* x, const float* coef, double count, void* gx, void* gpre,
                        float* dgamma, float* dbeta, float* part, float* kc, long rows, int C, int relu, int part_prezeroed,
                        const void* x2, float* part2, hipStream_t stream) {
@@ -1105,11 +1116,27 @@ static int bn_bwd_impl(const void* gy, const void* y, const void* x, const float
         const int arpp = 256 / (CS / 8);
         const long arpb = (long)arpp * iters;
         const dim3 grid((unsigned)((rows + arpb - 1) / arpb), (unsigned)(C / CS));
-#define PPV_APPLY(R, G) bn_bwd_apply_fused_kernel<R, G><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, fold_rows, nullptr, nullptr)
+        // a stop event asked for by the executor (ppv::bn_bwd_stop_event_once): the kernel's OWN dispatch packet signals it -- a fork of the
+        // weight-gradient stream then needs no event-record packet behind this launch on the main chain
+        const hipEvent_t stop_ev = t_stop_event;
+        t_stop_event = nullptr;
+#define PPV_APPLY(R, G)                                                                                                                      \
+    do {                                                                                                                                     \
+        if (stop_ev)                                                                                                                         \
+            hipExtLaunchKernelGGL((bn_bwd_apply_fused_kernel<R, G>), grid, dim3(256), 0, stream, nullptr, stop_ev, 0, g, yy, xx, (const float*)part, \
+                                  coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, fold_rows, (const bf16_t*)nullptr, (float*)nullptr); \
+        else                                                                                                                                 \
+            bn_bwd_apply_fused_kernel<R, G><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, \
+                                                                      fold_rows, nullptr, nullptr);                                           \
+    } while (0)
         if (x2) {                                               // projection-shortcut sums ride along (relu 0, no g_pre copy)
             if (relu || gpre || !part2) return PPV_ERR_BAD_SIZE;
-            bn_bwd_apply_fused_kernel<0, false, true><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C,
-                                                                             (int)arpb, fold_rows, (const bf16_t*)x2, part2);
+            if (stop_ev)
+                hipExtLaunchKernelGGL((bn_bwd_apply_fused_kernel<0, false, true>), grid, dim3(256), 0, stream, nullptr, stop_ev, 0, g, yy, xx,
+                                      (const float*)part, coef, count, ox, op, dgamma, dbeta, rows, C, (int)arpb, fold_rows, (const bf16_t*)x2, part2);
+            else
+                bn_bwd_apply_fused_kernel<0, false, true><<<grid, 256, 0, stream>>>(g, yy, xx, part, coef, count, ox, op, dgamma, dbeta, rows, C,
+                                                                                 (int)arpb, fold_rows, (const bf16_t*)x2, part2);
         } else
         if (relu == 2 && gpre) PPV_APPLY(2, true);
         else if (relu == 2) PPV_APPLY(2, false);

@@ -28,6 +28,10 @@ bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N);
 void wgrad_pair_begin(size_t scratch_bytes, bool defer_to_next_block);
 int wgrad_pair_flush(hipStream_t main, hipStream_t ws, bool join);
 int wgrad_pair_end(hipStream_t main, hipStream_t ws);
+// trunk_ops.hip: the next fused BatchNorm-backward apply launch signals an event from its own dispatch packet (see block_exec.hip)
+void bn_bwd_stop_event_once(hipEvent_t e);
+bool bn_bwd_stop_event_unused();
+int fork_stop_event(hipEvent_t* out);
 }
 
 namespace {
@@ -170,6 +174,27 @@ int fork_between(hipStream_t from, hipStream_t to) {
     return PPV_OK;
 }
 
+}  // namespace
+namespace ppv {
+// next event of a second per-device ring, for launches that signal it from their own dispatch packet (hipExtLaunchKernel's stopEvent)
+int fork_stop_event(hipEvent_t* out) {
+    static hipEvent_t ring[MAXDEV][RING];
+    static bool made[MAXDEV] = {};
+    static unsigned next[MAXDEV] = {};
+    int dev = 0;
+    if (hipError_t r = hipGetDevice(&dev)) return -(int)r;
+    if (dev < 0 || dev >= MAXDEV) return PPV_ERR_BAD_SIZE;
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    if (!made[dev]) {
+        for (auto& ev : ring[dev])
+            if (hipError_t r = hipEventCreateWithFlags(&ev, hipEventDefault)) return -(int)r;
+        made[dev] = true;
+    }
+    *out = ring[dev][next[dev]++ & (RING - 1)];
+    return PPV_OK;
+}
+}  // namespace ppv
+namespace {
 inline const PpvTrunkConv& conv_of(const PpvTrunkConv* cv, int blk, int which) { return cv[1 + 4 * blk + which]; }
 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
@@ -349,35 +374,57 @@ int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, co
             continue;
         }
         // ---- projection block (the per-kernel order of encoder.py: each weight gradient as soon as its operand exists)
+        // forks behind a BatchNorm-backward launch wait for that launch's own stop event where PPV_FORK_STOPEV (default 1) allows it
+        static const int stopev_on = getenv("PPV_FORK_STOPEV") ? atoi(getenv("PPV_FORK_STOPEV")) : 1;
+        const bool use_stop = stopev_on && side && side != main;
+        hipEvent_t sev = nullptr;
+        auto arm = [&](bool wanted) -> int {
+            sev = nullptr;
+            if (!use_stop || !wanted) return PPV_OK;
+            if (int r = ppv::fork_stop_event(&sev)) return r;
+            ppv::bn_bwd_stop_event_once(sev);
+            return PPV_OK;
+        };
+        auto fork_now = [&]() -> int {
+            if (sev && ppv::bn_bwd_stop_event_unused()) sev = nullptr;
+            if (!side) return PPV_OK;
+            if (sev) { if (hipError_t r = hipStreamWaitEvent(side, sev, 0)) return -(int)r; return PPV_OK; }
+            return fork_between(main, side);
+        };
         // bn3 backward; the shortcut's BatchNorm sees the same gradient: its sums ride along
+        TRY(arm(k3.dw != nullptr));
         TRY(ppv_bn_bwd_sums2(g, A + o.x3, (const float*)(A + o.c3), (double)M2, A + o.gx3, k3.dgamma, k3.dbeta, (float*)(A + o.p3), kc[0], M2, C3,
                              part3_ready ? 2 : 1, A + o.xd, (float*)(A + o.pd), main));
         if (k3.dw) {
-            if (side) TRY(fork_between(main, side));
+            TRY(fork_now());
             TRY(ppv_conv_wgrad(A + o.gx3, A + o.y2, k3.dw, wscr, zero_page, B, o.H2, o.W2, P, o.H2, o.W2, C3, 1, 1, 1, 0, ws));
         }
         if (red2) {
             TRY(ppv_conv_gemm_red(A + o.gx3, k3.wd, A + o.gy2, (float*)(A + o.p2), A + o.x2, (const float*)(A + o.c2), nullptr, nullptr, zero_page,
                                   B, o.H2, o.W2, C3, o.H2, o.W2, P, 1, 1, 1, 0, 1, 8, main));
+            TRY(arm(k2.dw != nullptr));
             TRY(ppv_bn_bwd(A + o.gy2, nullptr, A + o.x2, (const float*)(A + o.c2), (double)M2, A + o.gx2, nullptr, k2.dgamma, k2.dbeta, (float*)(A + o.p2), kc[1], M2, P, 0, 2, main));
         } else {
             TRY(ppv_conv_gemm(A + o.gx3, k3.wd, A + o.gy2, nullptr, nullptr, nullptr, zero_page, B, o.H2, o.W2, C3, o.H2, o.W2, P, 1, 1, 1, 0, 1, 0, 0, main));
+            TRY(arm(k2.dw != nullptr));
             TRY(ppv_bn_bwd(A + o.gy2, nullptr, A + o.x2, (const float*)(A + o.c2), (double)M2, A + o.gx2, nullptr, k2.dgamma, k2.dbeta, (float*)(A + o.p2), kc[1], M2, P, 2, 1, main));
         }
         if (k2.dw) {
-            if (side) TRY(fork_between(main, side));
+            TRY(fork_now());
             TRY(ppv_conv_wgrad(A + o.gx2, A + o.y1, k2.dw, wscr, zero_page, B, o.Hin, o.Win, P, o.H2, o.W2, P, 3, 3, o.st, 1, ws));
         }
         if (red1) {
             TRY(ppv_conv_gemm_red(A + o.gx2, k2.wd, A + o.gy1, (float*)(A + o.p1), A + o.x1, (const float*)(A + o.c1), nullptr, nullptr, zero_page,
                                   B, o.H2, o.W2, P, o.Hin, o.Win, P, 3, 3, 1, -1, o.st, 8, main));
+            TRY(arm(k1.dw != nullptr));
             TRY(ppv_bn_bwd(A + o.gy1, nullptr, A + o.x1, (const float*)(A + o.c1), (double)M1, A + o.gx1, nullptr, k1.dgamma, k1.dbeta, (float*)(A + o.p1), kc[2], M1, P, 0, 2, main));
         } else {
             TRY(ppv_conv_gemm(A + o.gx2, k2.wd, A + o.gy1, nullptr, nullptr, nullptr, zero_page, B, o.H2, o.W2, P, o.Hin, o.Win, P, 3, 3, 1, -1, o.st, 0, 0, main));
+            TRY(arm(k1.dw != nullptr));
             TRY(ppv_bn_bwd(A + o.gy1, nullptr, A + o.x1, (const float*)(A + o.c1), (double)M1, A + o.gx1, nullptr, k1.dgamma, k1.dbeta, (float*)(A + o.p1), kc[2], M1, P, 2, 1, main));
         }
         if (k1.dw) {
-            if (side) TRY(fork_between(main, side));
+            TRY(fork_now());
             TRY(ppv_conv_wgrad(A + o.gx1, xin, k1.dw, wscr, zero_page, B, o.Hin, o.Win, o.Cin, o.Hin, o.Win, P, 1, 1, 1, 0, ws));
         }
         // shortcut: its BatchNorm (sums already taken), weight gradient, data gradient; then conv1's data gradient adds it, applies the

@@ -127,7 +127,11 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     // PPV_FORK_STOPEV (round 6; default 1, 0 = event records): the fork behind a BatchNorm-backward launch waits for an event that launch's OWN dispatch packet
     // signals (hipExtLaunchKernel stopEvent) instead of an event-record packet enqueued behind it on the main chain
     static const int stopev_on = getenv("PPV_FORK_STOPEV") ? atoi(getenv("PPV_FORK_STOPEV")) : 1;
-    const bool use_stop = stopev_on && side && side != main;
+    bool use_stop = stopev_on && side && side != main;
+    if (use_stop) {                                   // a stop event does not fork a stream CAPTURE over to `side`: event records there
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_stop = false;
+    }
     hipEvent_t ev3 = nullptr, ev2 = nullptr, ev1 = nullptr;
     auto arm = [&](hipEvent_t& ev, bool wanted) -> int {
         ev = nullptr;

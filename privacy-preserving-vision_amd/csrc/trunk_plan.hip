@@ -376,7 +376,11 @@ int ppv_trunk_bwd(const PpvTrunkDesc* d, const PpvTrunkConv* cv, void* arena, co
         // ---- projection block (the per-kernel order of encoder.py: each weight gradient as soon as its operand exists)
         // forks behind a BatchNorm-backward launch wait for that launch's own stop event where PPV_FORK_STOPEV (default 1) allows it
         static const int stopev_on = getenv("PPV_FORK_STOPEV") ? atoi(getenv("PPV_FORK_STOPEV")) : 1;
-        const bool use_stop = stopev_on && side && side != main;
+        bool use_stop = stopev_on && side && side != main;
+        if (use_stop) {                               // (not inside a stream capture: see block_exec.hip)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_stop = false;
+        }
         hipEvent_t sev = nullptr;
         auto arm = [&](bool wanted) -> int {
             sev = nullptr;

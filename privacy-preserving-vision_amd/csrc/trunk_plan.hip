@@ -187,7 +187,7 @@ int fork_stop_event(hipEvent_t* out) {
     std::lock_guard<std::mutex> lk(g_ring_mu);
     if (!made[dev]) {
         for (auto& ev : ring[dev])
-            if (hipError_t r = hipEventCreateWithFlags(&ev, hipEventDefault)) return -(int)r;
+            if (hipError_t r = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) return -(int)r;
         made[dev] = true;
     }
     *out = ring[dev][next[dev]++ & (RING - 1)];

@@ -13,6 +13,10 @@ void conv_set_output_nt_once(int nt);       // conv_gemm.hip
 void bn_bwd_stop_event_once(hipEvent_t e);  // trunk_ops.hip
 bool bn_bwd_stop_event_unused();
 int fork_stop_event(hipEvent_t* out);       // trunk_plan.hip
+int fork_flag_next(hipStream_t main, unsigned long long** word, unsigned long long* val);
+int fork_flag_wait(hipStream_t side, unsigned long long* word, unsigned long long val);
+int fork_flag_settle(hipStream_t main, unsigned long long* word, unsigned long long val);
+void conv_set_start_flag_once(unsigned long long* flag, unsigned long long val);   // conv_gemm.hip
 }
 
 extern "C" {
@@ -132,10 +136,26 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_stop = false;
     }
+    // PPV_FORK_FLAG=1 (round 6, opt-in: MEASURED LOSS): no packet on the main chain at all -- the side stream waits (hipStreamWaitValue64)
+    // for a value the NEXT launch of the main chain stores when it starts (trunk_plan.hip fork_flag_*).  The main chain's gaps do go, but
+    // the step is 0.35-0.8 ms SLOWER (profiles/r06_fork_ab.json): the wait-value packet holds the side queue far longer than an event
+    // wait does.  Falls back to the stop event / event record where the device cannot wait on memory, inside a capture, and in the A/B
+    // fork schedules.
+    static const int flag_on = getenv("PPV_FORK_FLAG") ? atoi(getenv("PPV_FORK_FLAG")) : 0;
+    static const int fork_mode00 = getenv("PPV_WGRAD_FORKS") ? atoi(getenv("PPV_WGRAD_FORKS")) : 0;
+    bool use_flag = flag_on && use_stop && fork_mode00 == 0 && !(a->wstride > 0) && !(t_pair_scratch > 0);   // (use_stop: two streams, no capture)
+    // a flag the side stream already waits for is ALWAYS reached: by the launch that carries it, or (any early return) by the main chain
+    struct FlagGuard {
+        hipStream_t main;
+        unsigned long long* word = nullptr;
+        unsigned long long val = 0;
+        bool pending = false;
+        ~FlagGuard() { if (pending) (void)ppv::fork_flag_settle(main, word, val); }
+    } fg{main};
     hipEvent_t ev3 = nullptr, ev2 = nullptr, ev1 = nullptr;
     auto arm = [&](hipEvent_t& ev, bool wanted) -> int {
         ev = nullptr;
-        if (!use_stop || !wanted) return PPV_OK;
+        if (!use_stop || use_flag || !wanted) return PPV_OK;
         if (int r = ppv::fork_stop_event(&ev)) return r;
         ppv::bn_bwd_stop_event_once(ev);
         return PPV_OK;
@@ -143,11 +163,25 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     auto armed = [&](hipEvent_t& ev) { if (ev && ppv::bn_bwd_stop_event_unused()) ev = nullptr; };   // (not the fused apply kernel: plain fork)
     auto fork_on = [&](hipEvent_t ev) -> int {
         if (!side) return PPV_OK;
+        if (use_flag) {
+            if (ppv::fork_flag_next(main, &fg.word, &fg.val) == PPV_OK) {
+                if (int r = ppv::fork_flag_wait(side, fg.word, fg.val)) return r;
+                fg.pending = true;
+                return PPV_OK;
+            }
+            use_flag = false;                          // (not available here: event records from now on)
+        }
         if (ev) { if (hipError_t r = hipStreamWaitEvent(side, ev, 0)) return -(int)r; return PPV_OK; }
         return fork_to(main, side);
     };
     static const int fork_mode0 = getenv("PPV_WGRAD_FORKS") ? atoi(getenv("PPV_WGRAD_FORKS")) : 0;
     const bool stop_ok = (fork_mode0 == 0 || fork_mode0 == 1) && !(a->wstride > 0) && !(t_pair_scratch > 0);     // three / two forks per block
+    // the main-chain launch behind a flag fork carries the flag; if it does not launch, the main chain stores the value itself
+    auto carry = [&]() { if (fg.pending) ppv::conv_set_start_flag_once(fg.word, fg.val); };
+    auto settled = [&](int rc) -> int {
+        if (fg.pending && rc == PPV_OK) fg.pending = false;       // launched: the kernel stores the value (otherwise ~FlagGuard does)
+        return rc;
+    };
     if ((e = arm(ev3, stop_ok && a->dw3 != nullptr))) return e;
     if ((e = ppv_bn_bwd(a->g, nullptr, a->x3, a->c3, (double)M, a->gx3, nullptr, a->dg3, a->db3, a->part3, a->kc3, M, C3, 0, a->part3_ready ? 2 : 1, main))) return e;
     armed(ev3);
@@ -173,9 +207,10 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
         }
     }
     // conv3 data gradient (+ bn2's sums and recomputed ReLU mask)
+    carry();
     if (a->red2) e = ppv_conv_gemm_red(a->gx3, a->wd3, a->gy2, a->part2, a->x2, a->c2, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 8, main);
     else e = ppv_conv_gemm(a->gx3, a->wd3, a->gy2, nullptr, nullptr, nullptr, a->zero_page, B, H, W, C3, H, W, P, 1, 1, 1, 0, 1, 0, 0, main);
-    if (e) return e;
+    if (settled(e)) return e;
     if ((e = arm(ev2, stop_ok && fork_mode0 == 0 && a->dw2 != nullptr))) return e;
     if ((e = ppv_bn_bwd(a->gy2, nullptr, a->x2, a->c2, (double)M, a->gx2, nullptr, a->dg2, a->db2, a->part2, a->kc2, M, P, a->red2 ? 0 : 2, a->red2 ? 2 : 1, main))) return e;
     armed(ev2);
@@ -184,9 +219,10 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
         if ((e = ppv_conv_wgrad_ex(a->gx2, a->y1, a->dw2, wsb + (defer ? a->wstride : 0), a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, 1, ws, defer ? &red[1] : nullptr))) return e;
     }
     // conv2 data gradient (+ bn1's sums)
+    carry();
     if (a->red1) e = ppv_conv_gemm_red(a->gx2, a->wd2, a->gy1, a->part1, a->x1, a->c1, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 8, main);
     else e = ppv_conv_gemm(a->gx2, a->wd2, a->gy1, nullptr, nullptr, nullptr, a->zero_page, B, H, W, P, H, W, P, 3, 3, 1, -1, 1, 0, 0, main);
-    if (e) return e;
+    if (settled(e)) return e;
     if ((e = arm(ev1, stop_ok && (a->dw1 != nullptr || (fork_mode0 == 1 && a->dw2 != nullptr))))) return e;
     if ((e = ppv_bn_bwd(a->gy1, nullptr, a->x1, a->c1, (double)M, a->gx1, nullptr, a->dg1, a->db1, a->part1, a->kc1, M, P, a->red1 ? 0 : 2, a->red1 ? 2 : 1, main))) return e;
     armed(ev1);
@@ -212,8 +248,9 @@ int ppv_bottleneck_bwd(const PpvBottleneckBwd* a, hipStream_t main, hipStream_t 
     }
     if (defer && !a->dw1 && (e = ppv_wgrad_reduce_multi(red, 3, ws))) return e;      // (a block whose conv1 alone is frozen)
     // conv1 data gradient + the identity branch's gradient + the block input's ReLU mask (+ the sums bn3 of the NEXT block to run needs)
-    if (a->x3_prev) return ppv_conv_gemm_red(a->gx1, a->wd1, a->gin, a->part3_prev, a->x3_prev, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 8, main);
-    return ppv_conv_gemm(a->gx1, a->wd1, a->gin, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 0, 0, main);
+    carry();
+    if (a->x3_prev) return settled(ppv_conv_gemm_red(a->gx1, a->wd1, a->gin, a->part3_prev, a->x3_prev, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 8, main));
+    return settled(ppv_conv_gemm(a->gx1, a->wd1, a->gin, nullptr, a->g, a->xin_bits, a->zero_page, B, H, W, P, H, W, C3, 1, 1, 1, 0, 1, 0, 0, main));
 }
 
 }  // extern "C"

@@ -26,7 +26,16 @@ struct ConvGeom {
     int add_lw = 0, add_lh = 0;   // != 0: the addend is COMPACT -- [B][Ho / 2][Wo / 2][N], the even-even pixels of the output map (every other
                                   // pixel adds zero), Wo = 1 << add_lw, Ho = 1 << add_lh: the projection shortcut's stride-2 data gradient
                                   // as trunk_plan.hip hands it to conv1's data gradient (conv_stream.hip only)
+    unsigned long long* start_flag = nullptr;   // != null: the launch stores start_val there when its first workgroup starts (conv_signal_start): a fork
+    unsigned long long start_val = 0;           // of the weight-gradient stream waits for it with hipStreamWaitValue64 -- no packet on the main chain
 };
+
+// The launch has STARTED, i.e. everything enqueued before it on its stream is complete and visible: tell a stream that waits for that
+// (trunk_plan.hip fork_flag_*).  One relaxed system-scope store by one lane; the memory is HSA signal memory (uncached).
+__device__ __forceinline__ void conv_signal_start(const ConvGeom& g) {
+    if (g.start_flag != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(g.start_flag, g.start_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Cooperative (grid-barrier) BatchNorm of the tile epilogue (conv_tile_epilogue.h, COOP; experiment of round 4): the
 // launch's workgroups are all resident (one per CU), leave their statistics, cross ONE grid barrier and apply train-mode BatchNorm +

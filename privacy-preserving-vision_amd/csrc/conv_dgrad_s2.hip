@@ -50,6 +50,7 @@ __global__ __launch_bounds__(512, BK == 64 ? 1 : 2) void conv_dgrad_s2_kernel(co
                                                                const bf16_t* __restrict__ zero_page, ConvGeom g, S2Tab tab,
                                                                int tiles_per_class, int tiles_n, int stat_rows,
                                                                const bf16_t* __restrict__ red_x, const float* __restrict__ red_coef) {
+    conv_signal_start(g);
     constexpr int BM = S2_BM, BN = S2_BN, NSTAGE = S2_NS, S2_LDS = s2_lds<BK>();
     constexpr int NT = 512, NWAVE = 8, ROWB = BK * 2, CH = BK / 8, RPI = 1024 / ROWB, RPR = NWAVE * RPI;
     constexpr int WN = 2, WROWS = 64, WCOLS = 64, MI = 4, NI = 4;

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                            const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                            int tiles_n, int stat_rows) {
+    conv_signal_start(g);
     constexpr int BM = 128, BK = 64, WN = 4 / WM;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;   // 16 x 16 fragments per wave
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
                                                                    const bf16_t* __restrict__ zero_page, ConvGeom g,
                                                                    int tiles_n, int stat_rows, const bf16_t* __restrict__ red_x,
                                                                    const float* __restrict__ red_coef, CoopBn cb) {
+    conv_signal_start(g);
     constexpr int NT = BM * 2, NWAVE = NT / 64;
     constexpr int ROWB = BK * 2, CH = BK / 8;                             // bytes / 16-byte chunks per staged row
     constexpr int RPI = 1024 / ROWB;                                       // rows per 1-KiB LDS-DMA wave-instruction
@@ -605,6 +607,12 @@ namespace ppv {
 void conv_set_addend_compact(bool on) { g_addend_compact = on; }
 static thread_local int g_nt_once = -1;                       // conv_set_output_nt_once: one-shot, consumed by the next conv_gemm_impl
 void conv_set_output_nt_once(int nt) { g_nt_once = nt; }
+// one-shot: the next conv_gemm_impl launch stores `val` at `flag` when it starts (ConvGeom::start_flag); consumed whatever happens.  A
+// call that returns PPV_OK has launched exactly one kernel that carries the flag; on any other status the CALLER settles the flag
+// (ppv::fork_flag_settle), or the stream that waits for it never runs again.
+static thread_local unsigned long long* g_start_flag = nullptr;
+static thread_local unsigned long long g_start_val = 0;
+void conv_set_start_flag_once(unsigned long long* flag, unsigned long long val) { g_start_flag = flag; g_start_val = val; }
 bool conv_addend_compact_supported(int B, int H, int W, int Cs, int N) {
     static const int on = getenv("PPV_ADDEND_COMPACT") ? atoi(getenv("PPV_ADDEND_COMPACT")) : 1;   // A/B: 0 = dense shortcut gradient
     if (!on || g_conv_variant != 0 || H < 2 || W < 2 || (H & (H - 1)) || (W & (W - 1))) return false;
@@ -642,6 +650,9 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g_addend_compact = false;
     const int nt_once = g_nt_once;
     g_nt_once = -1;
+    unsigned long long* const start_flag = ppv::g_start_flag;
+    const unsigned long long start_val = ppv::g_start_val;
+    ppv::g_start_flag = nullptr;
     if (!X || !Wt || !out || !zero_page) return PPV_ERR_NULL;
     if (Cs % 64 || (N % 64 && N != 16) || (div != 1 && div != 2)) return PPV_ERR_BAD_SIZE;
     if (stat_part && stat_rows < 1) return PPV_ERR_BAD_SIZE;
@@ -656,6 +667,8 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     g.chunked = 0;
     static const int nt_store = getenv("PPV_NT_STORE") ? atoi(getenv("PPV_NT_STORE")) : 1;         // A/B: 0 = ordinary output stores
     g.nt = nt_once >= 0 ? nt_once : nt_store;
+    g.start_flag = start_flag;
+    g.start_val = start_val;
     static const int conv_debug = getenv("PPV_CONV_DEBUG") ? atoi(getenv("PPV_CONV_DEBUG")) : 0;   // 1 = loads only, 2 = compute only (wrong results: timing experiments)
     if (conv_debug > 0) g.chunked = 1 + conv_debug;
     if (g_conv_variant & 0x1000) {            // layout A/B (tools/bench_layout_ab.py): flat launches on the BK = 64 tiles read a chunked source

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(HL_NT, 1) void conv3x3_halo_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ zero_page, ConvGeom g, HaloGeom hg,
                                                                 int stat_rows, const bf16_t* __restrict__ red_x,
                                                                 const float* __restrict__ red_coef, HaloBn bn = HaloBn{}) {
+    conv_signal_start(g);
     static_assert(!(BNIN && RED), "BNIN is a forward form");
     using Cfg = HaloCfg<HL_BN>;
     constexpr int MI = Cfg::MI, NI = Cfg::NI, WN = Cfg::WN, WROWS = MI * 16, WCOLS = 64, WI = Cfg::WI;
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo64_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
                                                                 const bf16_t* __restrict__ zero_page, ConvGeom g, int stat_rows,
                                                                 const bf16_t* __restrict__ red_x, const float* __restrict__ red_coef) {
+    conv_signal_start(g);
     constexpr int MI = 2, NI = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(ST_NT, 3) void conv1x1_stream_kernel(const bf16_t* 
                                                                    const unsigned char* __restrict__ mask_bits, ConvGeom g,
                                                                    int n_splits, int nspan, int stat_rows,
                                                                    const bf16_t* __restrict__ red_x, const float* __restrict__ red_coef) {
+    conv_signal_start(g);
     constexpr int ROWB = KC * 2, CH = KC / 8, RPI = 1024 / ROWB;          // bytes / 16-byte chunks per weight row; rows per LDS-DMA
     constexpr int TILE_BYTES = 64 * ROWB, LI = (64 / RPI) / ST_NLW;       // weight tile of one step; DMA instructions per loader wave
     constexpr int KK = KC / 32, MI = 2;

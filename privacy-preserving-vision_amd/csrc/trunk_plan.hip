@@ -32,6 +32,7 @@ int wgrad_pair_end(hipStream_t main, hipStream_t ws);
 void bn_bwd_stop_event_once(hipEvent_t e);
 bool bn_bwd_stop_event_unused();
 int fork_stop_event(hipEvent_t* out);
+void conv_set_start_flag_once(unsigned long long* flag, unsigned long long val);   // conv_gemm.hip
 }
 
 namespace {
@@ -191,6 +192,48 @@ int fork_stop_event(hipEvent_t* out) {
         made[dev] = true;
     }
     *out = ring[dev][next[dev]++ & (RING - 1)];
+    return PPV_OK;
+}
+// ---- forks without a packet on the main chain (round 6).  An event record behind a launch costs the main chain ~6 us of idle queue, the
+// launch's own stop event ~4.5 us (kernel traces under profiles/r06_*); a fork by FLAG costs it nothing: the weight-gradient stream waits
+// (hipStreamWaitValue64, >=) for a value that the NEXT launch of the main chain stores when its first workgroup starts (ConvGeom::start_flag)
+// -- at that moment everything enqueued before it on the main chain, the producer of the weight gradient's operand included, is complete
+// and visible.  One 64-bit HSA signal word and one counter per (device, main stream): launches of one stream start in order, so the
+// values a stream's forks wait for are reached in order; streams do not share a word.
+struct ForkFlag { hipStream_t stream; int dev; unsigned long long* word; unsigned long long next; };
+static ForkFlag g_flags[64];
+static int g_nflags = 0;
+static int g_flag_ok[MAXDEV] = {};          // 0 unknown, 1 usable, -1 not
+int fork_flag_next(hipStream_t main, unsigned long long** word, unsigned long long* val) {
+    int dev = 0;
+    if (hipError_t r = hipGetDevice(&dev)) return -(int)r;
+    if (dev < 0 || dev >= MAXDEV) return PPV_ERR_BAD_SIZE;
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    if (g_flag_ok[dev] == 0) {
+        int can = 0;
+        g_flag_ok[dev] = (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) ? 1 : -1;
+    }
+    if (g_flag_ok[dev] < 0) return PPV_ERR_INIT;
+    for (int i = 0; i < g_nflags; i++)
+        if (g_flags[i].stream == main && g_flags[i].dev == dev) { *word = g_flags[i].word; *val = ++g_flags[i].next; return PPV_OK; }
+    if (g_nflags == 64) return PPV_ERR_INIT;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess || !p) { g_flag_ok[dev] = -1; return PPV_ERR_INIT; }
+    if (hipMemset(p, 0, 8) != hipSuccess) { g_flag_ok[dev] = -1; return PPV_ERR_INIT; }
+    g_flags[g_nflags] = ForkFlag{main, dev, (unsigned long long*)p, 0};
+    *word = (unsigned long long*)p;
+    *val = ++g_flags[g_nflags].next;
+    ++g_nflags;
+    return PPV_OK;
+}
+// `side` waits until the word reaches val
+int fork_flag_wait(hipStream_t side, unsigned long long* word, unsigned long long val) {
+    if (hipError_t r = hipStreamWaitValue64(side, word, val, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull)) return -(int)r;
+    return PPV_OK;
+}
+// the launch that was to store the value did not happen: the main chain stores it itself (a packet on `main`, in stream order)
+int fork_flag_settle(hipStream_t main, unsigned long long* word, unsigned long long val) {
+    if (hipError_t r = hipStreamWriteValue64(main, word, val, 0)) return -(int)r;
     return PPV_OK;
 }
 }  // namespace ppv

@@ -66,8 +66,9 @@ print(json.dumps(res))
 
 def test_executor_schedules_of_the_weight_gradients_agree():
     """The whole-trunk executor under its weight-gradient schedules -- PPV_WGRAD_PAIR=1 (paired launches), PPV_WGRAD_FORKS=0 / 1 / 3 (three,
-    two, one fork per identity bottleneck; 3 defers conv2 / conv1 to the next bottleneck's fork), PPV_FORK_STOPEV=1 (the forks wait for the
-    BatchNorm-backward launch's own stop event) -- against the default, separate
+    two, one fork per identity bottleneck; 3 defers conv2 / conv1 to the next bottleneck's fork), the three fork mechanisms (default: the
+    BatchNorm-backward launch's own stop event; PPV_FORK_STOPEV=0: event records; PPV_FORK_FLAG=1: the side stream waits for a flag the
+    next main-chain launch stores) -- against the default, separate
     processes (the switches are read once)."""
     import json
 
@@ -87,7 +88,8 @@ def test_executor_schedules_of_the_weight_gradients_agree():
     # band of its own at this size (f32 atomics in the BatchNorm sums of the 64 x 64 / 32 x 32 maps -> one-ulp flips -> train-mode BN:
     # 2e-2 .. 7e-2 on a BatchNorm gradient norm between two runs of the SAME schedule), so the bound is that band; a weight gradient that
     # is launched before its operand exists (the null-stream bug of the first pairing: 0.38 and 1.0) is far outside it.
-    for env in ({"PPV_WGRAD_PAIR": "1"}, {"PPV_WGRAD_FORKS": "0"}, {"PPV_WGRAD_FORKS": "2"}, {"PPV_WGRAD_FORKS": "3"}, {"PPV_FORK_STOPEV": "1"}):
+    for env in ({"PPV_WGRAD_PAIR": "1"}, {"PPV_WGRAD_FORKS": "0"}, {"PPV_WGRAD_FORKS": "2"}, {"PPV_WGRAD_FORKS": "3"}, {"PPV_FORK_FLAG": "1"},
+                {"PPV_FORK_STOPEV": "0"}):
         b = run(env)
         assert a.keys() == b.keys()
         diff = worst(a, b)

@@ -936,6 +936,104 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const TG* __rest
     store8(gx + i * 8, acc);
 }
 
+// ---- round 6: the same two passes with NO per-thread index arithmetic.  The kernels above decode (b, oy, ox, c) from a flat thread index
+// (three integer divisions per thread, two more per window) for 32 bytes of output: the dense 1.36-GB f32 tensor left at 4.1 TB/s and its
+// gradient came back at 4.6 where a plain store / load stream runs at 6-6.8 (tools/micro/write_pattern.hip).  Here a workgroup owns one
+// output row (forward) / one input pixel (backward): the window bounds are wave-uniform, a lane owns four channels per 1024-channel
+// chunk, and every wave store / load is one contiguous KB.  C % 4 == 0.
+template <typename TO>
+__global__ __launch_bounds__(256) void adaptive_pool_fwd_row_kernel(const bf16_t* __restrict__ x, TO* __restrict__ y, int H, int W, int C, int E) {
+    const int oy = blockIdx.x, b = blockIdx.y;
+    const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E;
+    const bf16_t* xb = x + (long)b * H * W * C;
+    TO* ob = y + ((long)b * E + oy) * E * C;
+    // windows are one or two pixels wide / high (E >= H, W): the (up to) four taps are loaded unconditionally from clamped positions and
+    // weighted 0 / 1 -- no data-dependent control flow, so the loads of several output pixels are in flight together
+    const int hb = (h1 - h0 > 1) ? h0 + 1 : h0;
+    const float kh = (h1 - h0 > 1) ? 1.f : 0.f;
+#pragma unroll 4
+    for (int ox = 0; ox < E; ++ox) {
+        const int w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
+        const int wb = (w1 - w0 > 1) ? w0 + 1 : w0;
+        const float kw = (w1 - w0 > 1) ? 1.f : 0.f;
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll 2
+        for (int c = threadIdx.x * 4; c < C; c += 1024) {
+            const uint2 v00 = *reinterpret_cast<const uint2*>(xb + ((long)h0 * W + w0) * C + c);
+            const uint2 v01 = *reinterpret_cast<const uint2*>(xb + ((long)h0 * W + wb) * C + c);
+            const uint2 v10 = *reinterpret_cast<const uint2*>(xb + ((long)hb * W + w0) * C + c);
+            const uint2 v11 = *reinterpret_cast<const uint2*>(xb + ((long)hb * W + wb) * C + c);
+            auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+            auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+            const float k01 = kw, k10 = kh, k11 = kw * kh;
+            float a0 = lo(v00.x) + k01 * lo(v01.x) + k10 * lo(v10.x) + k11 * lo(v11.x);
+            float a1 = hi(v00.x) + k01 * hi(v01.x) + k10 * hi(v10.x) + k11 * hi(v11.x);
+            float a2 = lo(v00.y) + k01 * lo(v01.y) + k10 * lo(v10.y) + k11 * lo(v11.y);
+            float a3 = hi(v00.y) + k01 * hi(v01.y) + k10 * hi(v10.y) + k11 * hi(v11.y);
+            TO* o = ob + (long)ox * C + c;
+            if constexpr (sizeof(TO) == 4) {
+                typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                const f32x4_ r = {a0 * inv, a1 * inv, a2 * inv, a3 * inv};
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4_*>(o));     // streamed out once, far larger than the Infinity Cache
+            } else {
+                o[0] = (TO)(a0 * inv); o[1] = (TO)(a1 * inv); o[2] = (TO)(a2 * inv); o[3] = (TO)(a3 * inv);
+            }
+        }
+    }
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_px_kernel(const TG* __restrict__ gy, bf16_t* __restrict__ gx,
+                                                                   const bf16_t* __restrict__ mask_src, int H, int W, int C, int E) {
+    const int w = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // outputs whose window contains h / w, with the reciprocal of the window's extent (wave-uniform; at most MAXO per axis)
+    constexpr int MAXO = 8;
+    __shared__ int s_oy[MAXO], s_ox[MAXO];
+    __shared__ float s_iy[MAXO], s_ix[MAXO];
+    __shared__ int s_n[2];
+    if (threadIdx.x == 0) {
+        int ny = 0, nx = 0;
+        for (int oy = max(0, (h * E) / H - 1); oy <= min(E - 1, ((h + 1) * E + H - 1) / H); ++oy) {
+            const int h0 = (oy * H) / E, h1 = ((oy + 1) * H + E - 1) / E;
+            if (h >= h0 && h < h1 && ny < MAXO) { s_oy[ny] = oy; s_iy[ny] = 1.f / (float)(h1 - h0); ++ny; }
+        }
+        for (int ox = max(0, (w * E) / W - 1); ox <= min(E - 1, ((w + 1) * E + W - 1) / W); ++ox) {
+            const int w0 = (ox * W) / E, w1 = ((ox + 1) * W + E - 1) / E;
+            if (w >= w0 && w < w1 && nx < MAXO) { s_ox[nx] = ox; s_ix[nx] = 1.f / (float)(w1 - w0); ++nx; }
+        }
+        s_n[0] = ny; s_n[1] = nx;
+    }
+    __syncthreads();
+    const int ny = s_n[0], nx = s_n[1];
+    const long pix = ((long)b * H + h) * W + w;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int i = 0; i < ny; ++i) {
+            const TG* row = gy + (((long)b * E + s_oy[i]) * E) * C + c;
+            const float iy = s_iy[i];
+#pragma unroll
+            for (int j = 0; j < MAXO; ++j) {                   // (unrolled: the loads of one output row are in flight together)
+                if (j < nx) {
+                    const TG* g = row + (long)s_ox[j] * C;
+                    const float k = iy * s_ix[j];
+                    a0 += (float)g[0] * k; a1 += (float)g[1] * k; a2 += (float)g[2] * k; a3 += (float)g[3] * k;
+                }
+            }
+        }
+        if (mask_src) {                                        // ReLU backward of the tensor that was pooled (y > 0)
+            const uint2 m = *reinterpret_cast<const uint2*>(mask_src + pix * C + c);
+            if ((short)(m.x & 0xffffu) <= 0) a0 = 0.f;
+            if ((short)(m.x >> 16) <= 0) a1 = 0.f;
+            if ((short)(m.y & 0xffffu) <= 0) a2 = 0.f;
+            if ((short)(m.y >> 16) <= 0) a3 = 0.f;
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf_(a0) | ((unsigned)f2bf_(a1) << 16);
+        o.y = (unsigned)f2bf_(a2) | ((unsigned)f2bf_(a3) << 16);
+        *reinterpret_cast<uint2*>(gx + pix * C + c) = o;
+    }
+}
+
 }  // namespace ppv
 
 using namespace ppv;
@@ -1226,6 +1324,12 @@ int ppv_maxpool_bn_bwd(const void* gy, const void* y, const void* arg, const voi
 int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int E, int out_f32, hipStream_t stream) {
     if (!x || !y) return PPV_ERR_NULL;
     if (C % 8) return PPV_ERR_BAD_SIZE;
+    static const int px = env_int_("PPV_POOL_PX", 1);           // A/B: 0 = the flat-index kernels of rounds 1-5
+    if (px && C % 4 == 0 && B <= 65535 && E <= 65535 && H <= E && W <= E) {          // (windows of one or two pixels per axis)
+        if (out_f32) adaptive_pool_fwd_row_kernel<float><<<dim3(E, B), 256, 0, stream>>>((const bf16_t*)x, (float*)y, H, W, C, E);
+        else adaptive_pool_fwd_row_kernel<__bf16><<<dim3(E, B), 256, 0, stream>>>((const bf16_t*)x, (__bf16*)y, H, W, C, E);
+        return ppv_last_error();
+    }
     const long tot = (long)B * E * E * (C / 8);
     const unsigned gb = (unsigned)((tot + 255) / 256);
     if (out_f32) adaptive_pool_fwd_kernel<float><<<gb, 256, 0, stream>>>((const bf16_t*)x, (float*)y, B, H, W, C, E);
@@ -1237,6 +1341,13 @@ int ppv_adaptive_pool_fwd(const void* x, void* y, int B, int H, int W, int C, in
 int ppv_adaptive_pool_bwd(const void* gy, void* gx, const void* mask_src, int B, int H, int W, int C, int E, int g_f32,
                           hipStream_t stream) {
     if (!gy || !gx) return PPV_ERR_NULL;
+    static const int px = env_int_("PPV_POOL_PX", 1);
+    // (E <= 4 * min(H, W) + ...: at most eight windows per axis cover one input pixel)
+    if (px && C % 4 == 0 && B <= 65535 && H <= 65535 && E <= 6 * H && E <= 6 * W) {
+        if (g_f32) adaptive_pool_bwd_px_kernel<float><<<dim3(W, H, B), 256, 0, stream>>>((const float*)gy, (bf16_t*)gx, (const bf16_t*)mask_src, H, W, C, E);
+        else adaptive_pool_bwd_px_kernel<__bf16><<<dim3(W, H, B), 256, 0, stream>>>((const __bf16*)gy, (bf16_t*)gx, (const bf16_t*)mask_src, H, W, C, E);
+        return ppv_last_error();
+    }
     const long tot = (long)B * H * W * (C / 8);
     const unsigned gb = (unsigned)((tot + 255) / 256);
     if (g_f32) adaptive_pool_bwd_kernel<float><<<gb, 256, 0, stream>>>((const float*)gy, (bf16_t*)gx, (const bf16_t*)mask_src, B, H, W, C, E);

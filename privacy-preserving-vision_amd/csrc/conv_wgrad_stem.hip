@@ -543,6 +543,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_lin_kernel(const bf16_t* __
     }
     // slab in accumulator order (wgrad_reduce_native_kernel<0>'s map): see wgrad_pipe_body
     f32x4* d4 = reinterpret_cast<f32x4*>(dW + (long)zslice * g.slab_elems) + ((long)(tl * NW + wave) * 16) * 64 + lane;
+    if (g.pf_dist == 777) {                                    // DIAGNOSTIC (PPV_WGRAD_NOSLAB=1, results wrong): what the slab traffic costs the step
+        if (acc[0][0][0] == 123456.789f) d4[0] = acc[0][0];
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1891,8 +1895,7 @@ static int wgrad_pf_dist() {
 static int wgrad3_target_wgs() {
     // whole step, same box: 384 -> 5177, 240 -> 5315, 192 -> 5330, 144 -> 5397, 120 -> 5395, 96 -> 5346, 72 -> 5329 images/s
     // (alone: 192 -> 77 us, 384 -> 89 us on the layer-3 shape: 16 instead of 32 nine-tap slabs)
-    // round 6 (linear-address 1x1 kernels, stop-event forks): 144 / 96 / 72 -> 20.56 / 20.56 / 20.59 ms per step: 96 = a third fewer slab bytes
-    static const int t = getenv("PPV_WGRAD3_WGS") ? atoi(getenv("PPV_WGRAD3_WGS")) : 96;
+    static const int t = getenv("PPV_WGRAD3_WGS") ? atoi(getenv("PPV_WGRAD3_WGS")) : 144;
     return t < 12 ? 12 : t;
 }
 // slabs in accumulator order + wgrad_reduce_native_kernel (PPV_WGRAD_NATIVE=0: the [N][R][S][C] slabs of rounds 1-2)
@@ -2015,7 +2018,7 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
     if (N % 128 || Cs % 128) return PPV_ERR_BAD_SIZE;
     // DIAGNOSTIC (results wrong): PPV_WGRAD_SKIP=1 launches nothing -- what the step costs without the weight-gradient class
     static const int skip_all = getenv("PPV_WGRAD_SKIP") ? atoi(getenv("PPV_WGRAD_SKIP")) : 0;
-    if (skip_all) return PPV_OK;
+    if (skip_all == 1 || (skip_all == 2 && R * S == 9) || (skip_all == 3 && R * S == 1)) return PPV_OK;    // 2: the 3x3 ones only, 3: the 1x1 ones only
     WgradGeom g;
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.Ho = Ho; g.Wo = Wo; g.N = N; g.R = R; g.S = S; g.st = stride; g.pad = pad;
     g.M = (long)B * Ho * Wo;
@@ -2182,6 +2185,12 @@ int ppv_conv_wgrad_ex(const void* G, const void* X, float* dW_out, void* scratch
         static const int lin_on = getenv("PPV_WGRAD_LIN") ? atoi(getenv("PPV_WGRAD_LIN")) : 1;
         const bool lin = lin_on && !(g_wgrad_variant & 0x4000) && R * S == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo && !g.chunked && g.M % 64 == 0 && g.native_slabs &&
                          !g.xcc_slabs && g.xcd_group && wgrad_debug == 0;
+        static const int noslab = getenv("PPV_WGRAD_NOSLAB") ? atoi(getenv("PPV_WGRAD_NOSLAB")) : 0;
+        if (lin && noslab) {
+            g.pf_dist = 777;
+            conv_wgrad_lin_kernel<3><<<grid, 512, lds, stream>>>((const bf16_t*)G, (const bf16_t*)X, slabs, g);
+            return ppv_last_error();                       // (no reduce launch either)
+        }
         if (lin) {
             static PpvDevOnce lin_once;
             if (lin_once.need()) {

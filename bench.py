@@ -399,7 +399,9 @@ def _step_hbm(sec_per_step):
         gb = d["total_fetch_GB_per_step"] + d["total_write_GB_per_step"]
         tbs = gb / 1e3 / sec_per_step
         return {"GB_per_step_pmc": round(gb, 1), "pmc_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run", "TB_per_s": round(tbs, 2),
-                "frac_of_8TBps_peak": round(tbs / 8.0, 3), "frac_of_6.3TBps_measured_copy_rate": round(tbs / 6.3, 3)}
+                "frac_of_8TBps_peak": round(tbs / 8.0, 3), "frac_of_6.3TBps_measured_copy_rate": round(tbs / 6.3, 3),
+                "note": "the HEADLINE step (dense surface since round 6): ~6.8 GB of it are the 1.36-GB f32 output written, read by the head, and "
+                        "its gradient written and pooled back; the lazy-consumer step moves that much less"}
     pmc = _latest_profile("_pmc_traffic.json")
     d, stale = _load_profile(pmc)
     if d is None:

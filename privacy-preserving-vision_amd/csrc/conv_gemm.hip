@@ -251,7 +251,7 @@ template <int STRIDE, int N, int... Is>
 __device__ __forceinline__ void lds_read_frags(bf16x8 (&f)[N], unsigned addr, std::integer_sequence<int, Is...>) {
     (lds_read128_off<Is * STRIDE>(f[Is], addr), ...);
 }
-template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false, bool COOP = false, bool LOOK = false>
+template <int BM, int BN, int NSTAGE, int BK, int WGPCU, bool OUT_F32, bool RED = false, bool COOP = false, bool LOOK = false, bool PP = false>
 __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                                    void* __restrict__ Out, float* __restrict__ stat_part,
                                                                    const bf16_t* __restrict__ addend, const unsigned char* __restrict__ mask_bits,
@@ -495,6 +495,60 @@ __global__ __launch_bounds__(BM * 2, (BM * 2 / 256) * WGPCU) void conv_gemm_pipe
 #pragma unroll
         for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(bfA[i]), "v"(bfB[i]));
         __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (PP) {
+        // PING-PONG (round 6, variant 11; flat 1x1 launches on the one-round 256 x 128 BK64 tile): a K-step is a READ phase (this wave's
+        // share of the DMA of stage t + 2, all sixteen fragment reads of stage t, wait) and an MFMA phase (32 MFMAs), a barrier after each;
+        // waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave issues MFMAs while the other's LDS reads and DMA requests
+        // fill the slots between them (conv_wgrad_lin_pp_kernel has the hazard argument).  The plain loop has all eight waves read
+        // together behind the step barrier and then issue MFMAs together: 18.0 us for 16 steps where the loads alone take 13.5 and the
+        // fragment + MFMA side alone 12.6 (profiles/r06_1x1_ladder.json).
+        static_assert(NSTAGE == 3 && BK == 64 && NWAVE == 8, "written for the three-stage BK64 tile of eight waves");
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+        unsigned a_base[2], b_base[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned chunk = (unsigned)(((kk * 4 + fq) ^ key(fr)) * 16);
+            a_base[kk] = lds0 + (wm * WROWS + fr) * ROWB + chunk;
+            b_base[kk] = lds0 + A_BYTES + (wn * WCOLS + fr) * ROWB + chunk;
+        }
+        if (nk > 1) wait_vmcnt_le<L>();
+        else wait_vmcnt_le<0>();                                          // this wave's share of stage 0 has landed
+        const bool late = wave >= NWAVE / 2;
+        if (late) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        for (int t = 0; t < nk; ++t) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef PPV_STAMPS
+            if (t == 0) PPV_STAMP(2);
+#endif
+            // ---- read phase
+            if (t + NSTAGE - 1 < nk) stage(wr);
+            const unsigned bofs = (unsigned)rd * STAGE_BYTES;
+            bf16x8 af[2][MI], bfr[2][NI];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                lds_read_frags<16 * ROWB>(af[kk], a_base[kk] + bofs, std::make_integer_sequence<int, MI>{});
+                lds_read_frags<16 * ROWB>(bfr[kk], b_base[kk] + bofs, std::make_integer_sequence<int, NI>{});
+            }
+            if (t + NSTAGE - 1 < nk) wait_vmcnt_le<L>();                  // own share of stage t + 1 has landed (stage t + 2 may still fly)
+            else wait_vmcnt_le<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA phase
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][mi], bfr[kk][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+            wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
+        }
+        if (!late) __builtin_amdgcn_s_barrier();                          // every wave has executed 2 nk + 1 barriers
     } else
     {
     const bool do_stage = g.chunked != 3, do_comp = g.chunked != 2;       // chunked 2 / 3: timing experiments (PPV_CONV_DEBUG: loads / compute only)
@@ -761,6 +815,21 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
         if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef, CoopBn{}); \
         else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
     } while (0)
+#define PPV_LAUNCH_PIPE_PP(BM_, BN_, NS_, BK_, WG_)                                                                      \
+    do {                                                                                                                \
+        constexpr int ring = NS_ * (BM_ + BN_) * BK_ * 2, epi = BM_ * (BN_ * 2 + 32) + 4096, lds = ring > epi ? ring : epi; \
+        const int tm = (int)((g.M + BM_ - 1) / BM_), tn = N / BN_;                                                      \
+        auto kf = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, false, false, false, true>;                     \
+        auto kr = conv_gemm_pipe_kernel<BM_, BN_, NS_, BK_, WG_, false, true, false, false, true>;                      \
+        static PpvDevOnce attr_once;                                                                                    \
+        if (attr_once.need()) {                                                                                         \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds));            \
+            PPV_ATTR(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));            \
+            attr_once.done();                                                                                           \
+        }                                                                                                               \
+        if (rx) kr<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, rx, red_coef, CoopBn{}); \
+        else kf<<<tm * tn, BM_ * 2, lds, stream>>>(x, w, out, stat_part, ad, mk, z, g, tn, stat_rows, nullptr, nullptr, CoopBn{}); \
+    } while (0)
 #define PPV_LAUNCH_PIPE(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, false)
 #define PPV_LAUNCH_PIPE_R(BM_, BN_, NS_, BK_, WG_) PPV_LAUNCH_PIPE_(BM_, BN_, NS_, BK_, WG_, true)
     // variant: 0 = auto, 1 = two-stage 128-row kernel, 2 = 128 x 128 x 4 stages, 3 = 256 x 128 x 3 stages (BK 64),
@@ -783,10 +852,16 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     static const int look = getenv("PPV_CONV_LOOK") ? atoi(getenv("PPV_CONV_LOOK")) : 0;          // A/B: 1 = the look-ahead form of the one-round 256 x 128 tile
     if (v == 3 && look && !out_f32 && (g_conv_variant & 0xfff) == 0 && g.chunked != 1) v = 6;
     if (v == 6 && (out_f32 || g.chunked == 1)) v = 3;     // (forced variant 6: the f32-output / layout-experiment launches stay on the plain tile)
-    if (rx && (v < 2 || (v > 4 && v != 6))) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the production tiles only
+    // ping-pong form of the same tile (variant 11 forces it; PPV_CONV_PP=1: wherever the automatic rule picks the one-round BK64 tile):
+    // flat 1x1 launches with whole 64-channel K-steps, bf16 output, no timing mode
+    static const int pp_auto = getenv("PPV_CONV_PP") ? atoi(getenv("PPV_CONV_PP")) : 0;
+    const bool pp_ok = g.flat && !out_f32 && g.chunked == 0 && Cs % 64 == 0 && N % 128 == 0;
+    if (((g_conv_variant & 0xfff) == 11 || (v == 3 && pp_auto && (g_conv_variant & 0xfff) == 0)) && pp_ok) v = 11;     // (elsewhere: the automatic rule's tile)
+    if (rx && (v < 2 || (v > 4 && v != 6 && v != 11))) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the production tiles only
     if (v == 5) PPV_LAUNCH_PIPE(128, 128, 3, 32, 3);      // 16 KB stages, three 4-wave workgroups per CU
     else if (v == 4) PPV_LAUNCH_PIPE_R(256, 128, 3, 32, 2); // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
     else if (v == 3) PPV_LAUNCH_PIPE_R(256, 128, 3, 64, 1);
+    else if (v == 11) PPV_LAUNCH_PIPE_PP(256, 128, 3, 64, 1);
     else if (v == 6) PPV_LAUNCH_PIPE_LOOK(256, 128, 6, 32, 1);  // fragment reads of step t + 1 under the MFMAs of step t (round 6)
     else if (v == 2) PPV_LAUNCH_PIPE_R(128, 128, 4, 64, 1);
     else if (N == 16) PPV_LAUNCH(16, 4, 1);
@@ -797,6 +872,7 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
 #undef PPV_LAUNCH_PIPE_R
 #undef PPV_LAUNCH_PIPE_
 #undef PPV_LAUNCH_PIPE_LOOK
+#undef PPV_LAUNCH_PIPE_PP
     return ppv_last_error();
 }
 

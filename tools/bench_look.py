@@ -53,7 +53,7 @@ for cin, cout, h in [(1024, 256, 16), (256, 1024, 16), (512, 128, 32), (128, 512
     row = {}
     for nm, fn in (("fwd+stats", fwd), ("dgrad+sums", dg)):
         r = {}
-        for v in (0, 3, 4, 6):
+        for v in (0, 3, 4, 6, 11):
             lib.ppv_conv_set_variant(v)
             try:
                 r[f"v{v}"] = timed(fn)
@@ -65,4 +65,4 @@ for cin, cout, h in [(1024, 256, 16), (256, 1024, 16), (512, 128, 32), (128, 512
     print(cin, cout, h, row, flush=True)
 if len(sys.argv) > 1:
     json.dump({"what": "1x1 conv tiles at B = 128, us per launch (cold operands, median of 3 loops): v0 = automatic rule, v3 = <256,128,3,64,1>, "
-                       "v4 = <256,128,3,32,2>, v6 = <256,128,6,32,1> look-ahead (round 6)", "us": out}, open(sys.argv[1], "w"), indent=1)
+                       "v4 = <256,128,3,32,2>, v6 = <256,128,6,32,1> look-ahead, v11 = <256,128,3,64,1> ping-pong (round 6)", "us": out}, open(sys.argv[1], "w"), indent=1)

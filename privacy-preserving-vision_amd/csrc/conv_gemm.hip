@@ -857,10 +857,18 @@ static int conv_gemm_impl(const void* X, const void* Wt, void* out, float* stat_
     static const int pp_auto = getenv("PPV_CONV_PP") ? atoi(getenv("PPV_CONV_PP")) : 0;
     const bool pp_ok = g.flat && !out_f32 && g.chunked == 0 && Cs % 64 == 0 && N % 128 == 0;
     if (((g_conv_variant & 0xfff) == 11 || (v == 3 && pp_auto && (g_conv_variant & 0xfff) == 0)) && pp_ok) v = 11;     // (elsewhere: the automatic rule's tile)
-    if (rx && (v < 2 || (v > 4 && v != 6 && v != 11))) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the production tiles only
+    // 256 x 256 tile (variant 12 forces it where N % 256 == 0; PPV_CONV_T256=1: the one-round launches with N == 256): one workgroup covers
+    // every column of its 256 rows -- A is staged once instead of once per 128-column tile (134 instead of 201 MB at the layer-3
+    // 1024 -> 256 shape) on HALF the workgroups: longer alone, less CU time where the launch shares the chip (backward: DESIGN 4c)
+    static const int t256_auto = getenv("PPV_CONV_T256") ? atoi(getenv("PPV_CONV_T256")) : 0;
+    const bool t256_ok = N % 256 == 0 && !out_f32 && g.chunked == 0;
+    if (t256_ok && ((g_conv_variant & 0xfff) == 12 ||
+                    (v == 3 && (g_conv_variant & 0xfff) == 0 && N == 256 && (t256_auto == 1 || (t256_auto == 2 && rx))))) v = 12;
+    if (rx && (v < 2 || (v > 4 && v != 6 && v != 11 && v != 12))) return PPV_ERR_BAD_SIZE;  // the fused BN-backward sums exist in the production tiles only
     if (v == 5) PPV_LAUNCH_PIPE(128, 128, 3, 32, 3);      // 16 KB stages, three 4-wave workgroups per CU
     else if (v == 4) PPV_LAUNCH_PIPE_R(256, 128, 3, 32, 2); // 24 KB stages, two workgroups per CU (tile pro/epilogues overlap)
     else if (v == 3) PPV_LAUNCH_PIPE_R(256, 128, 3, 64, 1);
+    else if (v == 12) PPV_LAUNCH_PIPE_R(256, 256, 4, 32, 1);
     else if (v == 11) PPV_LAUNCH_PIPE_PP(256, 128, 3, 64, 1);
     else if (v == 6) PPV_LAUNCH_PIPE_LOOK(256, 128, 6, 32, 1);  // fragment reads of step t + 1 under the MFMAs of step t (round 6)
     else if (v == 2) PPV_LAUNCH_PIPE_R(128, 128, 4, 64, 1);

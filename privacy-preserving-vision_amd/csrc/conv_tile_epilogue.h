@@ -50,7 +50,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
     char* sO = smem;
     float* sStat = reinterpret_cast<float*>(smem + BM * LDO);
     constexpr int CPR = BN / 8;
-    static_assert(!RED || ((CPR == 16 || CPR == 8) && NT % CPR == 0 && !OUT_F32), "RED: 64- or 128-column bf16 tiles");
+    static_assert(!RED || ((CPR == 32 || CPR == 16 || CPR == 8) && NT % CPR == 0 && !OUT_F32), "RED: 64-, 128- or 256-column bf16 tiles");
     float ra[8], rb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) ra[k] = rb[k] = 0.f;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], char* smem, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (CPR == 8) { ra[k] += __shfl_xor(ra[k], 8, 64); rb[k] += __shfl_xor(rb[k], 8, 64); }
-            ra[k] += __shfl_xor(ra[k], 16, 64); rb[k] += __shfl_xor(rb[k], 16, 64);
+            if (CPR <= 16) { ra[k] += __shfl_xor(ra[k], 16, 64); rb[k] += __shfl_xor(rb[k], 16, 64); }
             ra[k] += __shfl_xor(ra[k], 32, 64); rb[k] += __shfl_xor(rb[k], 32, 64);
         }
         float* sRed = reinterpret_cast<float*>(smem);

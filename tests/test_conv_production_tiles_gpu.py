@@ -129,14 +129,14 @@ FORCED = [  # (B, H, Cin, Cout, k, stride): N % 128 == 0 in both directions, rag
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6, 8, 11])      # 6: look-ahead form, 11: ping-pong form of the one-round tile (round 6)
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6, 8, 11, 12])      # round 6: 6 look-ahead, 11 ping-pong form of the one-round tile, 12 the 256 x 256 tile
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", FORCED)
 def test_forced_tile_forward(variant, B, H, Cin, Cout, k, stride):
     with _variant(variant):
         _check_forward(B, H, Cin, Cout, k, stride)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6, 8, 11])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 6, 8, 11, 12])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,stride", FORCED)
 def test_forced_tile_dgrad(variant, B, H, Cin, Cout, k, stride):
     with _variant(variant):

@@ -53,7 +53,7 @@ for cin, cout, h in [(1024, 256, 16), (256, 1024, 16), (512, 128, 32), (128, 512
     row = {}
     for nm, fn in (("fwd+stats", fwd), ("dgrad+sums", dg)):
         r = {}
-        for v in (0, 3, 4, 6, 11):
+        for v in (0, 3, 4, 6, 11, 12):
             lib.ppv_conv_set_variant(v)
             try:
                 r[f"v{v}"] = timed(fn)

@@ -138,16 +138,44 @@ def _pool_tables(Hc, Wc, Eo, dev):
 
 
 def _linear(x, w, bias, out, hip):
-    """x @ w^T (+ bias): exact f32 on the matrix pipe (convops.linear_f32) where its layout rules hold (K % 16 == 0, 16-byte
-    aligned rows), the library GEMM otherwise (toy sizes; the 9490-wide transposed vocabulary layer, whose rows are not aligned)."""
+    """x @ w^T (+ bias): exact f32 on the matrix pipe (convops.linear_f32).  Its layout rules (K % 16 == 0, unit column stride, 16-byte
+    aligned rows) are met by every buffer the decoder allocates itself; operands that do not meet them (a reduction length that is not
+    a multiple of 16: models.py:199-214 has no such restriction; a column slice that starts off a 16-byte boundary) are copied into
+    zero-padded aligned buffers first -- zero columns add nothing to the products -- and a misaligned `out` is filled from a temporary.
+    hip=False (PPV_DEC_GEMM=lib) is the library A/B switch of tools/find_lib_gemm.py, never the default."""
+    if not hip:
+        if bias is None:
+            return torch.mm(x, w.t(), out=out) if out is not None else x @ w.t()
+        return torch.addmm(bias, x, w.t(), out=out) if out is not None else torch.addmm(bias, x, w.t())
     K = x.shape[1]
-    ok = (hip and K % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
-          and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (out is None or out.stride(1) == 1))
-    if ok:
-        return co.linear_f32(x, w, bias, out=out)
-    if bias is None:
-        return torch.mm(x, w.t(), out=out) if out is not None else x @ w.t()
-    return torch.addmm(bias, x, w.t(), out=out) if out is not None else torch.addmm(bias, x, w.t())
+    Kp = (K + 15) // 16 * 16
+
+    def aligned(t):
+        if t.dtype == F32 and t.shape[1] == Kp and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+            return t
+        p = torch.zeros((t.shape[0], Kp), dtype=F32, device=t.device) if Kp != K else torch.empty((t.shape[0], Kp), dtype=F32, device=t.device)
+        p[:, :K] = t
+        return p
+
+    xa, wa = aligned(x), aligned(w)
+    ba = bias
+    if ba is not None and (ba.dtype != F32 or not ba.is_contiguous() or ba.data_ptr() % 16):
+        ba = ba.float().contiguous().clone()
+    if out is not None and (out.stride(1) != 1 or out.dtype != F32):
+        out.copy_(co.linear_f32(xa, wa, ba))
+        return out
+    return co.linear_f32(xa, wa, ba, out=out)
+
+
+def _acc_outer_over_time(acc, wts, daw, hip):
+    """acc[b] += wts[:, b, :]^T @ daw[:, b, :] for every image (wts [T, B, R] attention weights, daw [T, B, E]): the geometries the one-pass
+    kernels of csrc/decoder.hip do not cover (E % 256 != 0, more than 128 decode steps).  One exact-f32 MFMA product per image through
+    _linear (was a library baddbmm_)."""
+    if not hip:
+        acc.baddbmm_(wts.permute(1, 2, 0), daw.transpose(0, 1))
+        return
+    for b in range(acc.shape[0]):
+        acc[b] += _linear(wts[:, b, :].t().contiguous().float(), daw[:, b, :].t().contiguous().float(), None, None, hip)
 
 
 def _linear_big(x, w, bias, hip):
@@ -220,7 +248,7 @@ class _DecoderFn(torch.autograd.Function):
                 mean = torch.empty((B, E), dtype=F32, device=dev)
                 check(L().ppv_decc_mean(ptr(rows), ptr(tables["gamma"]), ptr(mean), B, R, E, stream_ptr()), "ppv_decc_mean")
             else:
-                mean = torch.einsum("c,bce->be", tables["gamma"], rows.view(B, R, E).float())
+                mean = (rows.view(B, R, E).float() * tables["gamma"].view(1, R, 1)).sum(1)     # (element-wise + reduce: no library GEMM)
         else:
             R = P
             rows = torch.empty((B, R, 1, E), dtype=BF16, device=dev)
@@ -381,7 +409,7 @@ class _DecoderFn(torch.autograd.Function):
                     check(lib.ppv_decc_enc_grad(ptr(acc), ptr(dmean), ptr(BETA), ptr(DAW), ptr(order), ptr(tables["gamma"]), ptr(g_src),
                                                 int(ctx.src_dtype == BF16), B, R, E, T, stream_ptr()), "ppv_decc_enc_grad")
                 else:
-                    acc.baddbmm_(BETA.permute(1, 2, 0), DAW.transpose(0, 1))
+                    _acc_outer_over_time(acc, BETA, DAW, hip_gemm)
                     acc.add_(tables["gamma"].view(1, R, 1) * dmean.view(B, 1, E))
                     g_src[order] = acc.view((B,) + tuple(ctx.src_shape[1:])).to(ctx.src_dtype)
             else:
@@ -390,7 +418,7 @@ class _DecoderFn(torch.autograd.Function):
                     check(lib.ppv_dec_enc_grad(ptr(acc), ptr(dmean), ptr(AL), ptr(DAW), ptr(order), ptr(g_src), B, R, E, T,
                                                stream_ptr()), "ppv_dec_enc_grad")
                 else:
-                    acc.baddbmm_(AL.permute(1, 2, 0), DAW.transpose(0, 1))
+                    _acc_outer_over_time(acc, AL, DAW, hip_gemm)
                     check(lib.ppv_dec_combine(ptr(acc), ptr(dmean), ptr(order), ptr(g_src), B, R, E, stream_ptr()), "ppv_dec_combine")
                 g_src = g_src.view(ctx.src_shape)
         dwfull = dwfull.sum(0)

@@ -415,6 +415,11 @@ int ppv_corr_lookup_all(const float* const* corr_levels, const int* Hl, const in
 /* ---- FAN heat-map regressor forward, eval mode: Face-DeId/core/wing.py:178-260 (glue around ppv_conv_gemm) ------------- */
 int ppv_stem_conv6(const float* img, const void* wst, void* out, int B, int H, int W, ppv_stream_t stream);
 int ppv_fan_input(const float* x, const float* coords, float* out, int B, int Hin, int Win, int S, ppv_stream_t stream);
+/* Bilinear resize of `planes` NCHW f32 planes [Hi][Wi] -> [Ho][Wo] with torch's F.interpolate(mode='bilinear') arithmetic (both
+ * align_corners settings; scale = in / out resp. (in - 1) / (out - 1)) and its adjoint as a deterministic gather:
+ * FAN.get_heatmap_train, Face-DeId/core/wing.py:264,270. */
+int ppv_bilinear_resize_fwd(const float* x, float* y, long planes, int Hi, int Wi, int Ho, int Wo, int align_corners, ppv_stream_t stream);
+int ppv_bilinear_resize_bwd(const float* gy, float* gx, long planes, int Hi, int Wi, int Ho, int Wo, int align_corners, ppv_stream_t stream);
 int ppv_avgpool2_nhwc(const void* x, void* y, int B, int H, int W, int C, int f32, ppv_stream_t stream);   /* f32: 0 bf16 tensors, 1 f32 */
 int ppv_upsample2_add(const void* up1, const void* low, void* out, int B, int H, int W, int C, int f32, ppv_stream_t stream);
 int ppv_concat3_add(const void* o1, const void* o2, const void* o3, const void* res, void* out, long M, int n1, int n2,

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ppv_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 PPV_ERR_NULL, PPV_ERR_BAD_SIZE, PPV_ERR_INIT, PPV_ERR_WORKSPACE = -1001, -1002, -1003, -1004   # include/ppv_hip.h
 
 # name -> (restype, argtypes); mirrors include/ppv_hip.h (tests check the two agree)
@@ -56,6 +56,8 @@ PROTOTYPES = {
     "ppv_zernike_grad": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "ppv_stem_conv6": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ppv_fan_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ppv_bilinear_resize_fwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "ppv_bilinear_resize_bwd": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ppv_avgpool2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_upsample2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ppv_concat3_add": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -44,6 +44,6 @@ int ppv_init(void) {
     return PPV_OK;
 }
 
-int ppv_abi_version(void) { return 20; }   // 20: ppv_bn_f32_*, ppv_maxpool_f32_*, ppv_adaptive_pool_f32_*, ppv_conv3x3_bnin, ppv_ic_psf_set_fields_f32; 19: ppv_mse_fwd, ppv_mse_bwd; 18: ppv_adam_multi; 17: ppv_gemm_bf16x3_tn, ppv_decc_enc_grad, ppv_decc_mean, ppv_fftconv_ic_fwd_p / _bwd_p (any even patch size <= 512); 16: ppv_gemm_f32_tn; 15: ppv_gemm_f32_ws, ppv_gemm_f32_ws_plan; 14: ppv_conv_bn_relu_coop (experiment); 13: ppv_ic_psf_state_init, ppv_im2col_split, ppv_pad_split; 12: ppv_trunk_fwd, ppv_trunk_bwd, ppv_stream_fork; 11: ppv_conv_wgrad_ex, ppv_wgrad_reduce_multi; 10: ppv_bottleneck_bwd; 9: ppv_bottleneck_fwd; 8: ppv_bn_act_fold_rows; 7: ppv_ic_psf_symmetric; 6: ppv_ic_psf_mark_support; 2: mask_bits / pos_bits, decoder, SSIM, alt-corr, split-bf16 entries; 3: ppv_conv_gemm_red; 4: ppv_stem_dgrad, ppv_bn_bwd_sums2; 5: uint8 image entries (ppv_fftconv_fwd_u8, ppv_fftconv_ic_bwd_u8)
+int ppv_abi_version(void) { return 21; }   // 21: ppv_bilinear_resize_fwd / _bwd; 20: ppv_bn_f32_*, ppv_maxpool_f32_*, ppv_adaptive_pool_f32_*, ppv_conv3x3_bnin, ppv_ic_psf_set_fields_f32; 19: ppv_mse_fwd, ppv_mse_bwd; 18: ppv_adam_multi; 17: ppv_gemm_bf16x3_tn, ppv_decc_enc_grad, ppv_decc_mean, ppv_fftconv_ic_fwd_p / _bwd_p (any even patch size <= 512); 16: ppv_gemm_f32_tn; 15: ppv_gemm_f32_ws, ppv_gemm_f32_ws_plan; 14: ppv_conv_bn_relu_coop (experiment); 13: ppv_ic_psf_state_init, ppv_im2col_split, ppv_pad_split; 12: ppv_trunk_fwd, ppv_trunk_bwd, ppv_stream_fork; 11: ppv_conv_wgrad_ex, ppv_wgrad_reduce_multi; 10: ppv_bottleneck_bwd; 9: ppv_bottleneck_fwd; 8: ppv_bn_act_fold_rows; 7: ppv_ic_psf_symmetric; 6: ppv_ic_psf_mark_support; 2: mask_bits / pos_bits, decoder, SSIM, alt-corr, split-bf16 entries; 3: ppv_conv_gemm_red; 4: ppv_stem_dgrad, ppv_bn_bwd_sums2; 5: uint8 image entries (ppv_fftconv_fwd_u8, ppv_fftconv_ic_bwd_u8)
 
 }  // extern "C"

@@ -240,7 +240,92 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
 
 using namespace ppv;
 
+// ---- bilinear resize of NCHW f32 planes with autograd (round 6: FAN.get_heatmap_train's two F.interpolate calls, wing.py:264,270).
+// torch's arithmetic (aten UpSample.h area_pixel_compute_source_index): align_corners ? scale * dst, scale = (in - 1) / (out - 1)
+//                                                                                    : max(scale * (dst + 0.5) - 0.5, 0), scale = in / out
+__device__ __forceinline__ void bilin_src(int dst, float scale, int align, int in, int& i0, int& i1, float& l1) {
+    float s = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = min((int)s, in - 1);
+    i1 = min(i0 + 1, in - 1);
+    l1 = s - (float)i0;
+}
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int Hi, int Wi,
+                                                           int Ho, int Wo, float sh, float sw, int align) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * Ho * Wo) return;
+    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+    const long pl = i / ((long)Wo * Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(oy, sh, align, Hi, y0, y1, ly);
+    bilin_src(ox, sw, align, Wi, x0, x1, lx);
+    const float* p = x + pl * Hi * Wi;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    y[i] = hy * (hx * p[(long)y0 * Wi + x0] + lx * p[(long)y0 * Wi + x1]) + ly * (hx * p[(long)y1 * Wi + x0] + lx * p[(long)y1 * Wi + x1]);
+}
+// adjoint as a GATHER (deterministic, no atomics): input pixel (iy, ix) collects every output pixel whose two taps per axis include it;
+// the candidate output range per axis is bracketed from the inverse map (+-2) and each candidate re-derives its own taps
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, long planes, int Hi, int Wi,
+                                                           int Ho, int Wo, float sh, float sw, int align) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * Hi * Wi) return;
+    const int ix = (int)(i % Wi), iy = (int)((i / Wi) % Hi);
+    const long pl = i / ((long)Wi * Hi);
+    auto range = [&](int idx, float scale, int n_out, int& lo, int& hi) {
+        // outputs with source position in (idx - 1, idx + 1): dst in ((idx - 1) / scale, (idx + 1) / scale) up to the half-pixel shift
+        const float inv = scale > 0.f ? 1.f / scale : (float)n_out;
+        lo = max(0, (int)floorf(((float)idx - 1.f) * inv) - 2);
+        hi = min(n_out - 1, (int)ceilf(((float)idx + 1.f) * inv) + 2);
+        if (scale <= 0.f) { lo = 0; hi = n_out - 1; }
+    };
+    int oy_lo, oy_hi, ox_lo, ox_hi;
+    range(iy, sh, Ho, oy_lo, oy_hi);
+    range(ix, sw, Wo, ox_lo, ox_hi);
+    const float* g = gy + pl * Ho * Wo;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1;
+        float ly;
+        bilin_src(oy, sh, align, Hi, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            int x0, x1;
+            float lx;
+            bilin_src(ox, sw, align, Wi, x0, x1, lx);
+            const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+            if (wx != 0.f) row += wx * g[(long)oy * Wo + ox];
+        }
+        acc += wy * row;
+    }
+    gx[i] = acc;
+}
+
 extern "C" {
+
+static void bilin_scales(int Hi, int Wi, int Ho, int Wo, int align, float* sh, float* sw) {
+    *sh = align ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f) : (float)Hi / (float)Ho;
+    *sw = align ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) : (float)Wi / (float)Wo;
+}
+int ppv_bilinear_resize_fwd(const float* x, float* y, long planes, int Hi, int Wi, int Ho, int Wo, int align_corners, hipStream_t stream) {
+    if (!x || !y) return PPV_ERR_NULL;
+    if (planes < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return PPV_ERR_BAD_SIZE;
+    float sh, sw;
+    bilin_scales(Hi, Wi, Ho, Wo, align_corners, &sh, &sw);
+    const long tot = planes * Ho * Wo;
+    bilinear_fwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(x, y, planes, Hi, Wi, Ho, Wo, sh, sw, align_corners ? 1 : 0);
+    return ppv_last_error();
+}
+int ppv_bilinear_resize_bwd(const float* gy, float* gx, long planes, int Hi, int Wi, int Ho, int Wo, int align_corners, hipStream_t stream) {
+    if (!gy || !gx) return PPV_ERR_NULL;
+    if (planes < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return PPV_ERR_BAD_SIZE;
+    float sh, sw;
+    bilin_scales(Hi, Wi, Ho, Wo, align_corners, &sh, &sw);
+    const long tot = planes * Hi * Wi;
+    bilinear_bwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(gy, gx, planes, Hi, Wi, Ho, Wo, sh, sw, align_corners ? 1 : 0);
+    return ppv_last_error();
+}
 
 int ppv_fan_input(const float* x, const float* coords, float* out, int B, int Hin, int Win, int S, hipStream_t stream) {
     if (!x || !coords || !out) return PPV_ERR_NULL;

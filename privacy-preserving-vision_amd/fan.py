@@ -19,6 +19,12 @@ from . import convops as co
 from ._lib import check, ptr, stream_ptr
 
 
+def _coord_map(w_tail, coords):
+    """sum_c w_tail[o, c] * coords[c, h, w] -> [h, w, o]: the three CoordConv coordinate channels' contribution (a 3-term sum per output,
+    built once per weight load; element-wise, no library GEMM)."""
+    return (coords.permute(1, 2, 0).unsqueeze(-1) * w_tail.t().reshape(1, 1, w_tail.shape[1], w_tail.shape[0])).sum(2)
+
+
 def _coord_channels(h, w):
     xx = (torch.arange(h).unsqueeze(1).expand(h, w).float() / (h - 1)) * 2 - 1          # wing.py:86-90
     yy = (torch.arange(w).unsqueeze(0).expand(h, w).float() / (w - 1)) * 2 - 1
@@ -153,7 +159,7 @@ class FAN(nn.Module):
         # (the three coordinate channels are input independent) + bias, added by one broadcast element-wise pass
         wc = self.m0.coordconv.conv.weight.detach().float()                            # [256,259,1,1]
         cache["cc_w"] = co.weight_layout(wc[:, :256].contiguous(), 0)
-        cmap = torch.einsum("oc,chw->hwo", wc[:, 256:, 0, 0], _coord_channels(64, 64).to(dev))
+        cmap = _coord_map(wc[:, 256:, 0, 0], _coord_channels(64, 64).to(dev))
         cache["cc_map"] = cmap.to(torch.bfloat16).contiguous()                        # [64,64,256]
         one = torch.ones(256, device=dev)
         cache["coords64_tail"] = _coord_channels(64, 64)[1:].to(dev).contiguous()
@@ -202,7 +208,7 @@ class FAN(nn.Module):
                 cache["m0." + name] = self._block_consts_p(m)
         wc = self.m0.coordconv.conv.weight.detach().float()                            # [256,259,1,1]
         cache["cc_w"] = self._w3(wc[:, :256].contiguous())
-        cache["cc_map"] = (torch.einsum("oc,chw->hwo", wc[:, 256:, 0, 0], _coord_channels(64, 64).to(dev))
+        cache["cc_map"] = (_coord_map(wc[:, 256:, 0, 0], _coord_channels(64, 64).to(dev))
                            + self.m0.coordconv.conv.bias.detach().float()).contiguous()   # [64,64,256] f32, bias folded in
         cache["last_w"] = self._w3(self.conv_last0.weight)
         cache["end_bn"] = _bn_coef(self.bn_end0, extra_shift=self.conv_last0.bias.detach())
@@ -410,12 +416,13 @@ class FAN(nn.Module):
 
     def get_heatmap_train(self, x, b_preprocess=True, Privacy=False, delimiter=False):
         """wing.py:262-272: 0-1 normalised heat-maps WITH autograd (gradient w.r.t. ``x``)."""
-        x = F.interpolate(x, size=256, mode='bilinear')
+        from .nn_ops import bilinear_resize
+        x = bilinear_resize(x, size=256)                                    # F.interpolate(x, size=256, mode='bilinear'), wing.py:264
         outputs, _ = self.forward_train(x * 0.5 + 0.5)
         heatmaps = outputs[-1][:, :-1, :, :]
         scale_factor = x.size(2) // heatmaps.size(2)
         if b_preprocess and Privacy:
-            heatmaps = F.interpolate(heatmaps, scale_factor=scale_factor, mode='bilinear', align_corners=True)
+            heatmaps = bilinear_resize(heatmaps, scale_factor=scale_factor, align_corners=True)       # wing.py:270
             heatmaps = [heatmaps[:, :49].sum(dim=1, keepdim=True).clamp_(0, 1), heatmaps[:, 49:].sum(dim=1, keepdim=True).clamp_(0, 1)]
         return heatmaps
 

@@ -339,3 +339,45 @@ class _AdaptivePoolF32(torch.autograd.Function):
 def adaptive_avg_pool_f32(x, E):
     """nn.AdaptiveAvgPool2d((E, E)) (models.py:27) on NHWC f32 [B,H,W,C] -> [B,E,E,C] (already the layout models.py:40 permutes to)."""
     return _AdaptivePoolF32.apply(x, E)
+
+
+class _BilinearResize(torch.autograd.Function):
+    """F.interpolate(x, mode='bilinear', align_corners=...) on NCHW f32 with torch's source-index arithmetic, forward and adjoint on
+    csrc/fan.hip (ppv_bilinear_resize_fwd / _bwd: the adjoint is a deterministic gather).  Reference use: FAN.get_heatmap_train,
+    Face-DeId/core/wing.py:264 (input to 256 x 256) and :270 (heat-maps x4, align_corners=True)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align_corners):
+        from ._lib import lib, check, ptr, stream_ptr
+        xc = x.detach().float().contiguous()
+        B, C, Hi, Wi = xc.shape
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        check(lib().ppv_bilinear_resize_fwd(ptr(xc), ptr(y), B * C, Hi, Wi, Ho, Wo, int(bool(align_corners)), stream_ptr()), "ppv_bilinear_resize_fwd")
+        ctx.geom = (B, C, Hi, Wi, Ho, Wo, int(bool(align_corners)), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ._lib import lib, check, ptr, stream_ptr
+        B, C, Hi, Wi, Ho, Wo, ac, dt = ctx.geom
+        g = gy.detach().float().contiguous()
+        gx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=gy.device)
+        check(lib().ppv_bilinear_resize_bwd(ptr(g), ptr(gx), B * C, Hi, Wi, Ho, Wo, ac, stream_ptr()), "ppv_bilinear_resize_bwd")
+        return gx.to(dt), None, None, None
+
+
+def bilinear_resize(x, size=None, scale_factor=None, align_corners=False):
+    """torch.nn.functional.interpolate(x, size= / scale_factor=, mode='bilinear', align_corners=) for 4-D NCHW tensors on the HIP kernels
+    (output size floor(in * scale_factor) as torch; the sampling scale is in / out resp. (in - 1) / (out - 1), i.e. torch's behaviour
+    for `size=` and for align_corners=True -- the two forms the reference uses)."""
+    if x.dim() != 4:
+        raise ValueError("bilinear_resize: [B, C, H, W] tensors")
+    if (size is None) == (scale_factor is None):
+        raise ValueError("bilinear_resize: exactly one of size / scale_factor")
+    if size is not None:
+        Ho, Wo = (size, size) if isinstance(size, int) else tuple(size)
+    else:
+        if not align_corners and float(scale_factor) != int(scale_factor):
+            raise ValueError("bilinear_resize: fractional scale_factor with align_corners=False samples with 1 / scale_factor in torch; pass size=")
+        Ho, Wo = int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor)
+    return _BilinearResize.apply(x, int(Ho), int(Wo), bool(align_corners))

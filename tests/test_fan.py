@@ -89,3 +89,47 @@ def test_get_heatmap_train_carries_the_gradient_to_the_image():
     # the heat-maps agree to 1e-3; the gradient passes ~100 ReLU masks and two clamp(0, 1) edges, each of which flips for the few
     # activations that sit within fp32 rounding of its threshold (measured: rel L2 2.3e-2, cos 0.99974, max-norm 5e-2)
     assert rl2 < 5e-2 and cos > 0.999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hi,Wi,size,scale,align", [(64, 64, None, 4, True), (200, 180, 256, None, False), (256, 256, 256, None, False),
+                                                     (300, 340, 256, None, False), (7, 5, (19, 33), None, True), (17, 9, None, 2, False)])
+def test_bilinear_resize_equals_torch_interpolate(Hi, Wi, size, scale, align):
+    """nn_ops.bilinear_resize (round 6: the two F.interpolate calls of FAN.get_heatmap_train, wing.py:264,270, on csrc/fan.hip) against
+    torch's CPU F.interpolate: forward and the gradient to the input (a deterministic gather), up- and down-sampling, both align_corners
+    settings; the train path then patches F.interpolate to raise."""
+    import torch.nn.functional as F
+    from ppv_amd.nn_ops import bilinear_resize
+    g0 = torch.Generator().manual_seed(Hi * 31 + Wi)
+    x = torch.randn(2, 3, Hi, Wi, generator=g0)
+    xr = x.clone().requires_grad_(True)
+    kw = dict(size=size) if size is not None else dict(scale_factor=scale)
+    want = F.interpolate(xr, mode="bilinear", align_corners=align, **kw)
+    w = torch.randn(want.shape, generator=g0)
+    (want * w).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    got = bilinear_resize(xd, align_corners=align, **kw)
+    assert got.shape == want.shape
+    assert rel_err(got, want.detach()) < 1e-5
+    (got * w.cuda()).sum().backward()
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+    again = bilinear_resize(xd, align_corners=align, **kw)
+    assert torch.equal(again, got)
+
+
+@pytest.mark.gpu
+def test_get_heatmap_train_calls_no_torch_interpolate(monkeypatch):
+    import torch.nn.functional as F
+    from ppv_amd.fan import FAN
+    from fan_fill import fill_by_name
+    fan = FAN().eval()
+    fill_by_name(fan)
+    fan = fan.cuda()
+    x = torch.rand(1, 3, 200, 220, generator=torch.Generator().manual_seed(1)).cuda().requires_grad_(True)
+
+    def boom(*a, **k):
+        raise AssertionError("torch F.interpolate called inside FAN.get_heatmap_train")
+    monkeypatch.setattr(F, "interpolate", boom)
+    hm = fan.get_heatmap_train(x * 2 - 1, Privacy=True)
+    (hm[0].sum() + hm[1].sum()).backward()
+    assert hm[0].shape == (1, 1, 256, 256) and x.grad is not None and torch.isfinite(x.grad).all()
